@@ -1,0 +1,175 @@
+/*
+ * sehip.h -- C ABI of libsehip.so: the MI355X (gfx950) implementation of the cosine-embedding
+ * training + retrieval hot path of cvjena/semantic-embeddings.
+ *
+ * The reference is pure Python (Keras/TF + NumPy) and has no FFI; every entry point below names
+ * the reference Python interface it replaces (paths relative to the reference checkout) so a
+ * maintainer can bind it with ctypes -- INTEGRATION.md shows the stubs.
+ *
+ * Conventions (all entry points):
+ *   - plain C types only; every pointer is a DEVICE pointer unless marked "host";
+ *   - row-major, innermost dimension contiguous, explicit leading dimensions in ELEMENTS;
+ *   - the caller owns every buffer; scratch memory is sized by the *_workspace_bytes() queries
+ *     and passed in -- the library never allocates device memory;
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued asynchronously on it;
+ *   - return value: SE_OK (0) or a negative SE_ERR_* code; se_last_error() (thread-local text)
+ *     explains the last failure; no exceptions, no global mutable state, re-entrant;
+ *   - float32 arithmetic on the bit-exact paths follows the "canonical arithmetic" of
+ *     DESIGN.md section 3 (sequential fp32 FMA chain over k, NumPy pairwise row sums,
+ *     ascending (distance, index) order, NaN last, -0 == +0).
+ */
+#ifndef SEHIP_H
+#define SEHIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SE_OK 0
+#define SE_ERR_INVALID (-1)     /* bad argument (shape, null pointer, unsupported k ...) */
+#define SE_ERR_HIP (-2)         /* a HIP runtime call / kernel launch failed              */
+#define SE_ERR_UNSUPPORTED (-3) /* valid request that this build does not implement        */
+#define SE_ERR_WORKSPACE (-4)   /* workspace too small                                     */
+
+/* element type of the feature tensor handed to the loss kernels */
+#define SE_DTYPE_F32 0
+#define SE_DTYPE_BF16 1
+
+/* distance / similarity flavours of the all-pairs kernel */
+#define SE_METRIC_COSINE 0 /* out = -(a . b)              evaluate_retrieval.py:59  */
+#define SE_METRIC_EUCLID 1 /* out = (|a|^2 + |b|^2) - 2ab evaluate_retrieval.py:61-62 */
+#define SE_METRIC_DOT 2    /* out = a . b                 utils.py:90 (K.dot(y_pred, centroids)) */
+
+typedef void *se_stream_t; /* hipStream_t */
+
+int se_version(void);
+const char *se_last_error(void);
+/* host: name of the GPU architecture the embedded code objects were built for ("gfx950") */
+const char *se_build_arch(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Training side
+ * ------------------------------------------------------------------------------------------ */
+
+/*
+ * Fused  l2norm  +  embedding gather  +  cosine loss  (forward).
+ * Replaces: utils.l2norm (utils.py:125-127) wrapped as the model's last layer
+ *           (learn_image_embeddings.py:127-128), transform_inputs' host gather embedding[y]
+ *           (learn_image_embeddings.py:48-50), utils.inv_correlation (utils.py:44-46) and the
+ *           Keras batch mean.
+ *   x        [B, D] features (f32 or bf16, ldx elements between rows)
+ *   labels   [B] int64 class indices in [0, C)
+ *   emb      [C, D] f32 class embeddings (lde)
+ *   xhat     [B, D] f32 out: x * rsqrt(max(sum x^2, 1e-12))        (may be NULL)
+ *   inv_norm [B] f32 out: rsqrt(max(sum x^2, 1e-12))               (may be NULL)
+ *   loss_i   [B] f32 out: 1 - sum_d emb[labels[i], d] * xhat[i, d]
+ *   loss_mean[1] f32 out: mean_i loss_i, fixed summation order     (may be NULL)
+ */
+int se_cosine_loss_fwd(const void *x, int x_dtype, int64_t ldx, const int64_t *labels,
+                       const float *emb, int64_t lde, int64_t B, int64_t D, int64_t C,
+                       float *xhat, int64_t ldxhat, float *inv_norm, float *loss_i,
+                       float *loss_mean, se_stream_t stream);
+
+/*
+ * Backward of the above (what TF autodiff derives from utils.py:44-46,125-127):
+ *   g_i = -grad_loss_i[i] * emb[labels[i]]
+ *   dx_i = (g_i - xhat_i (xhat_i . g_i)) * inv_norm_i      where sum x^2 >= 1e-12
+ *   dx_i = g_i * inv_norm_i                                 where the max() clamp is active
+ *   x [B,D] is re-read (f32/bf16); dx is written in dx_dtype (f32/bf16).
+ *   grad_loss_i [B] f32 (upstream gradient per sample; 1/B for the plain batch mean);
+ *   if grad_loss_i is NULL, grad_scale is used for every row.
+ */
+int se_cosine_loss_bwd(const void *x, int x_dtype, int64_t ldx, const int64_t *labels,
+                       const float *emb, int64_t lde, const float *grad_loss_i, float grad_scale,
+                       int64_t B, int64_t D, int64_t C, void *dx, int dx_dtype, int64_t lddx,
+                       se_stream_t stream);
+
+/*
+ * Nearest-class-embedding accuracy metric.
+ * Replaces: utils.nn_accuracy(embedding, dot_prod_sim, k) (utils.py:57-100): the dense
+ *           contraction y_pred @ embedding.T (utils.py:90 / :78) on MFMA plus the
+ *           |best - true| < 1e-6 test (top-k: any of the k best within 1e-6).
+ *   y_pred  [B, D] f32 (already normalised when dot_prod_sim, as in the reference)
+ *   labels  [B] int64; y_true of the reference is emb[labels]
+ *   dot_prod_sim != 0: similarity = y_pred . emb^T, larger is better   (utils.py:87-95)
+ *   dot_prod_sim == 0: squared Euclidean distance, smaller is better    (utils.py:73-85)
+ *   acc     [B] f32 out (0/1)
+ *   scores  [B, C] f32 out, the similarity / distance matrix           (may be NULL)
+ *   best    [B] int32 out, argmax / argmin class (lowest index on ties) (may be NULL)
+ */
+int se_nn_accuracy(const float *y_pred, int64_t ldp, const int64_t *labels, const float *emb,
+                   int64_t lde, int64_t B, int64_t D, int64_t C, int dot_prod_sim, int k,
+                   float *acc, float *scores, int64_t lds, int32_t *best, se_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Retrieval side  (evaluate_retrieval.pairwise_retrieval, evaluate_retrieval.py:22-73)
+ * ------------------------------------------------------------------------------------------ */
+
+/* sq[i] = float32 np.sum(x[i]**2)  with NumPy's pairwise summation order, bit-exact.
+ * Replaces: `sqnorm = np.sum(features ** 2, axis = -1)`          evaluate_retrieval.py:61 */
+int se_row_sqnorm(const float *x, int64_t ldx, int64_t n, int64_t d, float *sq, se_stream_t stream);
+
+/* x[i] /= sqrt(np.sum(x[i]*x[i]))  in place, bit-exact w.r.t. float32 NumPy.
+ * Replaces: `features /= np.linalg.norm(features, axis = -1, keepdims = True)`
+ *                                                                 evaluate_retrieval.py:58 */
+int se_normalize_rows(float *x, int64_t ldx, int64_t n, int64_t d, se_stream_t stream);
+
+/*
+ * All-pairs distance matrix  out[i, j] = dist(a[i], b[j]),  i < q, j < n.
+ * Replaces: `pdist = -np.dot(features, features.T)`               evaluate_retrieval.py:59
+ *           `pdist = ne.evaluate('A + B - 2 * C', ...)`           evaluate_retrieval.py:61-62
+ * The dot product is a sequential fp32 FMA chain over k = 0..d-1 (v_mfma_f32_32x32x2_f32),
+ * bit-identical to the OpenBLAS sgemm/ssyrk result the reference obtains for d <= 448.
+ * kblocks (HOST pointer, may be NULL): K-block lengths summing to d; the chain restarts from 0
+ * at each block and block results are added in order (OpenBLAS behaviour for large d).
+ *   sqa [q], sqb [n]: row square norms, required for SE_METRIC_EUCLID only.
+ */
+int se_pairwise_dist(const float *a, int64_t lda, const float *b, int64_t ldb, const float *sqa,
+                     const float *sqb, int64_t q, int64_t n, int64_t d, int metric,
+                     const int32_t *kblocks, int nkb, float *out, int64_t ldo,
+                     se_stream_t stream);
+
+/*
+ * Full ranking of every row:  rank[i, r] = column index of the r-th smallest pdist[i, :]
+ * under the canonical order (distance ascending, index ascending; NaN last; -0 == +0).
+ * Replaces: `ranking = np.argsort(pdist, axis = -1)`              evaluate_retrieval.py:67
+ * (the reference's sort is unstable: ties are returned in canonical order here).
+ *   rank: int32 [q, n] when idx64 == 0, int64 [q, n] (NumPy's dtype) otherwise.
+ */
+int64_t se_rank_rows_workspace_bytes(int64_t q, int64_t n);
+int se_rank_rows(const float *pdist, int64_t ldp, int64_t q, int64_t n, void *rank, int idx64,
+                 int64_t ldr, void *workspace, int64_t workspace_bytes, se_stream_t stream);
+
+/*
+ * The k nearest columns of every row of a distance matrix, canonical order, with a global
+ * column offset (sharded galleries: shard r passes col_offset = first gallery row of the shard).
+ *   out_d [q, k] f32, out_i [q, k] int32 (global indices).  k <= n, k <= SE_TOPK_MAX.
+ */
+#define SE_TOPK_MAX 2048
+int se_topk_rows(const float *pdist, int64_t ldp, int64_t q, int64_t n, int64_t col_offset, int k,
+                 float *out_d, int32_t *out_i, se_stream_t stream);
+
+/*
+ * Merge per-shard top-k lists (e.g. the RCCL all-gather of every rank's se_topk_rows output)
+ * into the global top-k; the result is independent of how the gallery was sharded.
+ *   d, idx: [parts, q, k];  out_d, out_i: [q, k].  parts * k <= SE_TOPK_MAX * 4.
+ */
+int se_topk_merge(const float *d, const int32_t *idx, int parts, int64_t q, int k, float *out_d,
+                  int32_t *out_i, se_stream_t stream);
+
+/*
+ * Fused convenience driver: query tile x gallery -> distances -> top-k, never materialising
+ * more than a [q_tile, n] slab of the distance matrix in `workspace`.
+ */
+int64_t se_retrieve_topk_workspace_bytes(int64_t q, int64_t n, int k);
+int se_retrieve_topk(const float *queries, int64_t ldq, const float *gallery, int64_t ldg,
+                     const float *sqq, const float *sqg, int64_t q, int64_t n, int64_t d,
+                     int metric, int64_t col_offset, int k, float *out_d, int32_t *out_i,
+                     void *workspace, int64_t workspace_bytes, se_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEHIP_H */

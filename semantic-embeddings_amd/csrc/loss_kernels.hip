@@ -1,0 +1,390 @@
+// loss_kernels.hip -- training-side hot path.
+//
+//   se_cosine_loss_fwd : l2norm head + class-embedding gather + inv_correlation + batch mean
+//                        (reference: utils.py:125-127, learn_image_embeddings.py:48-50,127-128,
+//                         utils.py:44-46)
+//   se_cosine_loss_bwd : closed-form backward of the above
+//   se_nn_accuracy     : nearest-class-embedding accuracy, y_pred @ emb^T on
+//                        v_mfma_f32_32x32x2_f32 (reference: utils.py:57-100)
+//
+// Layout: one 64-lane wavefront owns one feature row; rows are streamed with coalesced
+// 16-byte loads (float4 / 8 x bf16) when the row pitch allows it, the two row reductions
+// (sum x^2 and x . emb[y]) are done with DPP/shuffle wave reductions -- no LDS, no atomics.
+// The kernels are HBM-bound: algorithmic bytes per row = D*s_x (x) + D*4 (emb row, L2-resident)
+// + D*4 (xhat) + 16.
+#include "se_common.h"
+
+namespace se {
+
+constexpr int LOSS_ROWS_PER_BLOCK = 4;  // 4 waves = 256 threads
+constexpr float L2NORM_EPS = 1e-12f;    // tf.nn.l2_normalize default epsilon (TF 1.x)
+
+template <bool BF16>
+__device__ __forceinline__ float load_x(const void *row, int64_t d)
+{
+    if constexpr (BF16) return bf16_to_f32(((const uint16_t *)row)[d]);
+    else return ((const float *)row)[d];
+}
+
+// ss = sum x^2, dt = sum x * t  over one row, all 64 lanes get the totals.
+template <bool BF16>
+__device__ __forceinline__ void row_reduce(const void *xrow, const float *trow, int64_t D, bool vec_ok,
+                                           float &ss, float &dt)
+{
+    const int lane = lane_id();
+    float s = 0.f, t = 0.f;
+    if (vec_ok) {
+        if constexpr (BF16) {
+            const uint4 *xv = (const uint4 *)xrow;  // 8 bf16 per 16 B
+            const float4 *tv = (const float4 *)trow;
+            for (int64_t i = lane; i < D / 8; i += WAVE) {
+                uint4 p = xv[i];
+                float4 t0 = tv[2 * i], t1 = tv[2 * i + 1];
+                uint32_t w[4] = {p.x, p.y, p.z, p.w};
+                float xs[8];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    xs[2 * j] = __uint_as_float(w[j] << 16);
+                    xs[2 * j + 1] = __uint_as_float(w[j] & 0xFFFF0000u);
+                }
+                float ts[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    s = fmaf(xs[j], xs[j], s);
+                    t = fmaf(xs[j], ts[j], t);
+                }
+            }
+        } else {
+            const float4 *xv = (const float4 *)xrow;
+            const float4 *tv = (const float4 *)trow;
+            for (int64_t i = lane; i < D / 4; i += WAVE) {
+                float4 p = xv[i], q = tv[i];
+                s = fmaf(p.x, p.x, s); s = fmaf(p.y, p.y, s); s = fmaf(p.z, p.z, s); s = fmaf(p.w, p.w, s);
+                t = fmaf(p.x, q.x, t); t = fmaf(p.y, q.y, t); t = fmaf(p.z, q.z, t); t = fmaf(p.w, q.w, t);
+            }
+        }
+    } else {
+        for (int64_t i = lane; i < D; i += WAVE) {
+            float p = load_x<BF16>(xrow, i);
+            s = fmaf(p, p, s);
+            t = fmaf(p, trow[i], t);
+        }
+    }
+    ss = wave_sum(s);
+    dt = wave_sum(t);
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(256) void cosine_loss_fwd_kernel(
+    const void *__restrict__ x, int64_t ldx, const int64_t *__restrict__ labels,
+    const float *__restrict__ emb, int64_t lde, int64_t B, int64_t D, int64_t C,
+    float *__restrict__ xhat, int64_t ldxhat, float *__restrict__ inv_norm, float *__restrict__ loss_i,
+    int vec_ok)
+{
+    const int wave = threadIdx.x >> 6, lane = lane_id();
+    for (int64_t row = (int64_t)blockIdx.x * LOSS_ROWS_PER_BLOCK + wave; row < B;
+         row += (int64_t)gridDim.x * LOSS_ROWS_PER_BLOCK) {
+        const char *xrow = (const char *)x + row * ldx * (BF16 ? 2 : 4);
+        int64_t y = labels[row];
+        y = y < 0 ? 0 : (y >= C ? C - 1 : y);  // clamp like a safe gather; host validates
+        const float *trow = emb + y * lde;
+        float ss, dt;
+        row_reduce<BF16>(xrow, trow, D, vec_ok != 0, ss, dt);
+        const float inv = 1.0f / sqrtf(fmaxf(ss, L2NORM_EPS));
+        if (lane == 0) {
+            if (inv_norm) inv_norm[row] = inv;
+            loss_i[row] = 1.0f - dt * inv;
+        }
+        if (xhat) {
+            float *orow = xhat + row * ldxhat;
+            if (vec_ok && !BF16) {
+                const float4 *xv = (const float4 *)xrow;
+                float4 *ov = (float4 *)orow;
+                for (int64_t i = lane; i < D / 4; i += WAVE) {
+                    float4 p = xv[i];
+                    ov[i] = make_float4(p.x * inv, p.y * inv, p.z * inv, p.w * inv);
+                }
+            } else {
+                for (int64_t i = lane; i < D; i += WAVE) orow[i] = load_x<BF16>(xrow, i) * inv;
+            }
+        }
+    }
+}
+
+// Deterministic mean of n floats: one 256-thread block, fixed tree.
+__global__ __launch_bounds__(256) void mean_kernel(const float *__restrict__ v, int64_t n, float *__restrict__ out)
+{
+    __shared__ float part[256];
+    float s = 0.f;
+    for (int64_t i = threadIdx.x; i < n; i += 256) s += v[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) part[threadIdx.x] += part[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = part[0] / (float)n;
+}
+
+template <bool BF16, bool DX_BF16>
+__global__ __launch_bounds__(256) void cosine_loss_bwd_kernel(
+    const void *__restrict__ x, int64_t ldx, const int64_t *__restrict__ labels,
+    const float *__restrict__ emb, int64_t lde, const float *__restrict__ grad_loss_i, float grad_scale,
+    int64_t B, int64_t D, int64_t C, void *__restrict__ dx, int64_t lddx, int vec_ok)
+{
+    const int wave = threadIdx.x >> 6, lane = lane_id();
+    for (int64_t row = (int64_t)blockIdx.x * LOSS_ROWS_PER_BLOCK + wave; row < B;
+         row += (int64_t)gridDim.x * LOSS_ROWS_PER_BLOCK) {
+        const char *xrow = (const char *)x + row * ldx * (BF16 ? 2 : 4);
+        int64_t y = labels[row];
+        y = y < 0 ? 0 : (y >= C ? C - 1 : y);
+        const float *trow = emb + y * lde;
+        float ss, dt;
+        row_reduce<BF16>(xrow, trow, D, vec_ok != 0, ss, dt);
+        const float w = grad_loss_i ? grad_loss_i[row] : grad_scale;
+        const float inv = 1.0f / sqrtf(fmaxf(ss, L2NORM_EPS));
+        const bool clamped = !(ss >= L2NORM_EPS);
+        // g = -w t ; proj = xhat . g = -w inv (x . t)
+        const float proj = clamped ? 0.f : (-w * inv * dt);
+        // dx_d = (g_d - xhat_d proj) inv = (-w t_d - x_d inv proj) inv
+        const float c_t = -w * inv;
+        const float c_x = -inv * proj * inv;
+        char *drow = (char *)dx + row * lddx * (DX_BF16 ? 2 : 4);
+        for (int64_t i = lane; i < D; i += WAVE) {
+            float v = fmaf(c_t, trow[i], c_x * load_x<BF16>(xrow, i));
+            if constexpr (DX_BF16) ((uint16_t *)drow)[i] = f32_to_bf16(v);
+            else ((float *)drow)[i] = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// nn_accuracy: one wave owns a strip of 32 samples and walks all classes in tiles of 32 with
+// v_mfma_f32_32x32x2_f32.  Operands are staged through LDS in K-chunks of 64, stored with even
+// and odd k de-interleaved so that lanes 0-31 (k = 2t) and 32-63 (k = 2t+1) each read 16 B.
+// Instead of materialising top-k, the metric uses the equivalent counting form
+//     acc = (#within >= 1) && (#better < k)
+// with  within = |score - true| < 1e-6,  better = score beyond true by >= 1e-6   (utils.py:84-95).
+// ------------------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int ACC_BK = 64;            // k per staged chunk
+constexpr int ACC_LD = ACC_BK + 4;    // padded row pitch (floats): conflict-free ds_read_b128
+
+__device__ __forceinline__ void stage_tile32(float *lds, const float *src, int64_t ld, int64_t row0,
+                                             int64_t nrows, int64_t k0, int64_t K)
+{
+    // 32 rows x 64 k, each lane moves 8 float4 (row = idx / 16, 4 consecutive k = idx % 16)
+    const int lane = lane_id();
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+        const int idx = it * 64 + lane;
+        const int r = idx >> 4, kq = (idx & 15) * 4;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (row0 + r < nrows) {
+            const float *p = src + (row0 + r) * ld + k0 + kq;
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (k0 + kq + j < K) v[j] = p[j];
+        }
+        float *o = lds + r * ACC_LD;
+        // even k -> [0, 32), odd k -> [32, 64)
+        o[(kq >> 1)] = v[0];
+        o[(kq >> 1) + 1] = v[2];
+        o[32 + (kq >> 1)] = v[1];
+        o[32 + (kq >> 1) + 1] = v[3];
+    }
+}
+
+__global__ __launch_bounds__(64) void nn_accuracy_kernel(
+    const float *__restrict__ yp, int64_t ldp, const int64_t *__restrict__ labels,
+    const float *__restrict__ emb, int64_t lde, int64_t B, int64_t D, int64_t C, int dot_prod_sim, int k,
+    float *__restrict__ acc_out, float *__restrict__ scores, int64_t lds_, int32_t *__restrict__ best_out)
+{
+    __shared__ __attribute__((aligned(16))) float sA[32 * ACC_LD];
+    __shared__ __attribute__((aligned(16))) float sB[32 * ACC_LD];
+    __shared__ float sTrue[32], sPn[32], sCn[32];
+
+    const int lane = lane_id();
+    const int col = lane & 31, hi = lane >> 5;
+    const int64_t row0 = (int64_t)blockIdx.x * 32;
+
+    // true score per sample: sum(y_pred * y_true) (utils.py:91) or sum((y_pred - y_true)^2) (:80);
+    // two lanes per row, each sums half of D sequentially.
+    {
+        const int64_t r = row0 + col;
+        float t = 0.f, pn = 0.f;
+        if (r < B) {
+            int64_t y = labels[r];
+            y = y < 0 ? 0 : (y >= C ? C - 1 : y);
+            const float *p = yp + r * ldp, *e = emb + y * lde;
+            const int64_t half = (D + 1) / 2, kb = hi ? half : 0, ke = hi ? D : half;
+            for (int64_t d = kb; d < ke; d++) {
+                const float pv = p[d], ev = e[d];
+                if (dot_prod_sim) t = fmaf(pv, ev, t);
+                else { const float df = pv - ev; t = fmaf(df, df, t); pn = fmaf(pv, pv, pn); }
+            }
+        }
+        t += __shfl_xor(t, 32, 64);
+        pn += __shfl_xor(pn, 32, 64);
+        if (hi == 0) { sTrue[col] = t; sPn[col] = pn; }
+    }
+    __syncthreads();
+
+    int n_better[16], n_within[16];
+    float best_v[16];
+    int best_c[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        n_better[r] = 0; n_within[r] = 0;
+        best_v[r] = dot_prod_sim ? -INFINITY : INFINITY;
+        best_c[r] = 0x7FFFFFFF;
+    }
+
+    for (int64_t c0 = 0; c0 < C; c0 += 32) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[r] = 0.f;
+        float cn = 0.f;  // |emb_c|^2 for this lane's class (Euclidean variant), half of D per lane
+        for (int64_t k0 = 0; k0 < D; k0 += ACC_BK) {
+            __syncthreads();
+            stage_tile32(sA, yp, ldp, row0, B, k0, D);
+            stage_tile32(sB, emb, lde, c0, C, k0, D);
+            __syncthreads();
+            const int64_t kc = (D - k0 < ACC_BK) ? (D - k0) : ACC_BK;
+            const int steps = (int)((kc + 1) / 2);           // MFMA steps (2 k each), zero padded
+            const float *pa = sA + col * ACC_LD + hi * 32;
+            const float *pb = sB + col * ACC_LD + hi * 32;
+            for (int s = 0; s < steps; s += 4) {
+                const float4 a4 = *(const float4 *)(pa + s);
+                const float4 b4 = *(const float4 *)(pb + s);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc, 0, 0, 0);
+                if (s + 1 < steps) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc, 0, 0, 0);
+                if (s + 2 < steps) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
+                if (s + 3 < steps) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
+                if (!dot_prod_sim) {
+                    cn = fmaf(b4.x, b4.x, cn);
+                    if (s + 1 < steps) cn = fmaf(b4.y, b4.y, cn);
+                    if (s + 2 < steps) cn = fmaf(b4.z, b4.z, cn);
+                    if (s + 3 < steps) cn = fmaf(b4.w, b4.w, cn);
+                }
+            }
+        }
+        if (!dot_prod_sim) {
+            cn += __shfl_xor(cn, 32, 64);
+            __syncthreads();
+            if (hi == 0) sCn[col] = cn;
+            __syncthreads();
+        }
+        const int64_t c = c0 + col;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int lr = (r & 3) + 8 * (r >> 2) + 4 * hi;  // row of this accumulator register
+            float sc = acc[r];
+            if (!dot_prod_sim) sc = (sPn[lr] + sCn[col]) - 2.0f * sc;
+            const bool valid = (c < C) && (row0 + lr < B);
+            if (valid) {
+                if (scores) scores[(row0 + lr) * lds_ + c] = sc;
+                const float diff = dot_prod_sim ? (sc - sTrue[lr]) : (sTrue[lr] - sc);  // > 0: better than true
+                if (fabsf(diff) < 1e-6f) n_within[r]++;
+                else if (diff >= 1e-6f) n_better[r]++;
+                const bool better = dot_prod_sim ? (sc > best_v[r]) : (sc < best_v[r]);
+                if (better) { best_v[r] = sc; best_c[r] = (int)c; }
+            }
+        }
+    }
+
+    // reduce over the 32 lanes (classes) that share `hi`
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+#pragma unroll
+        for (int off = 1; off < 32; off <<= 1) {
+            n_better[r] += __shfl_xor(n_better[r], off, 64);
+            n_within[r] += __shfl_xor(n_within[r], off, 64);
+            const float ov = __shfl_xor(best_v[r], off, 64);
+            const int oc = __shfl_xor(best_c[r], off, 64);
+            const bool take = dot_prod_sim ? (ov > best_v[r] || (ov == best_v[r] && oc < best_c[r]))
+                                           : (ov < best_v[r] || (ov == best_v[r] && oc < best_c[r]));
+            if (take) { best_v[r] = ov; best_c[r] = oc; }
+        }
+        const int lr = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (col == 0 && row0 + lr < B) {
+            acc_out[row0 + lr] = (n_within[r] >= 1 && n_better[r] < k) ? 1.0f : 0.0f;
+            if (best_out) best_out[row0 + lr] = best_c[r];
+        }
+    }
+}
+
+static inline bool aligned16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
+
+}  // namespace se
+
+using namespace se;
+
+extern "C" int se_cosine_loss_fwd(const void *x, int x_dtype, int64_t ldx, const int64_t *labels,
+                                  const float *emb, int64_t lde, int64_t B, int64_t D, int64_t C,
+                                  float *xhat, int64_t ldxhat, float *inv_norm, float *loss_i,
+                                  float *loss_mean, se_stream_t stream)
+{
+    if (B < 0 || D <= 0 || C <= 0) return fail(SE_ERR_INVALID, "se_cosine_loss_fwd: bad shape B=%lld D=%lld C=%lld", (long long)B, (long long)D, (long long)C);
+    if (B == 0) return SE_OK;
+    if (!x || !labels || !emb || !loss_i) return fail(SE_ERR_INVALID, "se_cosine_loss_fwd: null pointer");
+    if (ldx < D || lde < D || (xhat && ldxhat < D)) return fail(SE_ERR_INVALID, "se_cosine_loss_fwd: leading dimension < D");
+    if (x_dtype != SE_DTYPE_F32 && x_dtype != SE_DTYPE_BF16) return fail(SE_ERR_INVALID, "se_cosine_loss_fwd: bad dtype %d", x_dtype);
+    hipStream_t s = (hipStream_t)stream;
+    const bool bf = x_dtype == SE_DTYPE_BF16;
+    const int vq = bf ? 8 : 4;
+    const int vec_ok = (D % vq == 0) && (ldx % vq == 0) && (lde % 4 == 0) && aligned16(x) && aligned16(emb) &&
+                       (!xhat || ((ldxhat % 4 == 0) && aligned16(xhat)));
+    int64_t blocks = (B + LOSS_ROWS_PER_BLOCK - 1) / LOSS_ROWS_PER_BLOCK;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    if (bf) hipLaunchKernelGGL(cosine_loss_fwd_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, x, ldx, labels, emb, lde, B, D, C, xhat, ldxhat, inv_norm, loss_i, vec_ok);
+    else hipLaunchKernelGGL(cosine_loss_fwd_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, x, ldx, labels, emb, lde, B, D, C, xhat, ldxhat, inv_norm, loss_i, vec_ok);
+    SE_LAUNCH_CHECK();
+    if (loss_mean) {
+        hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, s, (const float *)loss_i, B, loss_mean);
+        SE_LAUNCH_CHECK();
+    }
+    return SE_OK;
+}
+
+extern "C" int se_cosine_loss_bwd(const void *x, int x_dtype, int64_t ldx, const int64_t *labels,
+                                  const float *emb, int64_t lde, const float *grad_loss_i, float grad_scale,
+                                  int64_t B, int64_t D, int64_t C, void *dx, int dx_dtype, int64_t lddx,
+                                  se_stream_t stream)
+{
+    if (B < 0 || D <= 0 || C <= 0) return fail(SE_ERR_INVALID, "se_cosine_loss_bwd: bad shape");
+    if (B == 0) return SE_OK;
+    if (!x || !labels || !emb || !dx) return fail(SE_ERR_INVALID, "se_cosine_loss_bwd: null pointer");
+    if (ldx < D || lde < D || lddx < D) return fail(SE_ERR_INVALID, "se_cosine_loss_bwd: leading dimension < D");
+    hipStream_t s = (hipStream_t)stream;
+    const bool bf = x_dtype == SE_DTYPE_BF16, dbf = dx_dtype == SE_DTYPE_BF16;
+    if ((x_dtype != SE_DTYPE_F32 && !bf) || (dx_dtype != SE_DTYPE_F32 && !dbf)) return fail(SE_ERR_INVALID, "se_cosine_loss_bwd: bad dtype");
+    const int vq = bf ? 8 : 4;
+    const int vec_ok = (D % vq == 0) && (ldx % vq == 0) && (lde % 4 == 0) && aligned16(x) && aligned16(emb);
+    int64_t blocks = (B + LOSS_ROWS_PER_BLOCK - 1) / LOSS_ROWS_PER_BLOCK;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+#define SE_BWD(XB, DB) hipLaunchKernelGGL((cosine_loss_bwd_kernel<XB, DB>), dim3((unsigned)blocks), dim3(256), 0, s, x, ldx, labels, emb, lde, grad_loss_i, grad_scale, B, D, C, dx, lddx, vec_ok)
+    if (bf && dbf) SE_BWD(true, true);
+    else if (bf) SE_BWD(true, false);
+    else if (dbf) SE_BWD(false, true);
+    else SE_BWD(false, false);
+#undef SE_BWD
+    SE_LAUNCH_CHECK();
+    return SE_OK;
+}
+
+extern "C" int se_nn_accuracy(const float *y_pred, int64_t ldp, const int64_t *labels, const float *emb,
+                              int64_t lde, int64_t B, int64_t D, int64_t C, int dot_prod_sim, int k,
+                              float *acc, float *scores, int64_t lds, int32_t *best, se_stream_t stream)
+{
+    if (B < 0 || D <= 0 || C <= 0) return fail(SE_ERR_INVALID, "se_nn_accuracy: bad shape");
+    if (B == 0) return SE_OK;
+    if (!y_pred || !labels || !emb || !acc) return fail(SE_ERR_INVALID, "se_nn_accuracy: null pointer");
+    if (ldp < D || lde < D || (scores && lds < C)) return fail(SE_ERR_INVALID, "se_nn_accuracy: leading dimension too small");
+    if (k < 1) k = 1;
+    hipLaunchKernelGGL(nn_accuracy_kernel, dim3((unsigned)((B + 31) / 32)), dim3(64), 0, (hipStream_t)stream,
+                       y_pred, ldp, labels, emb, lde, B, D, C, dot_prod_sim, k, acc, scores, lds, best);
+    SE_LAUNCH_CHECK();
+    return SE_OK;
+}

@@ -1,0 +1,253 @@
+"""Torch-facing wrappers of the HIP hot path (device tensors in, device tensors out).
+
+Every function here calls straight through the C ABI of libsehip.so on the current torch stream;
+PyTorch only provides device memory, streams and autograd plumbing.  Reference citations are into
+the cvjena/semantic-embeddings checkout.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import (DTYPE_BF16, DTYPE_F32, METRIC_COSINE, METRIC_DOT, METRIC_EUCLID, SehipError, check, lib, ptr,
+                   require_gpu, stream_ptr)
+
+__all__ = [
+    "cosine_embedding_loss", "cosine_loss_forward", "cosine_loss_backward", "nn_accuracy",
+    "row_sqnorm", "normalize_rows_", "pairwise_dist", "rank_rows", "topk_rows", "topk_merge", "retrieve_topk",
+    "METRIC_COSINE", "METRIC_EUCLID", "METRIC_DOT",
+]
+
+
+def _dtype_code(t):
+    if t.dtype == torch.float32:
+        return DTYPE_F32
+    if t.dtype == torch.bfloat16:
+        return DTYPE_BF16
+    raise SehipError("features must be float32 or bfloat16, got %s" % t.dtype)
+
+
+def _rows(t, what):
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise SehipError("%s must be a 2-d tensor with contiguous rows" % what)
+    return t
+
+
+# --------------------------------------------------------------------------------------------
+# training side
+# --------------------------------------------------------------------------------------------
+
+def cosine_loss_forward(x, labels, embedding, want_xhat=True):
+    """Fused l2norm + gather + inv_correlation (+ batch mean).
+
+    reference: utils.l2norm (utils.py:125-127), transform_inputs (learn_image_embeddings.py:48-50),
+    utils.inv_correlation (utils.py:44-46).  Returns (xhat | None, inv_norm, loss_i, loss_mean)."""
+    require_gpu(x, labels, embedding)
+    _rows(x, "x"); _rows(embedding, "embedding")
+    B, D = x.shape
+    C = embedding.shape[0]
+    if embedding.shape[1] != D or embedding.dtype != torch.float32:
+        raise SehipError("embedding must be float32 [C, %d]" % D)
+    if labels.dtype != torch.int64 or labels.numel() != B or not labels.is_contiguous():
+        raise SehipError("labels must be a contiguous int64 [B] tensor")
+    xhat = torch.empty((B, D), dtype=torch.float32, device=x.device) if want_xhat else None
+    inv_norm = torch.empty((B,), dtype=torch.float32, device=x.device)
+    loss_i = torch.empty((B,), dtype=torch.float32, device=x.device)
+    loss_mean = torch.empty((1,), dtype=torch.float32, device=x.device)
+    check(lib().se_cosine_loss_fwd(ptr(x), _dtype_code(x), x.stride(0), ptr(labels), ptr(embedding),
+                                   embedding.stride(0), B, D, C, ptr(xhat), D, ptr(inv_norm), ptr(loss_i),
+                                   ptr(loss_mean), stream_ptr()), "se_cosine_loss_fwd")
+    return xhat, inv_norm, loss_i, loss_mean
+
+
+def cosine_loss_backward(x, labels, embedding, grad_loss_i=None, grad_scale=1.0, out_dtype=None):
+    """Closed-form backward of cosine_loss_forward w.r.t. x (what TF autodiff derives from
+    utils.py:44-46,125-127)."""
+    require_gpu(x, labels, embedding, grad_loss_i)
+    _rows(x, "x"); _rows(embedding, "embedding")
+    B, D = x.shape
+    C = embedding.shape[0]
+    out_dtype = out_dtype or x.dtype
+    dx = torch.empty((B, D), dtype=out_dtype, device=x.device)
+    if grad_loss_i is not None:
+        grad_loss_i = grad_loss_i.to(torch.float32).contiguous()
+    check(lib().se_cosine_loss_bwd(ptr(x), _dtype_code(x), x.stride(0), ptr(labels), ptr(embedding),
+                                   embedding.stride(0), ptr(grad_loss_i), ctypes.c_float(grad_scale), B, D, C,
+                                   ptr(dx), _dtype_code(dx), D, stream_ptr()), "se_cosine_loss_bwd")
+    return dx
+
+
+class _CosineEmbeddingLoss(torch.autograd.Function):
+    """Per-sample loss_i = 1 - <l2norm(x_i), E[y_i]> with the HIP forward/backward."""
+
+    @staticmethod
+    def forward(ctx, x, labels, embedding):
+        x = x if x.stride(-1) == 1 else x.contiguous()
+        _, _, loss_i, _ = cosine_loss_forward(x, labels, embedding, want_xhat=False)
+        ctx.save_for_backward(x, labels, embedding)
+        return loss_i
+
+    @staticmethod
+    def backward(ctx, grad_loss_i):
+        x, labels, embedding = ctx.saved_tensors
+        dx = cosine_loss_backward(x, labels, embedding, grad_loss_i.contiguous())
+        return dx, None, None
+
+
+def cosine_embedding_loss(x, labels, embedding, reduction="mean"):
+    """Differentiable cosine-embedding loss on un-normalised features ``x`` [B, D].
+
+    Equivalent to the reference's ``Lambda(utils.l2norm)`` head followed by
+    ``utils.inv_correlation(embedding[y], .)`` and Keras' batch mean."""
+    loss_i = _CosineEmbeddingLoss.apply(x, labels, embedding)
+    if reduction == "mean":
+        return loss_i.mean()
+    if reduction == "sum":
+        return loss_i.sum()
+    return loss_i
+
+
+def nn_accuracy(y_pred, labels, embedding, dot_prod_sim=False, k=1, want_scores=False, want_best=False):
+    """reference: utils.nn_accuracy(embedding, dot_prod_sim, k)(embedding[labels], y_pred) (utils.py:57-100).
+
+    Returns acc [B] float32 (and optionally the [B, C] score matrix and the best class per row)."""
+    require_gpu(y_pred, labels, embedding)
+    y_pred = _rows(y_pred.to(torch.float32), "y_pred")
+    _rows(embedding, "embedding")
+    B, D = y_pred.shape
+    C = embedding.shape[0]
+    acc = torch.empty((B,), dtype=torch.float32, device=y_pred.device)
+    scores = torch.empty((B, C), dtype=torch.float32, device=y_pred.device) if want_scores else None
+    best = torch.empty((B,), dtype=torch.int32, device=y_pred.device) if want_best else None
+    check(lib().se_nn_accuracy(ptr(y_pred), y_pred.stride(0), ptr(labels), ptr(embedding), embedding.stride(0),
+                               B, D, C, int(bool(dot_prod_sim)), int(k), ptr(acc), ptr(scores), C, ptr(best),
+                               stream_ptr()), "se_nn_accuracy")
+    out = (acc,)
+    if want_scores:
+        out += (scores,)
+    if want_best:
+        out += (best,)
+    return out if len(out) > 1 else acc
+
+
+# --------------------------------------------------------------------------------------------
+# retrieval side
+# --------------------------------------------------------------------------------------------
+
+def _f32_rows(t, what):
+    if t.dtype != torch.float32:
+        raise SehipError("%s must be float32" % what)
+    return _rows(t, what)
+
+
+def row_sqnorm(x):
+    """float32 ``np.sum(x ** 2, axis=-1)``, bit-exact (evaluate_retrieval.py:61)."""
+    require_gpu(x)
+    _f32_rows(x, "x")
+    sq = torch.empty((x.shape[0],), dtype=torch.float32, device=x.device)
+    check(lib().se_row_sqnorm(ptr(x), x.stride(0), x.shape[0], x.shape[1], ptr(sq), stream_ptr()), "se_row_sqnorm")
+    return sq
+
+
+def normalize_rows_(x):
+    """In-place ``x /= np.linalg.norm(x, axis=-1, keepdims=True)``, bit-exact (evaluate_retrieval.py:58)."""
+    require_gpu(x)
+    _f32_rows(x, "x")
+    check(lib().se_normalize_rows(ptr(x), x.stride(0), x.shape[0], x.shape[1], stream_ptr()), "se_normalize_rows")
+    return x
+
+
+def pairwise_dist(a, b=None, metric=METRIC_COSINE, sqa=None, sqb=None, kblocks=None, out=None):
+    """All-pairs distances [q, n] (evaluate_retrieval.py:59 / :61-62) with the canonical FMA chain."""
+    b = a if b is None else b
+    require_gpu(a, b, sqa, sqb, out)
+    _f32_rows(a, "a"); _f32_rows(b, "b")
+    q, d = a.shape
+    n = b.shape[0]
+    if b.shape[1] != d:
+        raise SehipError("a and b must have the same number of columns")
+    if metric == METRIC_EUCLID:
+        if sqa is None:
+            sqa = row_sqnorm(a)
+        if sqb is None:
+            sqb = sqa if b is a else row_sqnorm(b)
+    if out is None:
+        out = torch.empty((q, n), dtype=torch.float32, device=a.device)
+    kb, nkb = None, 0
+    if kblocks is not None and len(kblocks) > 1:
+        kb = (ctypes.c_int32 * len(kblocks))(*[int(v) for v in kblocks])
+        nkb = len(kblocks)
+    check(lib().se_pairwise_dist(ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(sqa), ptr(sqb), q, n, d, int(metric),
+                                 kb, nkb, ptr(out), out.stride(0), stream_ptr()), "se_pairwise_dist")
+    return out
+
+
+_ws_cache = {}
+
+
+def _workspace(nbytes, device):
+    """Grow-only per-device scratch buffer (the C ABI never allocates)."""
+    key = (device.index if device.index is not None else torch.cuda.current_device())
+    ws = _ws_cache.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = None
+        _ws_cache.pop(key, None)
+        ws = torch.empty((max(int(nbytes), 1),), dtype=torch.uint8, device=device)
+        _ws_cache[key] = ws
+    return ws
+
+
+def rank_rows(pdist, idx64=False, out=None):
+    """Canonical ``np.argsort(pdist, axis=-1)`` (evaluate_retrieval.py:67): (distance, index) ascending."""
+    require_gpu(pdist, out)
+    _f32_rows(pdist, "pdist")
+    q, n = pdist.shape
+    if out is None:
+        out = torch.empty((q, n), dtype=torch.int64 if idx64 else torch.int32, device=pdist.device)
+    need = lib().se_rank_rows_workspace_bytes(q, n)
+    ws = _workspace(need, pdist.device)
+    check(lib().se_rank_rows(ptr(pdist), pdist.stride(0), q, n, ptr(out), int(out.dtype == torch.int64),
+                             out.stride(0), ptr(ws), ws.numel(), stream_ptr()), "se_rank_rows")
+    return out
+
+
+def topk_rows(pdist, k, col_offset=0):
+    """k nearest columns per row under the canonical order -> (dist [q,k] f32, idx [q,k] i32)."""
+    require_gpu(pdist)
+    _f32_rows(pdist, "pdist")
+    q, n = pdist.shape
+    od = torch.empty((q, k), dtype=torch.float32, device=pdist.device)
+    oi = torch.empty((q, k), dtype=torch.int32, device=pdist.device)
+    check(lib().se_topk_rows(ptr(pdist), pdist.stride(0), q, n, int(col_offset), int(k), ptr(od), ptr(oi),
+                             stream_ptr()), "se_topk_rows")
+    return od, oi
+
+
+def topk_merge(d, idx):
+    """Merge per-shard lists [parts, q, k] (e.g. an all-gather result) into the global top-k."""
+    require_gpu(d, idx)
+    d = d.contiguous(); idx = idx.contiguous()
+    parts, q, k = d.shape
+    od = torch.empty((q, k), dtype=torch.float32, device=d.device)
+    oi = torch.empty((q, k), dtype=torch.int32, device=d.device)
+    check(lib().se_topk_merge(ptr(d), ptr(idx), parts, q, k, ptr(od), ptr(oi), stream_ptr()), "se_topk_merge")
+    return od, oi
+
+
+def retrieve_topk(queries, gallery, k, metric=METRIC_COSINE, col_offset=0, sqq=None, sqg=None):
+    """Distances + top-k without materialising the full [q, n] matrix (query tiles of <= 2 GiB)."""
+    require_gpu(queries, gallery)
+    _f32_rows(queries, "queries"); _f32_rows(gallery, "gallery")
+    q, d = queries.shape
+    n = gallery.shape[0]
+    if metric == METRIC_EUCLID:
+        sqq = row_sqnorm(queries) if sqq is None else sqq
+        sqg = row_sqnorm(gallery) if sqg is None else sqg
+    od = torch.empty((q, k), dtype=torch.float32, device=queries.device)
+    oi = torch.empty((q, k), dtype=torch.int32, device=queries.device)
+    need = lib().se_retrieve_topk_workspace_bytes(q, n, int(k))
+    ws = _workspace(need, queries.device)
+    check(lib().se_retrieve_topk(ptr(queries), queries.stride(0), ptr(gallery), gallery.stride(0), ptr(sqq), ptr(sqg),
+                                 q, n, d, int(metric), int(col_offset), int(k), ptr(od), ptr(oi), ptr(ws), ws.numel(),
+                                 stream_ptr()), "se_retrieve_topk")
+    return od, oi

@@ -1,0 +1,218 @@
+"""GPU parity tests for the retrieval hot path: HIP kernels (through the C ABI) vs the oracle.
+
+Bar: bit-exact distances under the canonical arithmetic and bit-exact ranking indices
+(BASELINE.json north_star: "bit-exact for retrieval ranking indices").
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import retrieval_oracle as ro
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sehip():
+    import sehip as m
+    m.lib()
+    return m
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def gauss(n, d, seed=0):
+    return np.random.default_rng(seed).standard_normal((n, d)).astype(np.float32)
+
+
+# ---------------------------------------------------------------- row norms (NumPy pairwise order)
+
+@pytest.mark.parametrize("d", [1, 5, 7, 8, 9, 63, 64, 100, 127, 128, 129, 200, 255, 256, 257, 555, 1000, 2048, 2500])
+def test_row_sqnorm_and_normalize_bit_exact(sehip, d):
+    x = gauss(131, d, seed=d)
+    sq = sehip.row_sqnorm(dev(x)).cpu().numpy()
+    assert np.array_equal(sq, np.sum(x ** 2, axis=-1))          # NumPy itself
+    assert np.array_equal(sq, ro.canon_row_sqsum(x))            # C restatement
+    xn = sehip.normalize_rows_(dev(x)).cpu().numpy()
+    ref = x.copy()
+    ref /= np.linalg.norm(ref, axis=-1, keepdims=True)
+    assert np.array_equal(xn, ref)
+
+
+def test_normalize_zero_row_gives_nan_like_numpy(sehip):
+    x = gauss(70, 16)
+    x[3] = 0
+    xn = sehip.normalize_rows_(dev(x)).cpu().numpy()
+    with np.errstate(invalid="ignore", divide="ignore"):
+        ref = x / np.linalg.norm(x, axis=-1, keepdims=True)
+    assert np.array_equal(np.isnan(xn), np.isnan(ref))
+    assert np.array_equal(xn[~np.isnan(ref)], ref[~np.isnan(ref)])
+
+
+# ---------------------------------------------------------------- distance kernel
+
+@pytest.mark.parametrize("metric", [ro.METRIC_COSINE, ro.METRIC_EUCLID, ro.METRIC_DOT])
+@pytest.mark.parametrize("q,n,d", [(1, 1, 1), (3, 5, 2), (37, 129, 7), (128, 128, 64), (130, 257, 100),
+                                   (200, 300, 101), (65, 400, 200), (300, 70, 448)])
+def test_pairwise_dist_bit_exact(sehip, metric, q, n, d):
+    a = gauss(q, d, seed=1)
+    b = gauss(n, d, seed=2)
+    got = sehip.pairwise_dist(dev(a), dev(b), metric=metric).cpu().numpy()
+    want = ro.canon_pdist(a, b, metric)
+    assert np.array_equal(got, want)
+
+
+def test_pairwise_dist_self_is_symmetric_and_transpose_detecting(sehip):
+    x = gauss(260, 100, seed=5)
+    got = sehip.pairwise_dist(dev(x), None, metric=ro.METRIC_COSINE).cpu().numpy()
+    assert np.array_equal(got, got.T)
+    assert np.array_equal(got, ro.canon_pdist(x, None, ro.METRIC_COSINE))
+    # asymmetric operands: a transposed write would be caught here
+    a = gauss(64, 32, seed=7)
+    b = np.arange(96 * 32, dtype=np.float32).reshape(96, 32) / 100
+    got = sehip.pairwise_dist(dev(a), dev(b), metric=ro.METRIC_DOT).cpu().numpy()
+    assert np.array_equal(got, ro.canon_pdist(a, b, ro.METRIC_DOT))
+
+
+@pytest.mark.parametrize("d,kblocks", [(555, [278, 277]), (1000, [448, 276, 276]), (130, [64, 66]), (100, [100])])
+def test_pairwise_dist_kblocks(sehip, d, kblocks):
+    a = gauss(70, d, seed=3)
+    b = gauss(140, d, seed=4)
+    got = sehip.pairwise_dist(dev(a), dev(b), metric=ro.METRIC_COSINE, kblocks=kblocks).cpu().numpy()
+    assert np.array_equal(got, ro.canon_pdist(a, b, ro.METRIC_COSINE, kblocks))
+
+
+def test_pairwise_dist_strided_rows(sehip):
+    big = dev(gauss(100, 128, seed=9))
+    a = big[:, :100]                       # ld = 128, d = 100
+    got = sehip.pairwise_dist(a, None, metric=ro.METRIC_DOT).cpu().numpy()
+    assert np.array_equal(got, ro.canon_pdist(a.cpu().numpy(), None, ro.METRIC_DOT))
+    odd = dev(gauss(50, 103, seed=10))[:, 1:101]   # misaligned rows -> scalar staging path
+    got = sehip.pairwise_dist(odd, None, metric=ro.METRIC_DOT).cpu().numpy()
+    assert np.array_equal(got, ro.canon_pdist(odd.cpu().numpy(), None, ro.METRIC_DOT))
+
+
+# ---------------------------------------------------------------- ranking
+
+def tie_heavy(q, n, seed=0):
+    rng = np.random.default_rng(seed)
+    pd = rng.integers(-3, 4, size=(q, n)).astype(np.float32)     # lots of exact ties
+    pd[0, :5] = [0.0, -0.0, np.nan, np.inf, -np.inf]
+    pd[1, ::7] = np.nan
+    return pd
+
+
+@pytest.mark.parametrize("q,n", [(1, 1), (2, 63), (5, 64), (7, 65), (33, 1000), (9, 4097), (3, 50000)])
+def test_rank_rows_matches_canonical_order(sehip, q, n):
+    pd = gauss(q, n, seed=n)
+    got = sehip.rank_rows(dev(pd)).cpu().numpy()
+    assert np.array_equal(got, ro.canon_rank_rows(pd))
+    assert np.array_equal(got, np.argsort(pd, axis=-1, kind="stable"))
+
+
+def test_rank_rows_ties_nan_negzero_int64(sehip):
+    pd = tie_heavy(40, 700)
+    want = ro.canon_rank_rows(pd)
+    got32 = sehip.rank_rows(dev(pd)).cpu().numpy()
+    got64 = sehip.rank_rows(dev(pd), idx64=True).cpu().numpy()
+    assert got64.dtype == np.int64
+    assert np.array_equal(got32, want)
+    assert np.array_equal(got64, want)
+
+
+@pytest.mark.parametrize("q,n,k", [(4, 10, 1), (4, 10, 10), (17, 300, 7), (9, 5000, 251), (3, 50000, 251), (5, 3000, 2048)])
+def test_topk_rows_equals_head_of_full_ranking(sehip, q, n, k):
+    pd = gauss(q, n, seed=k)
+    d, i = sehip.topk_rows(dev(pd), k, col_offset=1000)
+    wd, wi = ro.canon_topk_rows(pd, k, col_offset=1000)
+    assert np.array_equal(i.cpu().numpy(), wi)
+    assert np.array_equal(d.cpu().numpy(), wd)
+
+
+def test_topk_rows_ties(sehip):
+    pd = tie_heavy(30, 900, seed=3)
+    pd[np.isnan(pd)] = 9.0
+    for k in (1, 5, 129, 600, 900):
+        d, i = sehip.topk_rows(dev(pd), k)
+        wd, wi = ro.canon_topk_rows(pd, k)
+        assert np.array_equal(i.cpu().numpy(), wi), k
+        assert np.array_equal(d.cpu().numpy(), wd), k
+
+
+def test_topk_merge_is_shard_invariant(sehip):
+    # the sharded-gallery path: per-shard top-k + merge == top-k over the whole gallery
+    q, n, d, k = 50, 1200, 100, 25
+    x = gauss(n, d, seed=11)
+    qs = x[:q]
+    full = ro.canon_pdist(qs, x, ro.METRIC_COSINE)
+    wd, wi = ro.canon_topk_rows(full, k)
+    for parts in (2, 3, 8):
+        bounds = np.linspace(0, n, parts + 1).astype(int)
+        ds, is_ = [], []
+        for p in range(parts):
+            shard = x[bounds[p]:bounds[p + 1]]
+            dd, ii = sehip.retrieve_topk(dev(qs), dev(shard), k, metric=ro.METRIC_COSINE, col_offset=int(bounds[p]))
+            ds.append(dd); is_.append(ii)
+        md, mi = sehip.topk_merge(torch.stack(ds), torch.stack(is_))
+        assert np.array_equal(mi.cpu().numpy(), wi), parts
+        assert np.array_equal(md.cpu().numpy(), wd), parts
+
+
+# ---------------------------------------------------------------- end to end vs the reference's own output
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "retrieval_*.npz"))))
+def test_golden_rankings_from_the_imported_reference(sehip, path):
+    g = np.load(path)
+    feats = g["features"].astype(np.float32)
+    norm = bool(g["normalize"])
+    ref = g["ref_ranking"].astype(np.int64)
+    x = dev(feats.copy())
+    if norm:
+        sehip.normalize_rows_(x)
+        pd = sehip.pairwise_dist(x, None, metric=ro.METRIC_COSINE)
+    else:
+        pd = sehip.pairwise_dist(x, None, metric=ro.METRIC_EUCLID)
+    rk = sehip.rank_rows(pd).cpu().numpy().astype(np.int64)
+    if "ids" in g.files:
+        rk = g["ids"][rk]
+    pdh = pd.cpu().numpy()
+    # gate 1: exactly the canonical oracle
+    cpd, crk = ro.canon_retrieval(feats, norm)
+    assert np.array_equal(pdh, cpd)
+    crk = crk.astype(np.int64)
+    assert np.array_equal(rk, g["ids"][crk] if "ids" in g.files else crk)
+    # gate 2: equal to the reference's (unstable-sort) output except inside exact-tie groups
+    same = rk == ref
+    if not same.all():
+        pos = {int(v): i for i, v in enumerate(g["ids"])} if "ids" in g.files else None
+        for r in np.nonzero(~same.all(axis=1))[0]:
+            a = rk[r] if pos is None else np.array([pos[int(v)] for v in rk[r]])
+            b = ref[r] if pos is None else np.array([pos[int(v)] for v in ref[r]])
+            assert np.array_equal(pdh[r][a], pdh[r][b]), "row %d differs outside a tie group" % r
+
+
+def test_full_size_properties_50k(sehip):
+    """BASELINE config 3 at full gallery size (50k x 100) on a 512-query tile: size-independent
+    properties -- every row is a permutation, distances are sorted along the ranking, self is
+    first for cosine, and the tile equals the canonical oracle on sampled rows."""
+    n, d, q = 50000, 100, 512
+    x = gauss(n, d, seed=0)
+    xd = dev(x)
+    sehip.normalize_rows_(xd)
+    pd = sehip.pairwise_dist(xd[:q], xd, metric=ro.METRIC_COSINE)
+    rk = sehip.rank_rows(pd)
+    srt = torch.gather(pd, 1, rk.long())
+    assert bool((srt[:, 1:] >= srt[:, :-1]).all())
+    assert bool((rk.long().sort(dim=1).values == torch.arange(n, device="cuda")[None, :]).all())
+    ties_ok = (srt[:, 1:] > srt[:, :-1]) | (rk[:, 1:] > rk[:, :-1])
+    assert bool(ties_ok.all())
+    xn = xd.cpu().numpy()
+    rows = [0, 17, 511]
+    want_pd = ro.canon_pdist(xn[rows], xn, ro.METRIC_COSINE)
+    assert np.array_equal(pd[rows].cpu().numpy(), want_pd)
+    assert np.array_equal(rk[rows].cpu().numpy(), ro.canon_rank_rows(want_pd))
