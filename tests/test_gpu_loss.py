@@ -72,7 +72,8 @@ def test_cosine_loss_fwd_bwd_vs_oracle(sehip, B, D, C, dtype):
     w = rng.standard_normal(B)
     want = lo.cosine_loss_bwd(x_used, y, E_used, w)
     dx = sehip.cosine_loss_backward(xd, dev(y), Ed, grad_loss_i=dev(w.astype(np.float32)), out_dtype=torch.float32)
-    scale = np.abs(want).max() + 1e-30
+    # error budget relative to the size of the two terms that cancel in g - xhat (xhat . g)
+    scale = (np.abs(w)[:, None] * np.abs(E_used[y]) * fwd["inv_norm"][:, None]).max() + 1e-30
     assert np.abs(dx.cpu().numpy() - want).max() / scale <= 2e-6
 
 
@@ -87,7 +88,7 @@ def test_autograd_function_matches_torch_autograd(sehip, emb):
     xh = x2 * torch.rsqrt(torch.clamp((x2 * x2).sum(-1, keepdim=True), min=1e-12))
     ref = (1 - (E.double()[y] * xh).sum(-1)).mean()
     ref.backward()
-    assert abs(float(loss) - float(ref)) <= 1e-6
+    assert abs(float(loss.detach()) - float(ref.detach())) <= 1e-6
     assert float((x.grad.double() - x2.grad).abs().max()) <= 1e-8
 
 
@@ -127,14 +128,18 @@ def test_nn_accuracy_on_reference_embeddings(sehip, emb, name, dot, k):
     scores64 = lo.class_scores(p, E, dot)
     acc, scores, best = sehip.nn_accuracy(dev(p), dev(y), dev(E), dot_prod_sim=dot, k=k, want_scores=True, want_best=True)
     assert np.abs(scores.cpu().numpy() - scores64).max() <= 1e-5 * max(1.0, np.abs(scores64).max())
-    # The metric compares float32 scores against a 1e-6 band (utils.py:84,93); a row can only be
-    # compared with the float64 oracle when every class sits clear of the band edge by more than
-    # the float32 rounding noise (~1e-7 * score magnitude).  The true class itself sits 1e-6 inside.
+    # The metric compares float32 scores against a 1e-6 band (utils.py:84,93).  The kernel's true
+    # score equals its own matrix entry exactly, so only the OTHER classes can flip a decision: a row
+    # is comparable with the float64 oracle when every other class sits clear of the band edge by
+    # more than the float32 rounding noise of a score (~1e-7 * magnitude; the expanded Euclidean form
+    # |p|^2 + |c|^2 - 2pc carries a few ulps of the squared norms).
     scale = max(1.0, np.abs(scores64).max())
     true_s = scores64[np.arange(B), y]
-    margin = np.abs(np.abs(scores64 - true_s[:, None]) - 1e-6).min(axis=1)
-    safe = margin > 3e-7 * scale
-    if "unitsphere" in name and dot:
+    diff = np.abs(scores64 - true_s[:, None])
+    edge = np.abs(diff - 1e-6)
+    edge[diff == 0] = np.inf                      # the true class and exact duplicates of it
+    safe = edge.min(axis=1) > (3e-7 if dot else 3e-6) * scale
+    if "unitsphere" in name:
         assert safe.mean() > 0.9
     assert np.array_equal(acc.cpu().numpy()[safe], want[safe].astype(np.float32))
     want_best = scores64.argmax(1) if dot else scores64.argmin(1)
