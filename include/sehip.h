@@ -87,6 +87,20 @@ int se_cosine_loss_bwd(const void *x, int x_dtype, int64_t ldx, const int64_t *l
                        se_stream_t stream);
 
 /*
+ * Stand-alone L2-normalisation head and its backward.
+ * Replaces: utils.l2norm (utils.py:125-127) used as `Lambda(utils.l2norm, name='l2norm')`
+ *           (learn_image_embeddings.py:127-128) when the normalised embedding itself is wanted
+ *           (feature dumps, learn_image_embeddings.py:270-275; inference).
+ *   xhat [B, D] f32 = x * rsqrt(max(sum x^2, 1e-12)); inv_norm [B] f32 (may be NULL in fwd).
+ *   bwd: dx = (grad - xhat (xhat . grad)) * inv_norm  (rows on the epsilon clamp: grad * inv_norm)
+ */
+int se_l2norm_fwd(const void *x, int x_dtype, int64_t ldx, int64_t B, int64_t D, float *xhat,
+                  int64_t ldxhat, float *inv_norm, se_stream_t stream);
+int se_l2norm_bwd(const float *grad, int64_t ldg, const float *xhat, int64_t ldxhat,
+                  const float *inv_norm, int64_t B, int64_t D, float *dx, int64_t lddx,
+                  se_stream_t stream);
+
+/*
  * Nearest-class-embedding accuracy metric.
  * Replaces: utils.nn_accuracy(embedding, dot_prod_sim, k) (utils.py:57-100): the dense
  *           contraction y_pred @ embedding.T (utils.py:90 / :78) on MFMA plus the

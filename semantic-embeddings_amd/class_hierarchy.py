@@ -1,0 +1,281 @@
+"""Class taxonomy + hierarchical retrieval metrics: the consumer of the rankings produced by
+``evaluate_retrieval.pairwise_retrieval``.
+
+Same public surface as the reference's ``class_hierarchy.ClassHierarchy``
+(reference: class_hierarchy.py:7-367 -- ``from_file``/``save``, ``lcs``, ``wup_similarity``,
+``lcs_height``, ``depth``, ``heights``/``max_height``, ``hierarchical_precision`` ...), but built
+differently: node properties are computed once by memoised graph walks, and
+``hierarchical_precision`` works on NumPy look-up tables (class x class similarity matrices gathered
+along the ranking + prefix sums) instead of per-element Python dictionary look-ups.  The metric
+definitions (Deng et al., CVPR 2011 hierarchical precision; area under the HP@k curve; average
+precision) and every corner of the reference's bookkeeping are kept, so the numbers agree with the
+reference to float64 round-off (tests/test_class_hierarchy.py checks against values produced by the
+imported reference).
+"""
+import types
+
+import numpy as np
+
+_trapz = getattr(np, "trapezoid", None) or np.trapz
+
+
+class ClassHierarchy(object):
+    """A DAG of classes given as parent->children / child->parents adjacency dictionaries."""
+
+    def __init__(self, parents, children):
+        self.parents = parents
+        self.children = children
+        self.nodes = set(parents) | set(children)
+        self._depth = {False: {}, True: {}}
+        self._anc_depth = {False: {}, True: {}}
+        self._anc_dist = {}
+        self._lcs_cache = {}
+        self._wup_cache = {}
+        self._luts = {}
+        self.heights = {}
+        for node in self.nodes:
+            self._height(node)
+        self.max_height = max(self.heights.values())
+
+    # ------------------------------------------------------------------ construction / IO
+
+    @classmethod
+    def from_file(cls, rel_file, is_a_relations=False, id_type=str):
+        """Reads "<parent> <child>" lines ("<child> <parent>" with ``is_a_relations``)."""
+        parents, children = {}, {}
+        with open(rel_file) as f:
+            for line in f:
+                line = line.strip()
+                if not line:
+                    continue
+                first, second = (id_type(tok) for tok in line.split(maxsplit=1))
+                parent, child = (second, first) if is_a_relations else (first, second)
+                parents.setdefault(child, []).append(parent)
+                children.setdefault(parent, []).append(child)
+        return cls(parents, children)
+
+    def save(self, filename, is_a_relations=False):
+        """Writes the edges back in the format ``from_file`` reads."""
+        with open(filename, 'w') as f:
+            if is_a_relations:
+                f.writelines('{} {}\n'.format(c, p) for c, ps in self.parents.items() for p in ps)
+            else:
+                f.writelines('{} {}\n'.format(p, c) for p, cs in self.children.items() for c in cs)
+
+    # ------------------------------------------------------------------ node properties
+
+    def _height(self, node):
+        """Longest downward path to a leaf (leaves: 0)."""
+        h = self.heights.get(node)
+        if h is None:
+            kids = self.children.get(node, ())
+            h = 1 + max((self._height(k) for k in kids), default=-1) if node in self.children else 0
+            self.heights[node] = h
+        return h
+
+    def is_tree(self):
+        return all(len(ps) <= 1 for ps in self.parents.values())
+
+    def depth(self, id, use_min_depth=False):
+        """Roots have depth 1; otherwise 1 + max (or min) over the parents' depths."""
+        memo = self._depth[use_min_depth]
+        if id not in memo:
+            ps = self.parents.get(id) or []
+            if not ps:
+                memo[id] = 1
+            else:
+                pick = min if use_min_depth else max
+                memo[id] = 1 + pick(self.depth(p, use_min_depth) for p in ps)
+        return memo[id]
+
+    def all_hypernym_depths(self, id, use_min_depth=False):
+        """{ancestor (incl. id): depth of that ancestor}."""
+        memo = self._anc_depth[use_min_depth]
+        if id not in memo:
+            out = {}
+            for p in self.parents.get(id) or []:
+                out.update(self.all_hypernym_depths(p, use_min_depth))
+            out[id] = self.depth(id, use_min_depth)
+            memo[id] = out
+        return memo[id]
+
+    def all_hypernym_distances(self, id):
+        """{ancestor (incl. id): fewest upward edges from id}."""
+        if id not in self._anc_dist:
+            out = {id: 0}
+            for p in self.parents.get(id, ()):
+                for anc, dist in self.all_hypernym_distances(p).items():
+                    if dist + 1 < out.get(anc, float('inf')):
+                        out[anc] = dist + 1
+            self._anc_dist[id] = out
+        return self._anc_dist[id]
+
+    def root_paths(self, id):
+        """Every path from a direct parent of ``id`` up to a root."""
+        paths = []
+        for p in self.parents.get(id, ()):
+            above = self.root_paths(p)
+            paths.extend([[p] + tail for tail in above] if above else [[p]])
+        return paths
+
+    # ------------------------------------------------------------------ pairwise class relations
+
+    def lcs(self, a, b, use_min_depth=False):
+        """Deepest common ancestor (``None`` if there is none).  Among equally deep candidates --
+        only possible in non-tree hierarchies, where the reference's pick is arbitrary -- the one
+        with the smallest height, then the smallest repr, is chosen deterministically."""
+        key = (a, b)
+        if key not in self._lcs_cache:
+            da = self.all_hypernym_depths(a, use_min_depth)
+            common = da.keys() & self.all_hypernym_depths(b, use_min_depth).keys()
+            best = None
+            if common:
+                top = max(da[h] for h in common)
+                best = min((h for h in common if da[h] == top), key=lambda h: (self.heights[h], repr(h)))
+            self._lcs_cache[(a, b)] = self._lcs_cache[(b, a)] = best
+        return self._lcs_cache[key]
+
+    def shortest_path_length(self, a, b):
+        da, db = self.all_hypernym_distances(a), self.all_hypernym_distances(b)
+        return min((da[h] + db[h] for h in da.keys() & db.keys()), default=None)
+
+    def wup_similarity(self, a, b):
+        """Wu-Palmer: 2 depth(lcs) / (depth_via_lcs(a) + depth_via_lcs(b))."""
+        key = (a, b)
+        if key not in self._wup_cache:
+            anc = self.lcs(a, b)
+            ds = self.depth(anc)
+            d1 = ds + self.shortest_path_length(a, anc)
+            d2 = ds + self.shortest_path_length(b, anc)
+            self._wup_cache[(a, b)] = self._wup_cache[(b, a)] = (2.0 * ds) / (d1 + d2)
+        return self._wup_cache[key]
+
+    def lcs_height(self, a, b):
+        """height(lcs(a, b)) / height of the hierarchy (a dissimilarity in [0, 1])."""
+        return self.heights[self.lcs(a, b)] / self.max_height
+
+    def similarity_tables(self, classes):
+        """(WUP, 1 - LCS height) as float64 [C, C] matrices over ``classes`` (cached)."""
+        key = tuple(classes)
+        if key not in self._luts:
+            c = len(key)
+            wup = np.empty((c, c))
+            lcs = np.empty((c, c))
+            for i, a in enumerate(key):
+                for j in range(i, c):
+                    b = key[j]
+                    wup[i, j] = wup[j, i] = self.wup_similarity(a, b)
+                    lcs[i, j] = lcs[j, i] = 1.0 - np.array(self.heights[self.lcs(a, b)]) / self.max_height
+            self._luts[key] = (wup, lcs)
+        return self._luts[key]
+
+    # ------------------------------------------------------------------ retrieval metrics
+
+    def hierarchical_precision(self, retrieved, labels, ks=[1, 10, 50, 100], compute_ahp=False, compute_ap=False,
+                               ignore_qids=True, all_ids=None):
+        """Hierarchical precision@k, area under that curve (AHP / AHP@K) and AP per query + means.
+
+        Arguments and return value as in the reference (class_hierarchy.py:211-316):
+        ``retrieved`` maps query id -> ranked id list (dict or generator of pairs), ``labels`` maps
+        image id -> class label; returns ``(means, per_query)`` with metric names ``"P@K (WUP)"``,
+        ``"P@K (LCS_HEIGHT)"``, ``"AHP[@K] (...)"`` and ``"AP"``.
+
+        Bookkeeping kept from the reference: the best-possible cumulative similarity of a query
+        class is taken from the FIRST query of that class (full list, query included); removing the
+        query shifts that curve left at the query's rank and subtracts its self-similarity of 1;
+        ids missing from a ranking are appended in ``all_ids`` order."""
+        ks = [ks] if isinstance(ks, int) else list(ks)
+        kmax = max(ks)
+        ahp_clip = None if isinstance(compute_ahp, bool) else int(compute_ahp)
+        if ahp_clip is not None:
+            kmax = max(kmax, ahp_clip)
+        full_lists = compute_ahp is True
+
+        names = ['P@{} ({})'.format(k, t) for k in ks for t in ('WUP', 'LCS_HEIGHT')]
+        ahp_names = ()
+        if compute_ahp:
+            sfx = '' if ahp_clip is None else '@{}'.format(ahp_clip)
+            ahp_names = ('AHP{} (WUP)'.format(sfx), 'AHP{} (LCS_HEIGHT)'.format(sfx))
+        prec = {n: {} for n in names}
+        prec.update({n: {} for n in ahp_names})
+        if compute_ap:
+            prec['AP'] = {}
+
+        # label -> row/column index of the similarity tables
+        get_label = labels.__getitem__
+        label_of = {}
+        best_cum = {}
+        class_list, class_pos = [], {}
+
+        def cls_index(lbl):
+            if lbl not in class_pos:
+                class_pos[lbl] = len(class_list)
+                class_list.append(lbl)
+            return class_pos[lbl]
+
+        lut_cache = {'n': -1, 'wup': None, 'lcs': None}
+
+        def tables():
+            if lut_cache['n'] != len(class_list):
+                lut_cache['wup'], lut_cache['lcs'] = self.similarity_tables(class_list)
+                lut_cache['n'] = len(class_list)
+            return lut_cache['wup'], lut_cache['lcs']
+
+        items = retrieved if isinstance(retrieved, types.GeneratorType) else retrieved.items()
+        for qid, ret in items:
+            lbl = get_label(qid)
+            if all_ids and (len(ret) < len(all_ids)):
+                seen = set(ret)
+                ret = list(ret) + [i for i in all_ids if i not in seen]
+            need_full = full_lists or (lbl not in best_cum)
+            head = ret if need_full else ret[:kmax + 1]
+            cols = np.fromiter((cls_index(label_of.setdefault(r, get_label(r)) if r in label_of else
+                                          label_of.setdefault(r, get_label(r))) for r in head), dtype=np.int64, count=len(head))
+            qi = cls_index(lbl)
+            wup_t, lcs_t = tables()
+            wup = wup_t[qi, cols]
+            lcs = lcs_t[qi, cols]
+            if lbl not in best_cum:
+                best_cum[lbl] = (np.cumsum(np.sort(wup)[::-1]), np.cumsum(np.sort(lcs)[::-1]))
+            cum_best_wup, cum_best_lcs = best_cum[lbl]
+
+            q_pos = None
+            if ignore_qids:
+                try:
+                    q_pos = ret.index(qid)
+                except ValueError:
+                    q_pos = None
+                if q_pos is not None and q_pos < len(wup):
+                    wup = np.delete(wup, q_pos)
+                    lcs = np.delete(lcs, q_pos)
+                    cum_best_wup = np.concatenate((cum_best_wup[:q_pos], cum_best_wup[q_pos + 1:] - 1.0))
+                    cum_best_lcs = np.concatenate((cum_best_lcs[:q_pos], cum_best_lcs[q_pos + 1:] - 1.0))
+
+            cw, cl = np.cumsum(wup), np.cumsum(lcs)
+            for k in ks:
+                kk = min(k, len(cw))
+                prec['P@{} (WUP)'.format(k)][qid] = (cw[kk - 1] if kk else 0.0) / cum_best_wup[k - 1]
+                prec['P@{} (LCS_HEIGHT)'.format(k)][qid] = (cl[kk - 1] if kk else 0.0) / cum_best_lcs[k - 1]
+            if compute_ahp:
+                if ahp_clip is None:
+                    prec[ahp_names[0]][qid] = _trapz(cw / cum_best_wup, dx=1. / len(wup))
+                    prec[ahp_names[1]][qid] = _trapz(cl / cum_best_lcs, dx=1. / len(lcs))
+                else:
+                    prec[ahp_names[0]][qid] = _trapz(cw[:ahp_clip] / cum_best_wup[:ahp_clip], dx=1. / ahp_clip)
+                    prec[ahp_names[1]][qid] = _trapz(cl[:ahp_clip] / cum_best_lcs[:ahp_clip], dx=1. / ahp_clip)
+            if compute_ap:
+                rel = np.fromiter((label_of.setdefault(r, get_label(r)) == lbl for r in ret), dtype=bool, count=len(ret))
+                if ignore_qids and q_pos is not None:
+                    rel = np.delete(rel, q_pos)
+                prec['AP'][qid] = _average_precision(rel)
+
+        return {metric: sum(values.values()) / len(values) for metric, values in prec.items()}, prec
+
+
+def _average_precision(relevant):
+    """AP of a ranking with distinct scores: mean over the relevant items of precision at their
+    rank (== sklearn.metrics.average_precision_score for tie-free scores; 0 if nothing is relevant)."""
+    hits = np.flatnonzero(relevant)
+    if hits.size == 0:
+        return 0.0
+    return float(np.mean(np.arange(1, hits.size + 1) / (hits + 1.0)))

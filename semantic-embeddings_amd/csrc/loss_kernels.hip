@@ -158,6 +158,44 @@ __global__ __launch_bounds__(256) void cosine_loss_bwd_kernel(
     }
 }
 
+// Stand-alone l2norm head (utils.py:125-127) for inference / feature dumps and for callers that
+// keep the Keras-style ``Lambda(l2norm)`` layer separate from the loss.
+template <bool BF16>
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const void *__restrict__ x, int64_t ldx, int64_t B, int64_t D,
+                                                         float *__restrict__ xhat, int64_t ldo, float *__restrict__ inv_norm)
+{
+    const int wave = threadIdx.x >> 6, lane = lane_id();
+    for (int64_t row = (int64_t)blockIdx.x * LOSS_ROWS_PER_BLOCK + wave; row < B;
+         row += (int64_t)gridDim.x * LOSS_ROWS_PER_BLOCK) {
+        const char *xrow = (const char *)x + row * ldx * (BF16 ? 2 : 4);
+        float s = 0.f;
+        for (int64_t i = lane; i < D; i += WAVE) { const float p = load_x<BF16>(xrow, i); s = fmaf(p, p, s); }
+        const float inv = 1.0f / sqrtf(fmaxf(wave_sum(s), L2NORM_EPS));
+        if (lane == 0 && inv_norm) inv_norm[row] = inv;
+        float *orow = xhat + row * ldo;
+        for (int64_t i = lane; i < D; i += WAVE) orow[i] = load_x<BF16>(xrow, i) * inv;
+    }
+}
+
+// dx = (g - xhat (xhat . g)) * inv_norm ; rows on the epsilon clamp (inv_norm == 1e6): dx = g * inv_norm
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float *__restrict__ g, int64_t ldg,
+                                                         const float *__restrict__ xhat, int64_t ldh,
+                                                         const float *__restrict__ inv_norm, int64_t B, int64_t D,
+                                                         float *__restrict__ dx, int64_t lddx)
+{
+    const int wave = threadIdx.x >> 6, lane = lane_id();
+    for (int64_t row = (int64_t)blockIdx.x * LOSS_ROWS_PER_BLOCK + wave; row < B;
+         row += (int64_t)gridDim.x * LOSS_ROWS_PER_BLOCK) {
+        const float *gr = g + row * ldg, *hr = xhat + row * ldh;
+        float s = 0.f;
+        for (int64_t i = lane; i < D; i += WAVE) s = fmaf(gr[i], hr[i], s);
+        const float inv = inv_norm[row];
+        const float proj = (inv >= 1e6f) ? 0.f : wave_sum(s);
+        float *o = dx + row * lddx;
+        for (int64_t i = lane; i < D; i += WAVE) o[i] = (gr[i] - hr[i] * proj) * inv;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // nn_accuracy: one wave owns a strip of 32 samples and walks all classes in tiles of 32 with
 // v_mfma_f32_32x32x2_f32.  Operands are staged through LDS in K-chunks of 64, stored with even
@@ -398,6 +436,34 @@ extern "C" int se_nn_accuracy(const float *y_pred, int64_t ldp, const int64_t *l
     if (k < 1) k = 1;
     hipLaunchKernelGGL(nn_accuracy_kernel, dim3((unsigned)((B + 31) / 32)), dim3(64), 0, (hipStream_t)stream,
                        y_pred, ldp, labels, emb, lde, B, D, C, dot_prod_sim, k, acc, scores, lds, best);
+    SE_LAUNCH_CHECK();
+    return SE_OK;
+}
+
+extern "C" int se_l2norm_fwd(const void *x, int x_dtype, int64_t ldx, int64_t B, int64_t D, float *xhat,
+                             int64_t ldxhat, float *inv_norm, se_stream_t stream)
+{
+    if (B < 0 || D <= 0) return fail(SE_ERR_INVALID, "se_l2norm_fwd: bad shape");
+    if (B == 0) return SE_OK;
+    if (!x || !xhat || ldx < D || ldxhat < D) return fail(SE_ERR_INVALID, "se_l2norm_fwd: bad argument");
+    int64_t blocks = (B + LOSS_ROWS_PER_BLOCK - 1) / LOSS_ROWS_PER_BLOCK;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    if (x_dtype == SE_DTYPE_BF16) hipLaunchKernelGGL(l2norm_fwd_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, B, D, xhat, ldxhat, inv_norm);
+    else if (x_dtype == SE_DTYPE_F32) hipLaunchKernelGGL(l2norm_fwd_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, ldx, B, D, xhat, ldxhat, inv_norm);
+    else return fail(SE_ERR_INVALID, "se_l2norm_fwd: bad dtype %d", x_dtype);
+    SE_LAUNCH_CHECK();
+    return SE_OK;
+}
+
+extern "C" int se_l2norm_bwd(const float *grad, int64_t ldg, const float *xhat, int64_t ldxhat, const float *inv_norm,
+                             int64_t B, int64_t D, float *dx, int64_t lddx, se_stream_t stream)
+{
+    if (B < 0 || D <= 0) return fail(SE_ERR_INVALID, "se_l2norm_bwd: bad shape");
+    if (B == 0) return SE_OK;
+    if (!grad || !xhat || !inv_norm || !dx || ldg < D || ldxhat < D || lddx < D) return fail(SE_ERR_INVALID, "se_l2norm_bwd: bad argument");
+    int64_t blocks = (B + LOSS_ROWS_PER_BLOCK - 1) / LOSS_ROWS_PER_BLOCK;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, grad, ldg, xhat, ldxhat, inv_norm, B, D, dx, lddx);
     SE_LAUNCH_CHECK();
     return SE_OK;
 }

@@ -1,0 +1,276 @@
+"""Training engine: the role Keras' ``compile / fit_generator / evaluate_generator /
+predict_generator`` + ``multi_gpu_model`` play in the reference (learn_image_embeddings.py:120-148,
+224-255,270-275), re-designed for MI355X:
+
+* one process per GPU; gradients are all-reduced with RCCL (``torch.distributed`` backend "nccl")
+  in contiguous buckets that are launched from autograd hooks while backward is still running;
+* all parameters / gradients / momentum buffers live in three flat fp32 HBM buffers, so the
+  Keras-style update (L2 regulariser folded into the gradient BEFORE clipping, global-norm
+  clipping, ``lr / (1 + decay * t)``, momentum / Nesterov) is a handful of whole-buffer launches
+  regardless of the number of layers;
+* the loss head is the fused HIP kernel (``utils.CosineEmbeddingLoss``); backbone math runs under
+  bf16 autocast (MIOpen / hipBLASLt), master weights and the loss stay fp32;
+* metrics are accumulated on the device and read back once per epoch (no per-step host sync).
+
+Semantics mirrored from Keras 2.2 [third party, not in the reference tree]: SGD velocity
+``v = m v - lr g; w += v`` (Nesterov: ``w += m v - lr g``), ``clipnorm`` = global-norm clip,
+per-replica BatchNorm statistics (``multi_gpu_model`` towers == no SyncBN).
+"""
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def dist_info():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+class FlatState(object):
+    """Re-homes every trainable parameter of ``model`` into one flat fp32 buffer (keeping each
+    parameter's shape and strides, e.g. channels_last conv kernels), with matching flat gradient,
+    velocity and L2-coefficient buffers."""
+
+    def __init__(self, model, l2_of=None):
+        params = [p for p in model.parameters() if p.requires_grad]
+        self.params = params
+        total = sum(p.numel() for p in params)
+        dev = params[0].device
+        self.flat_p = torch.empty(total, dtype=torch.float32, device=dev)
+        self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_v = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.flat_l2 = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.offsets = []
+        off = 0
+        l2_of = l2_of or {}
+        for p in params:
+            n = p.numel()
+            dense = p.is_contiguous() or p.is_contiguous(memory_format=torch.channels_last)
+            src = p.data if dense else p.data.contiguous()
+            view = self.flat_p[off:off + n].as_strided(src.shape, src.stride())
+            view.copy_(src)
+            p.data = view
+            p.grad = self.flat_g[off:off + n].as_strided(src.shape, src.stride())
+            lam = l2_of.get(id(p), 0.0)
+            if lam:
+                self.flat_l2[off:off + n] = 2.0 * lam        # d/dw (lam * w^2)
+            self.offsets.append((off, n))
+            off += n
+        self.total = total
+        self.has_l2 = bool((self.flat_l2 != 0).any().item())
+
+
+class BucketedAllReduce(object):
+    """Gradient all-reduce over RCCL in contiguous buckets of the flat gradient buffer, launched
+    as soon as every gradient of a bucket has been accumulated (post-accumulate-grad hooks), i.e.
+    overlapped with the rest of backward.  Buckets are cut in reverse parameter order because
+    autograd produces the last layers' gradients first."""
+
+    def __init__(self, flat, bucket_bytes=25 << 20):
+        self.flat = flat
+        self.rank, self.world = dist_info()
+        self.enabled = self.world > 1
+        self.handles = []
+        if not self.enabled:
+            return
+        cap = max(1, bucket_bytes // 4)
+        self.bucket_of = {}
+        self.buckets = []              # (start, end, n_params)
+        end = flat.total
+        count, start = 0, end
+        for idx in range(len(flat.params) - 1, -1, -1):
+            off, n = flat.offsets[idx]
+            start = off
+            count += 1
+            self.bucket_of[idx] = len(self.buckets)
+            if end - start >= cap or idx == 0:
+                self.buckets.append([start, end, count])
+                end, count = start, 0
+        self.pending = [b[2] for b in self.buckets]
+        for idx, p in enumerate(flat.params):
+            p.register_post_accumulate_grad_hook(self._make_hook(idx))
+
+    def _make_hook(self, idx):
+        def hook(param):
+            b = self.bucket_of[idx]
+            self.pending[b] -= 1
+            if self.pending[b] == 0:
+                s, e, _ = self.buckets[b]
+                self.handles.append(dist.all_reduce(self.flat.flat_g[s:e], op=dist.ReduceOp.SUM, async_op=True))
+        return hook
+
+    def finish(self):
+        """Wait for the in-flight buckets; returns the factor that turns the summed gradient into
+        the mean over ranks (applied inside the fused update)."""
+        if not self.enabled:
+            return 1.0
+        for b, left in enumerate(self.pending):
+            if left != 0:   # parameters that received no gradient this step (frozen / unused)
+                s, e, _ = self.buckets[b]
+                self.handles.append(dist.all_reduce(self.flat.flat_g[s:e], op=dist.ReduceOp.SUM, async_op=True))
+        for h in self.handles:
+            h.wait()
+        self.handles = []
+        self.pending = [b[2] for b in self.buckets]
+        return 1.0 / self.world
+
+
+class Trainer(object):
+    """``compile`` + ``fit`` in one object.
+
+    losses:  dict output_name -> (loss_fn(y_true, y_pred) -> [B], weight); outputs of the model
+             are matched by position (tuple outputs) in the dict's order.
+    metrics: dict output_name -> list of metric fns with ``.name``.
+    A batch from the sequences is ``(X, y)`` or ``(X, [y_1, y_2, ...])``."""
+
+    def __init__(self, model, losses, metrics=None, lr=0.1, momentum=0.9, nesterov=False, clipnorm=None, decay=0.0,
+                 l2_of=None, autocast_dtype=torch.bfloat16, bucket_bytes=25 << 20, trainable=None):
+        self.model = model
+        self.losses = losses
+        self.metrics = metrics or {}
+        self.lr, self.momentum, self.nesterov, self.clipnorm, self.decay = lr, momentum, nesterov, clipnorm, decay
+        self.autocast_dtype = autocast_dtype
+        self.iterations = 0
+        self.rank, self.world = dist_info()
+        self.is_main_process = self.rank == 0
+        if trainable is not None:
+            for name, p in model.named_parameters():
+                p.requires_grad_(trainable(name))
+        self.flat = FlatState(model, l2_of)
+        self.reducer = BucketedAllReduce(self.flat, bucket_bytes)
+        self.stop_training = False
+
+    # ---------------------------------------------------------------- one step
+
+    def _forward(self, X):
+        if self.autocast_dtype is not None and X.is_cuda:
+            with torch.autocast('cuda', dtype=self.autocast_dtype):
+                out = self.model(X)
+        else:
+            out = self.model(X)
+        return out if isinstance(out, (tuple, list)) else (out,)
+
+    def _loss_and_metrics(self, outs, y, logs):
+        ys = y if isinstance(y, (tuple, list)) else (y,)
+        total = None
+        for (name, (fn, weight)), out, yt in zip(self.losses.items(), outs, ys):
+            li = fn(yt, out)
+            # a fused loss head exposes the normalised embedding it computed; metrics are defined on it
+            m_in = getattr(fn, 'last_normalized', None)
+            m_in = out.detach() if m_in is None else m_in
+            mean = li.mean()
+            total = mean * weight if total is None else total + mean * weight
+            key = 'loss' if len(self.losses) == 1 else name + '_loss'
+            logs[key] = logs.get(key, 0) + mean.detach()
+            for m in self.metrics.get(name, ()):
+                mname = m.name if len(self.losses) == 1 else '{}_{}'.format(name, m.name)
+                with torch.no_grad():
+                    logs[mname] = logs.get(mname, 0) + m(yt, m_in).float().mean()
+        if len(self.losses) > 1:
+            logs['loss'] = logs.get('loss', 0) + total.detach()
+        return total
+
+    def train_step(self, X, y, logs):
+        flat = self.flat
+        flat.flat_g.zero_()
+        outs = self._forward(X)
+        loss = self._loss_and_metrics(outs, y, logs)
+        loss.backward()
+        scale = self.reducer.finish()
+        self.apply_update(scale)
+        return loss
+
+    def apply_update(self, grad_scale=1.0):
+        """Keras-SGD update on the flat buffers (regulariser -> clip -> decayed lr -> momentum)."""
+        flat = self.flat
+        g = flat.flat_g
+        if grad_scale != 1.0:
+            g.mul_(grad_scale)
+        if flat.has_l2:
+            g.addcmul_(flat.flat_l2, flat.flat_p)
+        if self.clipnorm:
+            norm = torch.linalg.vector_norm(g)
+            g.mul_(torch.clamp(self.clipnorm / (norm + 1e-12), max=1.0))   # stays on the device
+        lr = self.lr / (1.0 + self.decay * self.iterations) if self.decay > 0 else self.lr
+        v = flat.flat_v
+        v.mul_(self.momentum).add_(g, alpha=-lr)
+        if self.nesterov:
+            flat.flat_p.add_(v, alpha=self.momentum).add_(g, alpha=-lr)
+        else:
+            flat.flat_p.add_(v)
+        self.iterations += 1
+
+    # ---------------------------------------------------------------- loops
+
+    def _reduce_logs(self, logs, n):
+        out = {}
+        if not logs:
+            return out
+        keys = sorted(logs)
+        vec = torch.stack([torch.as_tensor(logs[k], dtype=torch.float32, device=self.flat.flat_p.device) for k in keys]) / max(n, 1)
+        if self.world > 1:
+            dist.all_reduce(vec, op=dist.ReduceOp.SUM)
+            vec /= self.world
+        for k, v in zip(keys, vec.tolist()):
+            out[k] = v
+        return out
+
+    def evaluate(self, seq):
+        self.model.eval()
+        logs, n = {}, 0
+        with torch.no_grad():
+            for i in range(len(seq)):
+                X, y = seq[i]
+                self._loss_and_metrics(self._forward(X), y, logs)
+                n += 1
+        self.model.train()
+        return self._reduce_logs(logs, n)
+
+    def predict(self, seq, steps=None):
+        """Model outputs for every batch of ``seq`` (rank-local rows), concatenated on the host."""
+        self.model.eval()
+        outs = None
+        with torch.no_grad():
+            for i in range(len(seq) if steps is None else steps):
+                batch = seq[i]
+                X = batch[0] if isinstance(batch, (tuple, list)) else batch
+                o = [t.float().cpu() for t in self._forward(X)]
+                outs = [[t] for t in o] if outs is None else [a + [t] for a, t in zip(outs, o)]
+        self.model.train()
+        cat = [torch.cat(a).numpy() for a in outs]
+        return cat[0] if len(cat) == 1 else cat
+
+    def fit(self, train_seq, validation_data=None, epochs=1, initial_epoch=0, callbacks=(), verbose=True, log_every=50):
+        self.model.train()
+        for cb in callbacks:
+            cb.on_train_begin(self)
+        history = []
+        for epoch in range(initial_epoch, epochs):
+            for cb in callbacks:
+                cb.on_epoch_begin(self, epoch)
+            logs, t0, nb = {}, time.time(), len(train_seq)
+            for b in range(nb):
+                X, y = train_seq[b]
+                self.train_step(X, y, logs)
+                for cb in callbacks:
+                    cb.on_batch_end(self, b, logs)
+                if verbose and self.is_main_process and (b + 1) % log_every == 0:
+                    print('\rEpoch {}/{} - batch {}/{} - {:.1f} img/s'.format(
+                        epoch + 1, epochs, b + 1, nb, (b + 1) * train_seq.batch_size / (time.time() - t0)), end='', flush=True)
+            train_seq.on_epoch_end()
+            ep_logs = self._reduce_logs(logs, nb)
+            if validation_data is not None:
+                ep_logs.update({'val_' + k: v for k, v in self.evaluate(validation_data).items()})
+            for cb in callbacks:
+                cb.on_epoch_end(self, epoch, ep_logs)
+            history.append(ep_logs)
+            if verbose and self.is_main_process:
+                # keep the "name: value" format the reference's README greps (CosineLoss.md:95-104)
+                print('\rEpoch {}/{} - {:.0f}s - '.format(epoch + 1, epochs, time.time() - t0) +
+                      ' - '.join('{}: {:.4f}'.format(k, v) for k, v in ep_logs.items()), flush=True)
+            if self.stop_training:
+                break
+        return history

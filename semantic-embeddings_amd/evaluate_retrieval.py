@@ -1,0 +1,248 @@
+"""Drop-in for the reference's ``evaluate_retrieval.py`` (same CLI flags, same
+``pairwise_retrieval`` signature and return convention), with the all-pairs distance + ranking
+executed by the MI355X kernels of libsehip.so instead of NumPy/OpenBLAS/numexpr on the host.
+
+reference: evaluate_retrieval.py:22-73 (pairwise_retrieval), :76-151 (reporting helpers),
+:155-208 (CLI).  Differences a user can observe:
+
+* ties in the ranking come back in canonical (distance, index) order -- the reference's
+  ``np.argsort`` is unstable and returns them in arbitrary order;
+* the ranking is produced query tile by query tile (the generator is genuinely lazy), so the
+  N x N distance matrix never has to exist at once;
+* there is no CPU fallback: without a ROCm device the call raises ``sehip.SehipError``.
+"""
+import argparse
+import os.path
+import pickle
+from collections import OrderedDict
+
+import numpy as np
+
+try:
+    from tqdm import tqdm
+except ImportError:  # pragma: no cover
+    def tqdm(it, **kwargs):
+        return it
+
+
+METRICS = ['P@1 (WUP)', 'P@10 (WUP)', 'P@50 (WUP)', 'P@100 (WUP)', 'AHP (WUP)',
+           'P@1 (LCS_HEIGHT)', 'P@10 (LCS_HEIGHT)', 'P@50 (LCS_HEIGHT)', 'P@100 (LCS_HEIGHT)', 'AHP (LCS_HEIGHT)', 'AP']
+
+# rows of the distance matrix ranked per launch group; bounds device memory to ~8 B x TILE x N
+DEFAULT_TILE_BYTES = 4 << 30
+
+
+def _as_feature_matrix(features):
+    """Input normalisation of evaluate_retrieval.py:43-54: path | dict | {'feat': dict} | ndarray."""
+    if isinstance(features, str):
+        with open(features, 'rb') as feat_dump:
+            features = pickle.load(feat_dump)
+    if isinstance(features, dict):
+        if 'feat' in features:
+            features = features['feat']
+        ind2id = np.array(list(features.keys()))
+        features = np.stack(list(features.values()))
+        if features.ndim > 2:
+            raise ValueError('Feature matrix must be 2-dimensional. Actual shape: {}'.format(features.shape))
+        owned = True
+    else:
+        ind2id = None
+        owned = False
+    return features, ind2id, owned
+
+
+def ranking_tiles(features, normalize=False, tile_rows=None, idx64=False, queries=None):
+    """Generator over ``(first_row, rank_tile)`` with ``rank_tile`` an int32 (int64 if ``idx64``)
+    DEVICE tensor ``[rows, N]``: the canonical ranking of queries ``first_row .. first_row+rows``.
+
+    ``features`` must already be a float32 device tensor ``[N, D]``; it is normalised in place when
+    ``normalize`` is set (like the reference mutates its input, evaluate_retrieval.py:58).
+    ``queries`` optionally restricts the query rows to ``range(*queries)``."""
+    import torch
+    import sehip
+
+    n, _ = features.shape
+    if normalize:
+        sehip.normalize_rows_(features)
+        metric, sq = sehip.METRIC_COSINE, None
+    else:
+        metric, sq = sehip.METRIC_EUCLID, sehip.row_sqnorm(features)
+    if tile_rows is None:
+        tile_rows = max(128, min(n, (DEFAULT_TILE_BYTES // (8 * max(n, 1))) // 128 * 128))
+    q0, q1 = (0, n) if queries is None else queries
+    pd = torch.empty((min(tile_rows, max(q1 - q0, 1)), n), dtype=torch.float32, device=features.device)
+    for r0 in range(q0, q1, tile_rows):
+        rows = min(tile_rows, q1 - r0)
+        sehip.pairwise_dist(features[r0:r0 + rows], features, metric=metric,
+                            sqa=None if sq is None else sq[r0:r0 + rows], sqb=sq, out=pd[:rows])
+        yield r0, sehip.rank_rows(pd[:rows], idx64=idx64)
+
+
+def pairwise_retrieval(features, normalize=False, return_generator=True):
+    """ Uses each image as query and retrieves its nearest neighbors.
+
+    # Arguments (identical to the reference, evaluate_retrieval.py:22-41):
+
+    - features: 2-d numpy array | dict id -> feature vector | dict with key 'feat' | path to a pickle of those.
+    - normalize: Whether to L2-normalize the features.
+    - return_generator: If True, a generator will be returned instead of a dictionary.
+
+    # Returns:
+        generator (or dict) of ``(image ID, list of all image IDs ordered by increasing distance)``.
+    """
+    import torch
+    import sehip  # raises SehipError if the HIP library is missing -- no CPU fallback
+
+    features, ind2id, owned = _as_feature_matrix(features)
+    feats_h = np.ascontiguousarray(features, dtype=np.float32)
+    sehip._lib.require_gpu()
+    dev = torch.from_numpy(feats_h).cuda()
+
+    def gen():
+        first = True
+        for r0, tile in ranking_tiles(dev, normalize):
+            if first and normalize and not owned and isinstance(features, np.ndarray) and features.dtype == np.float32:
+                # the reference normalises the caller's array in place (`features /= ...`)
+                np.copyto(features, dev.cpu().numpy())
+            first = False
+            ranks = tile.cpu().numpy()
+            for i in range(ranks.shape[0]):
+                ret = ranks[i]
+                if ind2id is not None:
+                    yield ind2id[r0 + i], ind2id[ret].tolist()
+                else:
+                    yield r0 + i, ret.tolist()
+
+    g = gen()
+    return g if return_generator else dict(g)
+
+
+def print_performance(perf, metrics=METRICS):
+    """Console table: one row per feature file, one column per metric (4 decimals)."""
+    name_w = max(map(len, perf))
+    col_w = [max(len(m), 6) for m in metrics]
+    header = [' ' * name_w] + [m.center(6) for m in metrics]
+    print('\n' + ' | '.join(header))
+    print('-' * (name_w + sum(3 + w for w in col_w)))
+    for name, res in perf.items():
+        cells = ['%*.4f' % (w, res[m]) for m, w in zip(metrics, col_w)]
+        print(' | '.join([name.ljust(name_w)] + cells))
+    print()
+
+
+def write_performance(perf, csv_file, prec_type='LCS_HEIGHT'):
+    """Semicolon-separated P@k table, k = 1.. as long as every result has that cut-off."""
+    names = list(perf)
+    lines = ['k;' + ';'.join(names)]
+    k = 1
+    while all('P@%d (%s)' % (k, prec_type) in perf[n] for n in names):
+        lines.append(';'.join([str(k)] + [str(perf[n]['P@%d (%s)' % (k, prec_type)]) for n in names]))
+        k += 1
+    with open(csv_file, 'w') as f:
+        f.write('\n'.join(lines) + '\n')
+
+
+def plot_performance(perf, kmax=100, prec_type='LCS_HEIGHT', clip_ahp=None):
+    """Figure 1: hierarchical precision@k curves; figure 2: (clipped) mAHP as horizontal bars."""
+    import matplotlib.pyplot as plt
+
+    ks = np.arange(1, kmax + 1)
+    fig1, ax = plt.subplots()
+    lowest = 1.0
+    for name, res in perf.items():
+        curve = np.array([res['P@%d (%s)' % (k, prec_type)] for k in ks])
+        ax.plot(ks, curve, label=name)
+        lowest = min(lowest, float(curve.min()))
+    floor = np.floor(lowest * 20) / 20
+    ax.set(xlabel='k', ylabel='Hierarchical Precision', xlim=(0, kmax), ylim=(floor if floor >= 0.3 else 0, 1))
+    ax.grid(True)
+    ax.legend(fontsize='x-small')
+
+    key = 'AHP%s (%s)' % ('@%d' % clip_ahp if clip_ahp else '', prec_type)
+    fig2, ax = plt.subplots()
+    for pos, (name, res) in enumerate(perf.items()):
+        ax.barh(pos + 0.5, res[key], 0.8)
+        ax.text(0.01, pos + 0.5, name, va='center', ha='left', color='white', fontsize='small')
+        ax.text(res[key] - 0.01, pos + 0.5, '{:.1%}'.format(res[key]), va='center', ha='right', color='white')
+    ax.set(xlabel='Mean Average Hierarchical Precision', yticks=[])
+    ax.grid(axis='x')
+    plt.show()
+
+
+def str2bool(v):
+    """argparse type for the --norm flag: yes/true/t/y/1 and no/false/f/n/0 (case-insensitive)."""
+    word = v.lower()
+    if word in ('yes', 'true', 't', 'y', '1'):
+        return True
+    if word in ('no', 'false', 'f', 'n', '0'):
+        return False
+    raise argparse.ArgumentTypeError('Boolean value expected.')
+
+
+def build_parser():
+    """Same flags, defaults and grouping as the reference CLI (evaluate_retrieval.py:157-174)."""
+    p = argparse.ArgumentParser(description='Hierarchical-precision evaluation of nearest-neighbour image retrieval (MI355X kernels).',
+                                formatter_class=argparse.ArgumentDefaultsHelpFormatter)
+    g = p.add_argument_group('Dataset')
+    g.add_argument('--dataset', type=str, required=True, help='Dataset name (see datasets.get_data_generator).')
+    g.add_argument('--data_root', type=str, required=True, help='Dataset root directory.')
+    g.add_argument('--hierarchy', type=str, required=True, help='Text file with one "<parent> <child>" pair per line.')
+    g.add_argument('--is_a', action='store_true', default=False, help='Lines of --hierarchy are "<child> <parent>" instead.')
+    g.add_argument('--str_ids', action='store_true', default=False, help='Class IDs are strings (default: integers).')
+    g.add_argument('--classes_from', type=str, default=None, help='Pickle with an "ind2label" item restricting/ordering the classes.')
+    g = p.add_argument_group('Features')
+    g.add_argument('--feat', type=str, action='append', required=True, help='Feature pickle {"feat": {image id: vector}}; repeatable.')
+    g.add_argument('--label', type=str, action='append', help='Display name for the matching --feat.')
+    g.add_argument('--norm', type=str2bool, action='append', help='L2-normalise the matching --feat (cosine ranking); default no.')
+    g = p.add_argument_group('Output')
+    g.add_argument('--plot_max', type=int, default=250, help='Largest k of the precision curve; 0 disables plotting.')
+    g.add_argument('--prec_type', type=str, default='LCS_HEIGHT', choices=['WUP', 'LCS_HEIGHT'], help='Class-similarity measure for the curve/CSV.')
+    g.add_argument('--clip_ahp', type=int, default=None, help='Compute AHP on the first CLIP_AHP ranks only.')
+    g.add_argument('--csv', type=str, default=None, help='Write the P@k table to this CSV file.')
+    return p
+
+
+def main(argv=None):
+    from datasets import get_data_generator
+    from class_hierarchy import ClassHierarchy
+
+    args = build_parser().parse_args(argv)
+
+    if args.classes_from:
+        with open(args.classes_from, 'rb') as f:
+            embed_labels = pickle.load(f)['ind2label']
+    else:
+        embed_labels = None
+    data_generator = get_data_generator(args.dataset, args.data_root, classes=embed_labels)
+    labels_test = [embed_labels[lbl] for lbl in data_generator.labels_test] if embed_labels is not None else data_generator.labels_test
+
+    id_type = str if args.str_ids else int
+    hierarchy = ClassHierarchy.from_file(args.hierarchy, is_a_relations=args.is_a, id_type=id_type)
+
+    ks = list(range(1, args.plot_max + 1))
+    for k in [1, 10, 50, 100]:
+        if (len(ks) == 0) or (ks[-1] < k):
+            ks.append(k)
+    perf = OrderedDict()
+    for i, feat_dump in tqdm(enumerate(args.feat), total=len(args.feat)):
+        feat_name = args.label[i] if (args.label is not None) and (i < len(args.label)) else os.path.splitext(os.path.basename(feat_dump))[0]
+        normalize = args.norm[i] if (args.norm is not None) and (i < len(args.norm)) else False
+        perf[feat_name] = hierarchy.hierarchical_precision(
+            pairwise_retrieval(feat_dump, normalize), labels_test, ks,
+            compute_ahp=args.clip_ahp if args.clip_ahp else True, compute_ap=True,
+            all_ids=list(range(data_generator.num_test)))[0]
+
+    metrics = list(METRICS)
+    if args.clip_ahp:
+        metrics[4] = 'AHP@{} (WUP)'.format(args.clip_ahp)
+        metrics[9] = 'AHP@{} (LCS_HEIGHT)'.format(args.clip_ahp)
+    print_performance(perf, metrics)
+    if args.csv:
+        write_performance(perf, args.csv, args.prec_type)
+    if args.plot_max > 0:
+        plot_performance(perf, args.plot_max, args.prec_type, args.clip_ahp)
+    return perf
+
+
+if __name__ == '__main__':
+    main()

@@ -13,7 +13,7 @@ from ._lib import (DTYPE_BF16, DTYPE_F32, METRIC_COSINE, METRIC_DOT, METRIC_EUCL
                    require_gpu, stream_ptr)
 
 __all__ = [
-    "cosine_embedding_loss", "cosine_loss_forward", "cosine_loss_backward", "nn_accuracy",
+    "cosine_embedding_loss", "cosine_loss_forward", "cosine_loss_backward", "l2norm", "nn_accuracy",
     "row_sqnorm", "normalize_rows_", "pairwise_dist", "rank_rows", "topk_rows", "topk_merge", "retrieve_topk",
     "METRIC_COSINE", "METRIC_EUCLID", "METRIC_DOT",
 ]
@@ -78,33 +78,69 @@ def cosine_loss_backward(x, labels, embedding, grad_loss_i=None, grad_scale=1.0,
 
 
 class _CosineEmbeddingLoss(torch.autograd.Function):
-    """Per-sample loss_i = 1 - <l2norm(x_i), E[y_i]> with the HIP forward/backward."""
+    """Per-sample loss_i = 1 - <l2norm(x_i), E[y_i]> with the HIP forward/backward; also returns
+    the normalised features the forward kernel produces anyway (non-differentiable by-product)."""
 
     @staticmethod
-    def forward(ctx, x, labels, embedding):
+    def forward(ctx, x, labels, embedding, want_xhat):
         x = x if x.stride(-1) == 1 else x.contiguous()
-        _, _, loss_i, _ = cosine_loss_forward(x, labels, embedding, want_xhat=False)
+        xhat, _, loss_i, _ = cosine_loss_forward(x, labels, embedding, want_xhat=want_xhat)
         ctx.save_for_backward(x, labels, embedding)
-        return loss_i
+        if xhat is None:
+            xhat = loss_i.new_empty(0)
+        ctx.mark_non_differentiable(xhat)
+        return loss_i, xhat
 
     @staticmethod
-    def backward(ctx, grad_loss_i):
+    def backward(ctx, grad_loss_i, _grad_xhat):
         x, labels, embedding = ctx.saved_tensors
         dx = cosine_loss_backward(x, labels, embedding, grad_loss_i.contiguous())
-        return dx, None, None
+        return dx, None, None, None
 
 
-def cosine_embedding_loss(x, labels, embedding, reduction="mean"):
+def cosine_embedding_loss(x, labels, embedding, reduction="mean", return_normalized=False):
     """Differentiable cosine-embedding loss on un-normalised features ``x`` [B, D].
 
     Equivalent to the reference's ``Lambda(utils.l2norm)`` head followed by
-    ``utils.inv_correlation(embedding[y], .)`` and Keras' batch mean."""
-    loss_i = _CosineEmbeddingLoss.apply(x, labels, embedding)
+    ``utils.inv_correlation(embedding[y], .)`` and Keras' batch mean.  With ``return_normalized``
+    the L2-normalised features (what the reference's model outputs) are returned as well."""
+    loss_i, xhat = _CosineEmbeddingLoss.apply(x, labels, embedding, bool(return_normalized))
     if reduction == "mean":
-        return loss_i.mean()
-    if reduction == "sum":
-        return loss_i.sum()
-    return loss_i
+        loss_i = loss_i.mean()
+    elif reduction == "sum":
+        loss_i = loss_i.sum()
+    return (loss_i, xhat) if return_normalized else loss_i
+
+
+class _L2Norm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        require_gpu(x)
+        shape = x.shape
+        x2 = x.reshape(-1, shape[-1])
+        x2 = x2 if x2.stride(-1) == 1 else x2.contiguous()
+        B, D = x2.shape
+        xhat = torch.empty((B, D), dtype=torch.float32, device=x.device)
+        inv = torch.empty((B,), dtype=torch.float32, device=x.device)
+        check(lib().se_l2norm_fwd(ptr(x2), _dtype_code(x2), x2.stride(0), B, D, ptr(xhat), D, ptr(inv), stream_ptr()),
+              "se_l2norm_fwd")
+        ctx.save_for_backward(xhat, inv)
+        ctx.in_dtype = x.dtype
+        return xhat.reshape(shape)
+
+    @staticmethod
+    def backward(ctx, grad):
+        xhat, inv = ctx.saved_tensors
+        B, D = xhat.shape
+        g = grad.reshape(B, D).to(torch.float32).contiguous()
+        dx = torch.empty_like(xhat)
+        check(lib().se_l2norm_bwd(ptr(g), D, ptr(xhat), D, ptr(inv), B, D, ptr(dx), D, stream_ptr()), "se_l2norm_bwd")
+        return dx.reshape(grad.shape).to(ctx.in_dtype)
+
+
+def l2norm(x):
+    """reference: utils.l2norm (utils.py:125-127) == tf.nn.l2_normalize(x, -1); float32 output."""
+    return _L2Norm.apply(x)
 
 
 def nn_accuracy(y_pred, labels, embedding, dot_prod_sim=False, k=1, want_scores=False, want_best=False):

@@ -1,0 +1,52 @@
+"""Sharded-gallery retrieval across the GPUs of one node (BASELINE.json configs[4], SURVEY.md
+section 8e row 3; not present in the reference, which ranks on one host).
+
+Every rank holds ``1/G`` of the gallery rows (plus their global row offset) and ALL queries.  Per
+step:  local fused distance + top-k over the shard  ->  one RCCL all-gather of the per-shard
+``(distance f32, global index i32)`` lists  ->  k-way merge under the canonical (distance, index)
+order.  Because ties are broken by the GLOBAL index the result does not depend on G.
+
+The all-gather moves ``Q * k * 8`` bytes per rank (100 MB at Q = 50k, k = 250); xGMI is a full
+mesh, so the direct all-gather keeps all 7 links of a GPU busy at once.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n, world):
+    """Row ranges of an n-row gallery split into ``world`` near-equal contiguous shards."""
+    base, extra = divmod(n, world)
+    bounds, start = [], 0
+    for r in range(world):
+        size = base + (1 if r < extra else 0)
+        bounds.append((start, start + size))
+        start += size
+    return bounds
+
+
+def sharded_topk(queries, gallery_shard, k, shard_offset, metric=None, group=None, local_topk=None, merge=None):
+    """Global top-k of ``queries`` against the gallery whose local shard is ``gallery_shard``.
+
+    Returns ``(dist [Q, k] f32, idx [Q, k] i32)`` identical on every rank.  ``local_topk`` /
+    ``merge`` default to the HIP kernels (``sehip.retrieve_topk`` / ``sehip.topk_merge``); tests
+    inject CPU stand-ins to exercise the collective logic under gloo."""
+    if local_topk is None or merge is None:
+        import sehip
+        metric = sehip.METRIC_COSINE if metric is None else metric
+        local_topk = local_topk or (lambda q, g, kk, off: sehip.retrieve_topk(q, g, kk, metric=metric, col_offset=off))
+        merge = merge or sehip.topk_merge
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    k_local = min(k, gallery_shard.shape[0])
+    d, i = local_topk(queries, gallery_shard, k_local, shard_offset)
+    if k_local < k:   # tiny shard: pad with +inf so every rank contributes [Q, k]
+        pad = k - k_local
+        d = torch.cat([d, torch.full((d.shape[0], pad), float('inf'), dtype=d.dtype, device=d.device)], dim=1)
+        i = torch.cat([i, torch.full((i.shape[0], pad), 2 ** 31 - 1, dtype=i.dtype, device=i.device)], dim=1)
+    if world == 1:
+        return d, i
+    q = d.shape[0]
+    all_d = torch.empty((world * q, k), dtype=d.dtype, device=d.device)     # rank-major concatenation
+    all_i = torch.empty((world * q, k), dtype=i.dtype, device=i.device)
+    dist.all_gather_into_tensor(all_d, d.contiguous(), group=group)
+    dist.all_gather_into_tensor(all_i, i.contiguous(), group=group)
+    return merge(all_d.view(world, q, k), all_i.view(world, q, k))

@@ -1,0 +1,186 @@
+"""CPU: host-side logic -- class hierarchy metrics vs values produced by the imported reference,
+LR schedules, the Keras-style SGD update on the flat buffers, model factory."""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def hier():
+    from class_hierarchy import ClassHierarchy
+    g = np.load(os.path.join(GOLDEN, "hierarchy_cifar.npz"))
+    with tempfile.NamedTemporaryFile("w", suffix=".txt", delete=False) as f:
+        for p, c in g["edges"]:
+            f.write("%d %d\n" % (p, c))
+    h = ClassHierarchy.from_file(f.name, id_type=int)
+    os.unlink(f.name)
+    return h, g
+
+
+def test_hierarchy_structure_matches_reference(hier):
+    h, g = hier
+    assert h.is_tree() and h.max_height == int(g["max_height"])
+    assert [h.heights[n] for n in g["nodes"]] == g["heights"].tolist()
+    wup = np.array([[h.wup_similarity(a, b) for b in range(100)] for a in range(100)])
+    lcs = np.array([[1.0 - h.lcs_height(a, b) for b in range(100)] for a in range(100)])
+    assert np.array_equal(wup, g["wup"])
+    assert np.array_equal(lcs, g["lcs"])
+
+
+def test_hierarchical_precision_matches_reference(hier):
+    """Rankings come from the canonical oracle here (CPU); the metric values were produced by the
+    reference's class_hierarchy + the reference's own rankings (equal up to tie order, which the
+    metrics of same-class ties cannot see)."""
+    from oracle import retrieval_oracle as ro
+    h, g = hier
+    labels = g["labels"].tolist()
+    ks = g["ks"].tolist()
+    want = dict(zip(g["metric_names"].tolist(), g["metric_values"].tolist()))
+    for norm in (True, False):
+        _, rk = ro.canon_retrieval(g["features"], norm)
+        ret = {i: rk[i].tolist() for i in range(len(labels))}
+        for ahp in (True, 50):
+            avg, per_q = h.hierarchical_precision(ret, labels, ks, compute_ahp=ahp, compute_ap=True, all_ids=list(range(len(labels))))
+            for m, v in avg.items():
+                assert v == pytest.approx(want["%s|norm=%d|ahp=%s" % (m, norm, ahp)], rel=1e-12, abs=1e-12), (m, norm, ahp)
+            assert len(per_q["AP"]) == len(labels)
+
+
+def test_hierarchy_generator_input_and_save_roundtrip(hier, tmp_path):
+    from class_hierarchy import ClassHierarchy
+    h, g = hier
+    h.save(str(tmp_path / "h.txt"))
+    h2 = ClassHierarchy.from_file(str(tmp_path / "h.txt"), id_type=int)
+    assert h2.heights == h.heights
+    h.save(str(tmp_path / "isa.txt"), is_a_relations=True)
+    h3 = ClassHierarchy.from_file(str(tmp_path / "isa.txt"), is_a_relations=True, id_type=int)
+    assert h3.lcs(3, 7) == h.lcs(3, 7)
+    labels = g["labels"].tolist()[:30]
+    ret = ((i, list(range(30))) for i in range(30))
+    avg, _ = h.hierarchical_precision(ret, labels, [1, 5], compute_ahp=False, compute_ap=False)
+    assert set(avg) == {"P@1 (WUP)", "P@1 (LCS_HEIGHT)", "P@5 (WUP)", "P@5 (LCS_HEIGHT)"}
+
+
+# ---------------------------------------------------------------- schedules
+
+class FakeTrainer:
+    lr = None
+    is_main_process = True
+
+
+def test_sgdr_schedule_values():
+    import utils
+    cbs, n = utils.get_lr_schedule("SGDR", 50000, 128, {})
+    assert n == 372
+    t = FakeTrainer()
+    cbs[0].on_train_begin(t)
+    assert t.lr == 0.1
+    lrs = []
+    for ep in range(14):
+        lrs.append(t.lr)
+        cbs[0].on_epoch_end(t, ep, {})
+    # sgdr_callback.py:63-87: after the i-th epoch of a cycle the lr is f(i + 1), i.e. f(1) is skipped
+    f = lambda i, T: 1e-6 + 0.5 * (0.1 - 1e-6) * (1 + np.cos(np.pi * i / T))
+    want = [0.1] + [f(i, 12) for i in range(2, 13)] + [0.1]
+    assert np.allclose(lrs[:13], want)
+    assert lrs[13] == pytest.approx(f(2, 24))
+
+
+def test_sgd_clr_and_resnet_schedules():
+    import utils
+    cbs, n = utils.get_lr_schedule("SGD", 1000, 10, {"sgd_schedule": "1:0.1,31:0.01,41:0.001,50"})
+    assert n == 50
+    t = FakeTrainer(); t.lr = 0.5
+    got = []
+    for ep in (0, 29, 30, 39, 40, 49):
+        cbs[0].on_epoch_begin(t, ep); got.append(t.lr)
+    assert got == [0.1, 0.1, 0.01, 0.01, 0.001, 0.001]
+    cbs, n = utils.get_lr_schedule("CLR", 1000, 10, {})
+    assert n == 240
+    t = FakeTrainer(); cbs[0].on_train_begin(t)
+    assert t.lr == 1e-5
+    for b in range(1200):
+        cbs[0].on_batch_end(t, b, {})
+    assert t.lr == pytest.approx(0.1)
+    cbs, n = utils.get_lr_schedule("ResNet-Schedule", 1000, 10, {})
+    assert n == 164
+    t = FakeTrainer(); t.lr = 1.0
+    got = []
+    for ep in (0, 1, 79, 80, 120):
+        cbs[0].on_epoch_begin(t, ep); got.append(t.lr)
+    assert got == [0.01, 0.1, 0.1, 0.01, 0.001]
+    cbs, n = utils.get_lr_schedule("SGD", 1000, 10, {})
+    assert n == 200 and isinstance(cbs[0], utils.ReduceLROnPlateau)
+    with pytest.raises(ValueError):
+        utils.get_lr_schedule("nope", 1, 1)
+
+
+# ---------------------------------------------------------------- model factory + update rule
+
+def test_build_network_contract():
+    import utils
+    m = utils.build_network(100, "resnet-110-fc", input_channels=3)
+    assert sum(p.numel() for p in m.parameters()) == 1737860
+    assert hasattr(m, "embedding") and m(torch.randn(2, 3, 32, 32)).shape == (2, 100)
+    assert utils.build_network(100, "resnet-110").forward(torch.randn(2, 3, 32, 32)).shape == (2, 64)   # the 64-d trap
+    c = utils.build_network(10, "resnet-32", classification=True)
+    assert hasattr(c, "prob") and torch.allclose(c(torch.randn(2, 3, 32, 32)).sum(-1), torch.ones(2), atol=1e-5)
+    w = utils.build_network(100, "resnet-110-wfc")
+    assert w.num_features == 128
+    r = utils.build_network(200, "resnet-50")
+    assert r(torch.randn(1, 3, 64, 64)).shape == (1, 200) and hasattr(r, "embedding")
+    with pytest.raises(NotImplementedError):
+        utils.build_network(10, "wrn-28-10")
+    with pytest.raises(ValueError):
+        utils.build_network(10, "not-a-net")
+    assert "ChannelPadding" in utils.get_custom_objects("resnet-110-fc")
+    assert utils.ARCHITECTURES[0] == "simple" and utils.LR_SCHEDULES == ["SGD", "SGDR", "CLR", "ResNet-Schedule"]
+
+
+def test_keras_sgd_update_on_flat_buffers():
+    """v = m v - lr g ; w += v with the L2 term added before global-norm clipping."""
+    import engine
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(5, 3)
+    w0, b0 = lin.weight.detach().clone(), lin.bias.detach().clone()
+    loss_fn = lambda y, o: ((o - y) ** 2).sum(-1)
+    tr = engine.Trainer(lin, {"out": (loss_fn, 1.0)}, {}, lr=0.1, momentum=0.9, clipnorm=0.5, l2_of={id(lin.weight): 0.01},
+                        autocast_dtype=None)
+    X, Y = torch.randn(4, 5), torch.randn(4, 3)
+    ref = torch.nn.Linear(5, 3)
+    ref.load_state_dict({"weight": w0, "bias": b0})
+    vw, vb = torch.zeros_like(w0), torch.zeros_like(b0)
+    for step in range(3):
+        tr.train_step(X, Y, {})
+        l = ((ref(X) - Y) ** 2).sum(-1).mean() + 0.01 * (ref.weight ** 2).sum()
+        gw, gb = torch.autograd.grad(l, [ref.weight, ref.bias])
+        norm = torch.sqrt((gw ** 2).sum() + (gb ** 2).sum())
+        s = min(1.0, 0.5 / float(norm))
+        vw = 0.9 * vw - 0.1 * gw * s
+        vb = 0.9 * vb - 0.1 * gb * s
+        with torch.no_grad():
+            ref.weight += vw
+            ref.bias += vb
+        assert torch.allclose(lin.weight, ref.weight, atol=1e-6), step
+        assert torch.allclose(lin.bias, ref.bias, atol=1e-6), step
+
+
+def test_synthetic_generator_interface():
+    from datasets import get_data_generator
+    g = get_data_generator("synthetic:10x8x64x32", ".")
+    assert (g.num_classes, g.num_train, g.num_test, g.num_channels) == (10, 64, 32, 3)
+    seq = g.train_sequence(16, shuffle=False)
+    assert len(seq) == 4
+    X, y = seq[1]
+    assert X.shape == (16, 3, 8, 8) and y.dtype == torch.int64 and len(g.labels_test) == 32
+    X2, _ = seq[1]
+    assert torch.equal(X, X2)                       # seeded per batch
+    half = g.train_sequence(16, shuffle=False, rank=1, world_size=2)[1]
+    assert half[0].shape[0] == 8 and torch.equal(half[1], y[1::2])
+    with pytest.raises(NotImplementedError):
+        get_data_generator("ilsvrc", ".")

@@ -1,0 +1,75 @@
+"""Training-step benchmark used by bench.py: ResNet-110-fc (or resnet-50) cosine-embedding
+training on synthetic batches -- forward (bf16 autocast), fused HIP loss fwd/bwd + MFMA accuracy
+metric, backward, RCCL gradient all-reduce, Keras-style SGD update.  Nothing is skipped inside the
+timed region (BASELINE.json configs[1] / configs[3])."""
+import os
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+
+
+def load_embedding(num_classes):
+    """CIFAR-100 / CUB unit-sphere class embeddings from the committed fixtures; for other sizes a
+    seeded random orthonormal-ish unit-sphere matrix of the same shape (C x C)."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "embeddings.npz"))
+    if num_classes == 100:
+        return g["cifar100_unitsphere"]
+    if num_classes == 200:
+        return g["cub_balanced_unitsphere"]
+    rng = np.random.default_rng(0)
+    e = np.linalg.qr(rng.standard_normal((num_classes, num_classes)))[0]
+    return e
+
+
+def bench_train(args, rank, world):
+    import utils
+    from datasets import SyntheticGenerator
+    from engine import Trainer
+
+    dev = torch.device("cuda", torch.cuda.current_device())
+    arch = args.arch
+    if arch == "resnet-50":
+        classes, size = 200, 224
+    else:
+        classes, size = 100, 32
+    emb = load_embedding(classes)
+    emb_dev = torch.from_numpy(emb.astype(np.float32)).to(dev)
+    torch.manual_seed(0)
+    model = utils.build_network(classes, arch, input_channels=3).to(dev)
+    loss = utils.CosineEmbeddingLoss(emb_dev)
+    metric = utils.nn_accuracy(emb_dev, dot_prod_sim=True)
+    l2_of = {id(p): model.regularizer for p in model.regularized_parameters()} if getattr(model, "regularizer", 0) else {}
+    trainer = Trainer(model, {"l2norm": (loss, 1.0)}, {"l2norm": [metric]}, lr=0.1, momentum=0.9, clipnorm=10.0, l2_of=l2_of)
+    B = args.batch                                   # per-GPU batch: weak scaling
+    gen = SyntheticGenerator(classes, size, 3, B * 64 * world, B * world)
+    seq = gen.train_sequence(B * world, shuffle=False, rank=rank, world_size=world)
+    batches = [seq[i] for i in range(8)]             # pre-generated, resident in HBM
+    logs = {}
+    steps, warm = max(args.steps, 20) if args.workload != "train" else args.steps, max(args.warmup, 5)
+    for i in range(warm):
+        trainer.train_step(*batches[i % len(batches)], logs)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        trainer.train_step(*batches[i % len(batches)], logs)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss_val = float(torch.as_tensor(logs["loss"]).item()) / (steps + warm)
+    return {"metric": "train_images_per_sec", "value": B * world * steps / dt, "unit": "images/s", "n_gpus": world,
+            "steps": steps, "warmup": warm, "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "%s cosine-embedding training step, %dx%dx3, %d classes, per-GPU batch %d" % (arch, size, size, classes, B),
+                       "global_batch": B * world, "parallelism": "dp%d" % world},
+            "mean_loss": loss_val}
