@@ -3,16 +3,22 @@
 // Replaces `ranking = np.argsort(pdist, axis = -1)` (evaluate_retrieval.py:67) with the canonical
 // tie rule: ascending (distance, index), NaN last, -0 == +0.
 //
-// One workgroup sorts one row (a "segment" of N keys) with a stable LSD radix sort on the
-// order-preserving uint32 image of the float keys.  Stability + initial index order give the
-// index tiebreak for free.  Each wave owns a contiguous chunk of the row:
-//   1. per-wave digit histograms (LDS atomics),
-//   2. one digit-major / wave-minor exclusive scan turns them into scatter cursors,
-//   3. each wave walks its chunk in order, 64 keys per step; lanes holding equal digits find each
-//      other with BITS ballots (wave-level multisplit), which yields the stable rank inside the
-//      step without LDS traffic; one LDS read + one LDS write per digit group moves the cursor.
-// Keys/indices ping-pong between two scratch rows in the caller's workspace (they stay in L2 /
-// Infinity Cache: 2 x 8 B x N per resident workgroup); the last pass writes indices only.
+// One workgroup sorts one row (a segment of N keys) with a stable LSD radix sort (8-bit digits, 4
+// passes) on the order-preserving uint32 image of the float keys; stability + initial index order
+// give the index tiebreak for free.  Structure per row:
+//   H. one streaming read of the row builds the digit histograms of ALL four passes (LDS atomics);
+//      their exclusive scans are the running output cursors gbase[pass][digit].
+//   P. each pass walks the row in tiles of RK_TILE keys held in registers (wave w owns a contiguous
+//      sub-chunk of the tile, 64 keys per step, coalesced loads):
+//        1. per-wave digit counts of the tile (LDS atomics) -> digit-major / wave-minor scan;
+//        2. stable rank inside the tile: lanes holding equal digits find each other with 8 ballots
+//           (wave multisplit), one LDS cursor read+write per digit group; keys/indices are written
+//           to their tile-sorted slot IN LDS;
+//        3. the tile is read back in sorted order and written to global memory at
+//           gbase[digit] + offset: consecutive lanes write consecutive addresses inside each digit
+//           run, so HBM/L2 see coalesced runs (~RK_TILE/256 keys) instead of 4-byte scatters.
+// Keys/indices ping-pong between two scratch rows per resident workgroup in the caller's workspace;
+// the last pass writes the index matrix only.
 // HBM-side algorithmic traffic: 4 N bytes in (distances) + 4 N bytes out (int32 ranks) per row.
 #include "se_common.h"
 
@@ -20,128 +26,182 @@ namespace se {
 
 constexpr int RK_THREADS = 512;
 constexpr int RK_WAVES = RK_THREADS / WAVE;
+constexpr int RK_ITEMS = 16;                       // keys per thread per tile
+constexpr int RK_TILE = RK_THREADS * RK_ITEMS;     // 8192
+constexpr int RK_WCHUNK = RK_TILE / RK_WAVES;      // 1024 keys per wave per tile
+constexpr int RK_NB = 256;
 
-template <int BITS>
-__device__ __forceinline__ void rank_one_pass(
-    int pass, int shift, int nbits_this, int N, int chunk,
-    const float *__restrict__ drow,                 // pass 0 source (distances)
-    const uint32_t *src_k, const uint32_t *src_i,   // later passes
-    uint32_t *dst_k, uint32_t *dst_i,               // all but the last pass
-    void *out_row, int idx64, bool last,
-    uint32_t *cnt /* LDS [RK_WAVES][1 << BITS] */, uint32_t *scan_tmp /* LDS [64] */)
+struct RankLds {
+    uint32_t gbase[4][RK_NB];        // running global cursors per pass
+    uint32_t wcnt[RK_WAVES][RK_NB];  // per-wave cursors inside the current tile
+    uint32_t tile_start[RK_NB];      // first tile-sorted slot of each digit
+    uint32_t wave_tot[RK_WAVES];
+    uint32_t tkeys[RK_TILE];
+    uint32_t tidx[RK_TILE];
+};
+
+__device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t &total)
 {
-    constexpr int NB = 1 << BITS;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t mask = (1u << nbits_this) - 1u;
-
-    for (int i = tid; i < RK_WAVES * NB; i += RK_THREADS) cnt[i] = 0;
-    __syncthreads();
-
-    const int beg = wave * chunk;
-    const int end = (beg + chunk < N) ? (beg + chunk) : N;
-
-    // ---- 1. per-wave histogram ----
-    uint32_t *mycnt = cnt + wave * NB;
-    for (int i = beg + lane; i < end; i += WAVE) {
-        const uint32_t key = (pass == 0) ? canon_key(drow[i]) : src_k[i];
-        atomicAdd(&mycnt[(key >> shift) & mask], 1u);
-    }
-    __syncthreads();
-
-    // ---- 2. exclusive scan, digit-major then wave-minor (done by wave 0) ----
-    if (wave == 0) {
-        constexpr int PER = NB / WAVE;  // digits per lane (NB >= 64)
-        uint32_t local = 0;
-        for (int dd = 0; dd < PER; dd++) {
-            const int dgt = lane * PER + dd;
-            for (int w = 0; w < RK_WAVES; w++) local += cnt[w * NB + dgt];
-        }
-        // exclusive wave scan of `local`
-        uint32_t incl = local;
+    const int lane = lane_id();
+    uint32_t incl = v;
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t v = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += v;
-        }
-        uint32_t run = incl - local;
-        for (int dd = 0; dd < PER; dd++) {
-            const int dgt = lane * PER + dd;
-            for (int w = 0; w < RK_WAVES; w++) {
-                const uint32_t c = cnt[w * NB + dgt];
-                cnt[w * NB + dgt] = run;
-                run += c;
-            }
-        }
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
     }
-    (void)scan_tmp;
-    __syncthreads();
-
-    // ---- 3. stable scatter, 64 keys per step ----
-    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    volatile uint32_t *cur = mycnt;
-    for (int i0 = beg; i0 < end; i0 += WAVE) {
-        const int i = i0 + lane;
-        const bool valid = i < end;
-        uint32_t key = 0, idx = 0;
-        if (valid) {
-            if (pass == 0) { key = canon_key(drow[i]); idx = (uint32_t)i; }
-            else { key = src_k[i]; idx = src_i[i]; }
-        }
-        const uint32_t dgt = (key >> shift) & mask;
-        uint64_t peers = __ballot(valid);
-#pragma unroll
-        for (int bb = 0; bb < BITS; bb++) {
-            const bool bit = (dgt >> bb) & 1u;
-            const uint64_t m = __ballot(bit && valid);
-            peers &= bit ? m : ~m;
-        }
-        const int rank = __popcll(peers & lt_mask);
-        const int npeers = __popcll(peers);
-        uint32_t pos = 0;
-        if (valid) {
-            const uint32_t base = cur[dgt];
-            pos = base + (uint32_t)rank;
-            if (rank == npeers - 1) cur[dgt] = base + (uint32_t)npeers;
-        }
-        if (valid) {
-            if (last) {
-                if (idx64) ((int64_t *)out_row)[pos] = (int64_t)idx;
-                else ((int32_t *)out_row)[pos] = (int32_t)idx;
-            } else {
-                dst_k[pos] = key;
-                dst_i[pos] = idx;
-            }
-        }
-    }
-    __syncthreads();
+    total = __shfl(incl, 63, 64);
+    return incl - v;
 }
 
-template <int BITS>
+template <bool IDX64>
 __global__ __launch_bounds__(RK_THREADS) void rank_rows_kernel(const float *__restrict__ pdist, int64_t ldp,
-                                                               int64_t Q, int N, void *rank, int idx64,
-                                                               int64_t ldr, uint32_t *ws, int64_t n_pad)
+                                                               int64_t Q, int N, void *rank, int64_t ldr,
+                                                               uint32_t *ws, int64_t n_pad)
 {
-    extern __shared__ __attribute__((aligned(16))) uint32_t rk_lds[];
-    uint32_t *cnt = rk_lds;
-    uint32_t *scan_tmp = rk_lds + RK_WAVES * (1 << BITS);
-    // per-workgroup scratch: keysA, idxA, keysB, idxB
+    extern __shared__ __attribute__((aligned(16))) unsigned char rk_raw[];
+    RankLds &L = *reinterpret_cast<RankLds *>(rk_raw);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+
     uint32_t *kA = ws + (int64_t)blockIdx.x * 4 * n_pad;
     uint32_t *iA = kA + n_pad, *kB = iA + n_pad, *iB = kB + n_pad;
-    constexpr int NPASS = (32 + BITS - 1) / BITS;
-    int chunk = (N + RK_WAVES - 1) / RK_WAVES;
-    chunk = (chunk + WAVE - 1) / WAVE * WAVE;
+    const int ntiles = (N + RK_TILE - 1) / RK_TILE;
 
     for (int64_t row = blockIdx.x; row < Q; row += gridDim.x) {
         const float *drow = pdist + row * ldp;
-        void *orow = idx64 ? (void *)((int64_t *)rank + row * ldr) : (void *)((int32_t *)rank + row * ldr);
-        for (int p = 0; p < NPASS; p++) {
-            const int shift = p * BITS;
-            const int nb = (32 - shift < BITS) ? (32 - shift) : BITS;
+
+        // ---------------- H: histograms of all four digits, one read of the row ----------------
+        __syncthreads();
+        for (int i = tid; i < 4 * RK_NB; i += RK_THREADS) (&L.gbase[0][0])[i] = 0;
+        __syncthreads();
+        for (int i = tid; i < N; i += RK_THREADS) {
+            const uint32_t key = canon_key(drow[i]);
+            atomicAdd(&L.gbase[0][key & 0xFF], 1u);
+            atomicAdd(&L.gbase[1][(key >> 8) & 0xFF], 1u);
+            atomicAdd(&L.gbase[2][(key >> 16) & 0xFF], 1u);
+            atomicAdd(&L.gbase[3][key >> 24], 1u);
+        }
+        __syncthreads();
+        if (wave < 4) {  // wave p scans histogram p (4 digits per lane)
+            uint32_t c[4], s = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) { c[j] = L.gbase[wave][lane * 4 + j]; s += c[j]; }
+            uint32_t tot;
+            uint32_t run = wave_excl_scan(s, tot);
+#pragma unroll
+            for (int j = 0; j < 4; j++) { L.gbase[wave][lane * 4 + j] = run; run += c[j]; }
+        }
+        __syncthreads();
+
+        // ---------------- P: four stable counting passes ----------------
+#pragma unroll 1
+        for (int p = 0; p < 4; p++) {
+            const int shift = p * 8;
             const uint32_t *sk = (p & 1) ? kA : kB;
             const uint32_t *si = (p & 1) ? iA : iB;
             uint32_t *dk = (p & 1) ? kB : kA;
             uint32_t *di = (p & 1) ? iB : iA;
-            rank_one_pass<BITS>(p, shift, nb, N, chunk, drow, sk, si, dk, di, orow, idx64, p == NPASS - 1, cnt, scan_tmp);
+            const bool last = (p == 3);
+#pragma unroll 1
+            for (int t = 0; t < ntiles; t++) {
+                const int tbase = t * RK_TILE;
+                const int tcount = (N - tbase < RK_TILE) ? (N - tbase) : RK_TILE;
+                const int wbeg = wave * RK_WCHUNK;   // tile-local first element of this wave
+
+                // 1a. load the wave's sub-chunk (coalesced), zero own counters
+                uint32_t key[RK_ITEMS], idx[RK_ITEMS];
+#pragma unroll
+                for (int s = 0; s < RK_ITEMS; s++) {
+                    const int li = wbeg + s * WAVE + lane;
+                    const int gi = tbase + li;
+                    if (li < tcount) {
+                        if (p == 0) { key[s] = canon_key(drow[gi]); idx[s] = (uint32_t)gi; }
+                        else { key[s] = sk[gi]; idx[s] = si[gi]; }
+                    } else { key[s] = 0xFFFFFFFFu; idx[s] = 0xFFFFFFFFu; }
+                }
+#pragma unroll
+                for (int j = 0; j < RK_NB / WAVE; j++) L.wcnt[wave][j * WAVE + lane] = 0;
+                // 1b. per-wave digit counts
+#pragma unroll
+                for (int s = 0; s < RK_ITEMS; s++) {
+                    const int li = wbeg + s * WAVE + lane;
+                    if (li < tcount) atomicAdd(&L.wcnt[wave][(key[s] >> shift) & 0xFF], 1u);
+                }
+                __syncthreads();
+                // 1c. digit-major / wave-minor exclusive scan (threads 0..255 own one digit each)
+                uint32_t my_total = 0;
+                if (tid < RK_NB) {
+                    uint32_t run = 0;
+#pragma unroll
+                    for (int w = 0; w < RK_WAVES; w++) {
+                        const uint32_t c = L.wcnt[w][tid];
+                        L.wcnt[w][tid] = run;
+                        run += c;
+                    }
+                    my_total = run;
+                    uint32_t wtot;
+                    const uint32_t ex = wave_excl_scan(my_total, wtot);
+                    if (lane == 63) L.wave_tot[wave] = wtot;
+                    L.tile_start[tid] = ex;  // still missing the totals of the lower waves
+                }
+                __syncthreads();
+                if (tid < RK_NB) {
+                    uint32_t add = 0;
+                    for (int w = 0; w < wave; w++) add += L.wave_tot[w];
+                    const uint32_t st = L.tile_start[tid] + add;
+                    L.tile_start[tid] = st;
+#pragma unroll
+                    for (int w = 0; w < RK_WAVES; w++) L.wcnt[w][tid] += st;
+                }
+                __syncthreads();
+
+                // 2. stable rank inside the tile, place into LDS in tile-sorted order
+                volatile uint32_t *cur = L.wcnt[wave];
+#pragma unroll
+                for (int s = 0; s < RK_ITEMS; s++) {
+                    const int li = wbeg + s * WAVE + lane;
+                    const bool valid = li < tcount;
+                    const uint32_t dgt = (key[s] >> shift) & 0xFF;
+                    uint64_t peers = __ballot(valid);
+#pragma unroll
+                    for (int bb = 0; bb < 8; bb++) {
+                        const bool bit = (dgt >> bb) & 1u;
+                        const uint64_t m = __ballot(bit && valid);
+                        peers &= bit ? m : ~m;
+                    }
+                    if (valid) {
+                        const int rnk = __popcll(peers & lt_mask);
+                        const int npeers = __popcll(peers);
+                        const uint32_t base = cur[dgt];
+                        if (rnk == npeers - 1) cur[dgt] = base + (uint32_t)npeers;
+                        L.tkeys[base + rnk] = key[s];
+                        L.tidx[base + rnk] = idx[s];
+                    }
+                }
+                __syncthreads();
+
+                // 3. coalesced write-out of the tile-sorted keys
+#pragma unroll
+                for (int j = 0; j < RK_ITEMS; j++) {
+                    const int i = j * RK_THREADS + tid;
+                    if (i < tcount) {
+                        const uint32_t k = L.tkeys[i];
+                        const uint32_t id = L.tidx[i];
+                        const uint32_t d = (k >> shift) & 0xFF;
+                        const uint32_t gpos = L.gbase[p][d] + ((uint32_t)i - L.tile_start[d]);
+                        if (last) {
+                            if (IDX64) ((int64_t *)rank)[row * ldr + gpos] = (int64_t)id;
+                            else ((int32_t *)rank)[row * ldr + gpos] = (int32_t)id;
+                        } else {
+                            dk[gpos] = k;
+                            di[gpos] = id;
+                        }
+                    }
+                }
+                __syncthreads();
+                if (tid < RK_NB) L.gbase[p][tid] += my_total;
+                // (next tile's first barrier orders this update before its use)
+            }
         }
     }
 }
@@ -152,8 +212,8 @@ using namespace se;
 
 static int rank_grid(int64_t q)
 {
-    // resident workgroups: 256 CUs x up to 4 (512-thread, <= 16 KB LDS) -> 1024 scratch slots
-    int64_t g = 1024;
+    // resident workgroups: 256 CUs x 2 (512 threads, ~78 KB LDS each)
+    const int64_t g = 512;
     return (int)(q < g ? q : g);
 }
 
@@ -173,10 +233,15 @@ extern "C" int se_rank_rows(const float *pdist, int64_t ldp, int64_t q, int64_t 
     if (!pdist || !rank || ldp < n || ldr < n) return fail(SE_ERR_INVALID, "se_rank_rows: bad argument");
     const int64_t need = se_rank_rows_workspace_bytes(q, n);
     if (!workspace || workspace_bytes < need) return fail(SE_ERR_WORKSPACE, "se_rank_rows: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)need);
-    constexpr int BITS = 8;
-    const size_t lds = (size_t)(RK_WAVES * (1 << BITS) + 64) * sizeof(uint32_t);
-    hipLaunchKernelGGL(rank_rows_kernel<BITS>, dim3((unsigned)rank_grid(q)), dim3(RK_THREADS), lds, (hipStream_t)stream,
-                       pdist, ldp, q, (int)n, rank, idx64, ldr, (uint32_t *)workspace, rank_npad(n));
+    const size_t lds = sizeof(RankLds);
+    hipStream_t s = (hipStream_t)stream;
+    if (idx64) {
+        SE_HIP_CHECK(hipFuncSetAttribute((const void *)rank_rows_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(rank_rows_kernel<true>, dim3((unsigned)rank_grid(q)), dim3(RK_THREADS), lds, s, pdist, ldp, q, (int)n, rank, ldr, (uint32_t *)workspace, rank_npad(n));
+    } else {
+        SE_HIP_CHECK(hipFuncSetAttribute((const void *)rank_rows_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(rank_rows_kernel<false>, dim3((unsigned)rank_grid(q)), dim3(RK_THREADS), lds, s, pdist, ldp, q, (int)n, rank, ldr, (uint32_t *)workspace, rank_npad(n));
+    }
     SE_LAUNCH_CHECK();
     return SE_OK;
 }

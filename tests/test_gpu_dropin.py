@@ -1,0 +1,115 @@
+"""GPU: the drop-in Python interfaces (reference signatures) running on the HIP kernels --
+evaluate_retrieval.pairwise_retrieval, utils losses/metrics, one training step of the engine."""
+import glob
+import os
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import loss_oracle as lo
+from oracle import retrieval_oracle as ro
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "retrieval_*.npz"))))
+def test_pairwise_retrieval_dropin_vs_reference_output(path):
+    import evaluate_retrieval as er
+    g = np.load(path)
+    feats, norm = g["features"].astype(np.float32), bool(g["normalize"])
+    ref = g["ref_ranking"]
+    if "ids" in g.files:
+        inp = {"feat": {int(i): f.copy() for i, f in zip(g["ids"], feats)}}
+        ids = [int(i) for i in g["ids"]]
+    else:
+        inp, ids = feats.copy(), list(range(len(feats)))
+    got = er.pairwise_retrieval(inp, normalize=norm, return_generator=False)
+    assert list(got.keys()) == ids
+    pd, _ = ro.canon_retrieval(feats, norm)
+    pos = {v: i for i, v in enumerate(ids)}
+    for r, qid in enumerate(ids):
+        mine = np.array([pos[v] for v in got[qid]])
+        theirs = np.array([pos[int(v)] for v in ref[r]])
+        assert sorted(mine.tolist()) == list(range(len(ids)))
+        assert np.array_equal(pd[r][mine], pd[r][theirs])          # equal up to order inside exact ties
+    if norm and not isinstance(inp, dict):                          # the reference normalises its input in place
+        assert np.array_equal(inp, ro.canon_normalize_rows(feats))
+
+
+def test_pairwise_retrieval_generator_pickle_and_errors(tmp_path):
+    import evaluate_retrieval as er
+    rng = np.random.default_rng(0)
+    feats = {i * 3: rng.standard_normal(8).astype(np.float32) for i in range(20)}
+    p = tmp_path / "feat.pickle"
+    with open(p, "wb") as f:
+        pickle.dump({"feat": feats}, f)
+    gen = er.pairwise_retrieval(str(p), normalize=True)
+    first = next(gen)
+    assert first[0] == 0 and first[1][0] == 0 and len(first[1]) == 20 and isinstance(first[1], list)
+    with pytest.raises(ValueError):
+        er.pairwise_retrieval({i: np.zeros((2, 2), np.float32) for i in range(3)})
+
+
+def test_utils_losses_and_metrics_keras_signature():
+    import utils
+    E = np.load(os.path.join(GOLDEN, "embeddings.npz"))["cifar100_unitsphere"]
+    Ed = torch.from_numpy(E.astype(np.float32)).cuda()
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal((64, 100)).astype(np.float32)
+    y = rng.integers(0, 100, size=64)
+    xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    xn = utils.l2norm(xd)
+    assert np.abs(xn.cpu().numpy() - lo.l2norm(x.astype(np.float64))).max() < 1e-6
+    li = utils.inv_correlation(Ed[yd], xn)                         # reference convention: gathered y_true
+    want = lo.cosine_loss_fwd(x, y, E)["loss_i"]
+    assert np.abs(li.cpu().numpy() - want).max() < 1e-5
+    fused = utils.CosineEmbeddingLoss(Ed)(yd, xd)
+    assert np.abs(fused.cpu().numpy() - want).max() < 1e-5
+    m = utils.nn_accuracy(E, dot_prod_sim=True)
+    assert m.name == "max_sim_acc" and utils.nn_accuracy(E, True, 5).name == "max_sim_acc5" and utils.nn_accuracy(E).name == "nn_accuracy"
+    a_lab = m(yd, xn).cpu().numpy()
+    a_emb = m(Ed[yd], xn).cpu().numpy()                            # y_true as embeddings, like the reference
+    assert np.array_equal(a_lab, a_emb)
+    assert np.array_equal(a_lab, lo.nn_accuracy(E, True)(E[y], lo.l2norm(x.astype(np.float64))).astype(np.float32))
+    # l2norm backward through autograd vs oracle closed form
+    xr = xd.clone().requires_grad_(True)
+    (utils.inv_correlation(Ed[yd], utils.l2norm(xr)) / 64).sum().backward()
+    assert np.abs(xr.grad.cpu().numpy() - lo.cosine_loss_bwd(x, y, E, np.full(64, 1 / 64))).max() < 1e-7
+    d = utils.devise_ranking_loss(E)(yd, xn).cpu().numpy()
+    assert np.allclose(d, lo.devise_ranking_loss(E)(E[y], lo.l2norm(x.astype(np.float64))), atol=1e-4)
+    assert np.allclose(utils.squared_distance(Ed[yd], xd).cpu().numpy(), lo.squared_distance(E[y], x), rtol=1e-5)
+
+
+def test_training_step_resnet110_fc_uses_hip_loss_and_learns():
+    import utils
+    from datasets import SyntheticGenerator
+    from engine import Trainer
+    E = np.load(os.path.join(GOLDEN, "embeddings.npz"))["cifar100_unitsphere"]
+    Ed = torch.from_numpy(E.astype(np.float32)).cuda()
+    torch.manual_seed(0)
+    model = utils.build_network(100, "resnet-110-fc", input_channels=3).cuda()
+    loss = utils.CosineEmbeddingLoss(Ed)
+    l2 = {id(p): model.regularizer for p in model.regularized_parameters()}
+    tr = Trainer(model, {"l2norm": (loss, 1.0)}, {"l2norm": [utils.nn_accuracy(Ed, dot_prod_sim=True)]}, lr=0.05, clipnorm=10.0, l2_of=l2)
+    gen = SyntheticGenerator(100, 32, 3, 256, 64)
+    X, y = gen.train_sequence(64, shuffle=False)[0]
+    logs = {}
+    first = float(tr.train_step(X, y, logs).detach())
+    for _ in range(14):
+        last = float(tr.train_step(X, y, logs).detach())
+    assert np.isfinite(last) and last < first - 0.05                # memorises the fixed batch
+    assert "max_sim_acc" in logs and loss.last_normalized.shape == (64, 100)
+    # the fused head agrees with the oracle on the raw outputs the backbone produced
+    model.eval()
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        raw = model(X)
+    li = loss(y, raw)
+    want = lo.cosine_loss_fwd(raw.float().cpu().numpy().astype(np.float64), y.cpu().numpy(), E)["loss_i"]
+    assert np.abs(li.cpu().numpy() - want).max() < 1e-4
+    ev = tr.evaluate(gen.test_sequence(32))
+    assert set(ev) == {"loss", "max_sim_acc"}
+    feats = tr.predict(gen.test_sequence(32))
+    assert feats.shape == (64, 100)
