@@ -108,16 +108,28 @@ __global__ __launch_bounds__(RK_THREADS) void rank_rows_kernel(const float *__re
                 const int tcount = (N - tbase < RK_TILE) ? (N - tbase) : RK_TILE;
                 const int wbeg = wave * RK_WCHUNK;   // tile-local first element of this wave
 
-                // 1a. load the wave's sub-chunk (coalesced), zero own counters
+                // 1a. load the wave's sub-chunk (coalesced), zero own counters.  Loads are unconditional
+                //     (clamped index + select): branching around each load would serialise them.
                 uint32_t key[RK_ITEMS], idx[RK_ITEMS];
+                if (p == 0) {
 #pragma unroll
-                for (int s = 0; s < RK_ITEMS; s++) {
-                    const int li = wbeg + s * WAVE + lane;
-                    const int gi = tbase + li;
-                    if (li < tcount) {
-                        if (p == 0) { key[s] = canon_key(drow[gi]); idx[s] = (uint32_t)gi; }
-                        else { key[s] = sk[gi]; idx[s] = si[gi]; }
-                    } else { key[s] = 0xFFFFFFFFu; idx[s] = 0xFFFFFFFFu; }
+                    for (int s = 0; s < RK_ITEMS; s++) {
+                        const int li = wbeg + s * WAVE + lane;
+                        const int gi = tbase + li;
+                        const float f = drow[gi < N ? gi : N - 1];
+                        key[s] = (li < tcount) ? canon_key(f) : 0xFFFFFFFFu;
+                        idx[s] = (uint32_t)gi;
+                    }
+                } else {
+#pragma unroll
+                    for (int s = 0; s < RK_ITEMS; s++) {
+                        const int li = wbeg + s * WAVE + lane;
+                        const int gi = tbase + li;
+                        const int gc = gi < N ? gi : N - 1;
+                        const uint32_t k = sk[gc], i2 = si[gc];
+                        key[s] = (li < tcount) ? k : 0xFFFFFFFFu;
+                        idx[s] = i2;
+                    }
                 }
 #pragma unroll
                 for (int j = 0; j < RK_NB / WAVE; j++) L.wcnt[wave][j * WAVE + lane] = 0;
