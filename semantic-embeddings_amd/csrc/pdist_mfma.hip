@@ -9,94 +9,102 @@
 // reference's OpenBLAS sgemm/ssyrk produces for D <= 448.  For larger D the optional K-block list
 // restarts the chain per block and adds block results in order.
 //
-// Structure: persistent workgroups (2 per CU, 256 threads = 2 x 2 waves, 64 x 64 outputs per wave
-// = 2 x 2 MFMA tiles, 64 accumulator VGPRs) walk 128 x 128 output tiles.  Operands are staged
-// through LDS in K-chunks of 64 with even and odd k de-interleaved, so each lane feeds four MFMA
-// steps from one 16-byte ds_read_b128; the row pitch is padded to 68 floats (conflict-free reads).
+// Structure: persistent workgroups (2 per CU, 512 threads = 4 x 2 waves, 32 x 64 outputs per wave
+// = 1 x 2 MFMA tiles, 32 accumulator VGPRs -> 4 waves per SIMD keep the matrix pipe fed while
+// other waves stage or store) walk 128 x 128 output tiles.  Operands are staged through LDS in
+// K-chunks of 64 with even and odd k de-interleaved, so each lane feeds four MFMA steps from one
+// 16-byte ds_read_b128; the row pitch is padded to 68 floats (conflict-free reads).
 // The (tile, chunk) sequence is software-pipelined: while the MFMAs of chunk i run out of LDS, the
 // global loads of chunk i+1 -- possibly the first chunk of the NEXT tile -- are already in flight
 // into registers, and the accumulator stores of a finished tile overlap the next tile's MFMAs.
-// Tile order: block b stays on XCD b % 8; every XCD owns a contiguous band of the tile space in
-// "16 tile-rows deep" grouped order and its workgroups sweep it together, so a gallery panel is
-// re-read from that XCD's private L2 instead of HBM.
+// All global addressing is "uniform 64-bit tile base + 32-bit lane offset" to keep the VGPR count
+// under the 128 that 4 waves per SIMD allow (a spilled prefetch register would serialise the loads).
+// Tile order: block b stays on XCD b % 8; every XCD owns a contiguous band of the tile list and
+// its workgroups sweep it together, so operand panels are re-read from that XCD's private L2.
 //
-// Roofline: 2*D flop per output element against 4 output bytes: at D = 100 fp32 (157 TFLOP/s peak)
-// the kernel is MFMA-bound (3.2 ms for 50k x 50k) while the HBM bound is 1.25 ms.
+// Symmetric mode (a == b, the reference's ssyrk case `features . features^T`): only tiles on or
+// above the diagonal are computed; an off-diagonal tile is also written transposed (the transposed
+// element is the same FMA chain with commuted factors, i.e. bit-identical).  The transposed write
+// is 16 bytes per lane straight from the accumulator layout (4 consecutive rows per register
+// group).  This halves the MFMA work, which is what bounds the kernel at D = 100
+// (2*D flop per 4 output bytes: 3.2 ms of fp32 MFMA vs 1.25 ms of HBM time for 50k x 50k).
 #include "se_common.h"
+#include <stdlib.h>
 
 namespace se {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int PD_BM = 128, PD_BN = 128, PD_BK = 64;
+constexpr int PD_THREADS = 512;
 constexpr int PD_LD = PD_BK + 4;  // padded LDS row pitch in floats
 constexpr int PD_GROUP_M = 16;
 constexpr int PD_MAX_KB = 16;
 constexpr int PD_WGS_PER_CU = 2;
+constexpr int PD_NLOAD = PD_BM * (PD_BK / 4) / PD_THREADS;  // float4 per operand per thread = 4
+constexpr int64_t PD_MAX_LD = (int64_t)1 << 23;              // 128 rows * ld must fit 32-bit offsets
 
 struct KBlocks {
     int n;
     int len[PD_MAX_KB];
 };
 
-struct Staged {            // one K-chunk of a tile in registers: 8 + 8 float4 per thread
-    float4 a[8], b[8];
-};
+__device__ __forceinline__ float mask_f(float x, bool keep)
+{
+    return __uint_as_float(__float_as_uint(x) & (keep ? 0xFFFFFFFFu : 0u));   // branch-free, NaN-safe zeroing
+}
 
-// Global -> registers: rows [row0, row0+128) x k [k0, k0+64), zero filled outside [0,nrows) x [0,kend).
-// Every load is UNCONDITIONAL (clamped address + select): a branch around a load makes hipcc wait for
-// each load before issuing the next one, which serialises 16 L2 round trips per chunk.
-__device__ __forceinline__ void pd_load(float4 (&v)[8], const float *__restrict__ src, int64_t ld, int64_t row0,
-                                        int64_t nrows, int64_t k0, int64_t kend, bool vec_ok)
+// Global -> registers: rows [row0, row0+128) x k [k0, k0+64) of `src`, zero outside [0,nrows) x [0,kend).
+// Loads are UNCONDITIONAL (clamped 32-bit offsets from a uniform base, then bit-masking): a branch
+// around a load makes hipcc wait for each load before issuing the next one.
+template <bool VEC>
+__device__ __forceinline__ void pd_load(float4 (&v)[PD_NLOAD], const float *__restrict__ src, uint32_t ld, int64_t row0,
+                                        int64_t nrows, int64_t k0, int64_t kend)
 {
     const int tid = threadIdx.x;
-    if (vec_ok) {  // ld % 4 == 0, 16-byte aligned base, k0 % 4 == 0: a float4 at k < ld never leaves its row
+    const int r0 = tid >> 4, kq = (tid & 15) * 4;
+    const float *base = src + row0 * (int64_t)ld;                 // uniform
+    const int rows_here = (int)((nrows - row0 < PD_BM) ? (nrows - row0) : PD_BM);   // >= 1
+    const int klen = (int)(kend - k0);                            // valid k in this chunk (may exceed 64)
+    if (VEC) {   // ld % 4 == 0, 16-byte aligned base, k0 % 4 == 0: a float4 at k <= ld-4 never leaves its row
+        const int kmax = (int)ld - 4 - (int)k0;
+        const uint32_t kc = (uint32_t)(k0 + (kq < kmax ? kq : kmax));
 #pragma unroll
-        for (int it = 0; it < 8; it++) {
-            const int idx = it * 256 + tid;
-            const int r = idx >> 4, kq = (idx & 15) * 4;
-            const int64_t gr = row0 + r, gk = k0 + kq;
-            const int64_t grc = gr < nrows ? gr : nrows - 1;
-            const int64_t gkc = gk < ld - 4 ? gk : ld - 4;
-            const float4 x = *(const float4 *)(src + grc * ld + gkc);
-            const bool rok = gr < nrows;
-            v[it].x = (rok && gk + 0 < kend) ? x.x : 0.f;
-            v[it].y = (rok && gk + 1 < kend) ? x.y : 0.f;
-            v[it].z = (rok && gk + 2 < kend) ? x.z : 0.f;
-            v[it].w = (rok && gk + 3 < kend) ? x.w : 0.f;
+        for (int it = 0; it < PD_NLOAD; it++) {
+            const int r = it * 32 + r0;
+            const int rc = r < rows_here ? r : rows_here - 1;
+            v[it] = *(const float4 *)(base + ((uint32_t)rc * ld + kc));
         }
     } else {
 #pragma unroll
-        for (int it = 0; it < 8; it++) {
-            const int idx = it * 256 + tid;
-            const int r = idx >> 4, kq = (idx & 15) * 4;
-            const int64_t gr = row0 + r, gk = k0 + kq;
-            const int64_t grc = gr < nrows ? gr : nrows - 1;
-            const float *p = src + grc * ld;
-            const bool rok = gr < nrows;
+        for (int it = 0; it < PD_NLOAD; it++) {
+            const int r = it * 32 + r0;
+            const int rc = r < rows_here ? r : rows_here - 1;
             float e[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const int64_t kk = gk + j < kend ? gk + j : kend - 1;
-                const float x = p[kk];
-                e[j] = (rok && gk + j < kend) ? x : 0.f;
+                const int kk = (kq + j < klen) ? (kq + j) : (klen - 1);
+                e[j] = base[(uint32_t)rc * ld + (uint32_t)(k0 + kk)];
             }
             v[it] = make_float4(e[0], e[1], e[2], e[3]);
         }
     }
 }
 
-// Registers -> LDS, even k to [0,32), odd k to [32,64) of each row.
-__device__ __forceinline__ void pd_store(float *lds, const float4 (&v)[8])
+// Registers -> LDS, even k to [0,32), odd k to [32,64) of each row.  Elements outside the valid
+// rows / valid k of the chunk (loaded from clamped addresses) are zeroed HERE, at their only use, so no
+// predicate stays live across the MFMA phase.
+__device__ __forceinline__ void pd_store(float *lds, const float4 (&v)[PD_NLOAD], int rows_here, int klen)
 {
     const int tid = threadIdx.x;
+    const int r0 = tid >> 4, kq = (tid & 15) * 4;
+    const int nvalid = klen - kq;
+    float *o = lds + r0 * PD_LD + (kq >> 1);
 #pragma unroll
-    for (int it = 0; it < 8; it++) {
-        const int idx = it * 256 + tid;
-        const int r = idx >> 4, kq = (idx & 15) * 4;
-        float *o = lds + r * PD_LD + (kq >> 1);
-        *(float2 *)o = make_float2(v[it].x, v[it].z);
-        *(float2 *)(o + 32) = make_float2(v[it].y, v[it].w);
+    for (int it = 0; it < PD_NLOAD; it++) {
+        const bool rok = (it * 32 + r0) < rows_here;
+        *(float2 *)(o + it * 32 * PD_LD) = make_float2(mask_f(v[it].x, rok && nvalid > 0), mask_f(v[it].z, rok && nvalid > 2));
+        *(float2 *)(o + it * 32 * PD_LD + 32) = make_float2(mask_f(v[it].y, rok && nvalid > 1), mask_f(v[it].w, rok && nvalid > 3));
     }
 }
 
@@ -127,8 +135,24 @@ __device__ __forceinline__ void pd_chunk(int c, const KBlocks &kbs, bool multi, 
     closes_kb = true;
 }
 
+// linear tile index -> tile origin.  General: "16 tile-rows deep" grouped order.  Symmetric:
+// row-major walk of the upper triangle (tn >= tm).
+template <bool SYM>
 __device__ __forceinline__ void pd_tile_coords(int64_t t, int tiles_m, int tiles_n, int64_t &m0, int64_t &n0)
 {
+    if (SYM) {
+        const double T = (double)tiles_n;
+        int64_t tm = (int64_t)(((2.0 * T + 1.0) - sqrt((2.0 * T + 1.0) * (2.0 * T + 1.0) - 8.0 * (double)t)) * 0.5);
+        if (tm < 0) tm = 0;
+        if (tm > tiles_m - 1) tm = tiles_m - 1;
+        // offset(tm) = tm*T - tm*(tm-1)/2 ; fix rounding
+        while (tm > 0 && tm * (int64_t)tiles_n - tm * (tm - 1) / 2 > t) tm--;
+        while ((tm + 1) * (int64_t)tiles_n - (tm + 1) * tm / 2 <= t) tm++;
+        const int64_t off = tm * (int64_t)tiles_n - tm * (tm - 1) / 2;
+        m0 = tm * PD_BM;
+        n0 = (tm + (t - off)) * PD_BN;
+        return;
+    }
     const int64_t per_group = (int64_t)PD_GROUP_M * tiles_n;
     const int64_t group = t / per_group, in_g = t % per_group;
     const int64_t first_m = group * PD_GROUP_M;
@@ -137,138 +161,188 @@ __device__ __forceinline__ void pd_tile_coords(int64_t t, int tiles_m, int tiles
     n0 = (in_g / gsz) * PD_BN;
 }
 
-template <int METRIC, bool MULTI_KB>
-__global__ __launch_bounds__(256, 2) void pdist_kernel(
-    const float *__restrict__ A, int64_t lda, const float *__restrict__ Bm, int64_t ldb,
+template <int METRIC>
+__device__ __forceinline__ float pd_finish(float v, float sa, float sb)
+{
+    if (METRIC == SE_METRIC_COSINE) return -v;
+    if (METRIC == SE_METRIC_EUCLID) return (sa + sb) - 2.0f * v;
+    return v;
+}
+
+// flags
+constexpr int PDF_VEC_A = 1, PDF_VEC_B = 2, PDF_VEC_O = 4, PDF_NO_STORE = 8, PDF_NO_MFMA = 16, PDF_STAGGER = 32;
+
+template <int METRIC, bool MULTI_KB, bool SYM, bool VEC>
+__global__ __launch_bounds__(PD_THREADS, 4) void pdist_kernel(
+    const float *__restrict__ A, uint32_t lda, const float *__restrict__ Bm, uint32_t ldb,
     const float *__restrict__ sqa, const float *__restrict__ sqb, int64_t Q, int64_t N, int64_t D,
-    KBlocks kbs, int nchunks, float *__restrict__ out, int64_t ldo, int tiles_m, int tiles_n, int vec_a, int vec_b)
+    KBlocks kbs, int nchunks, float *__restrict__ out, uint32_t ldo, int tiles_m, int tiles_n, int64_t ntiles, int flags)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *sA = smem;
     float *sB = smem + PD_BM * PD_LD;
 
     // ---- this workgroup's tile list: XCD-contiguous band, round-robin inside the XCD ----
-    const int64_t nblk = (int64_t)tiles_m * tiles_n;
     const int64_t b = blockIdx.x, G = gridDim.x;
-    const int64_t xcd = b & 7, qq = nblk >> 3, rr = nblk & 7;
+    const int64_t xcd = b & 7, qq = ntiles >> 3, rr = ntiles & 7;
     const int64_t band_beg = (xcd < rr) ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq;
     const int64_t band_len = qq + (xcd < rr ? 1 : 0);
     const int64_t wg_in_xcd = b >> 3, wgs_per_xcd = (G + 7 - xcd) >> 3;  // blocks b' = xcd (mod 8), b' < G
     const int64_t my_tiles = (band_len > wg_in_xcd) ? (band_len - wg_in_xcd + wgs_per_xcd - 1) / wgs_per_xcd : 0;
     if (my_tiles == 0) return;
+    // De-phase the persistent workgroups: all tiles cost the same, so without this every workgroup on
+    // the chip reaches its store burst at the same moment and the matrix pipes idle behind the HBM queue.
+    if (flags & PDF_STAGGER) {
+        const int slot = (int)((b >> 3) & 3);
+        for (int i = 0; i < slot * 2; i++) __builtin_amdgcn_s_sleep(127);
+    }
 
     const int lane = lane_id(), wave = threadIdx.x >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave >> 1, wn = wave & 1;      // 4 x 2 waves: 32 rows x 64 cols each
     const int col = lane & 31, hi = lane >> 5;
+    const bool vec_o = flags & PDF_VEC_O;
 
-    f32x16 acc[2][2], tot[2][2];
+    f32x16 acc[2], tot[2];
 #pragma unroll
-    for (int i = 0; i < 2; i++)
+    for (int j = 0; j < 2; j++)
 #pragma unroll
-        for (int j = 0; j < 2; j++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) { acc[i][j][r] = 0.f; if (MULTI_KB) tot[i][j][r] = 0.f; }
+        for (int r = 0; r < 16; r++) { acc[j][r] = 0.f; if (MULTI_KB) tot[j][r] = 0.f; }
 
-    const float *pa0 = sA + (wm * 64 + col) * PD_LD + hi * 32;
-    const float *pa1 = pa0 + 32 * PD_LD;
+    const float *pa = sA + (wm * 32 + col) * PD_LD + hi * 32;
     const float *pb0 = sB + (wn * 64 + col) * PD_LD + hi * 32;
     const float *pb1 = pb0 + 32 * PD_LD;
 
     // ---- prologue: fetch (tile 0, chunk 0) ----
-    Staged st;
+    float4 ra[PD_NLOAD], rb[PD_NLOAD];
     int64_t m0, n0, k0, kend;
     bool closes_kb;
-    pd_tile_coords(band_beg + wg_in_xcd, tiles_m, tiles_n, m0, n0);
+    pd_tile_coords<SYM>(band_beg + wg_in_xcd, tiles_m, tiles_n, m0, n0);
     pd_chunk(0, kbs, MULTI_KB, D, k0, kend, closes_kb);
-    pd_load(st.a, A, lda, m0, Q, k0, kend, vec_a && ((k0 & 3) == 0));
-    pd_load(st.b, Bm, ldb, n0, N, k0, kend, vec_b && ((k0 & 3) == 0));
+#define PD_FETCH()                              \
+    pd_load<VEC>(ra, A, lda, m0, Q, k0, kend);  \
+    pd_load<VEC>(rb, Bm, ldb, n0, N, k0, kend);
+    PD_FETCH()
     bool first_kb = true;
 
     const int64_t total = my_tiles * nchunks;
 #pragma unroll 1
     for (int64_t it = 0; it < total; it++) {
         const int c = (int)(it % nchunks);
-        // current chunk geometry (what `st` holds)
-        const int64_t cur_m0 = m0, cur_n0 = n0;
+        const int64_t cur_m0 = m0, cur_n0 = n0;       // geometry of the chunk held in ra/rb
         const int kc = (int)((kend - k0 < PD_BK) ? (kend - k0) : PD_BK);
         const bool cur_closes = closes_kb;
 
+        const int rows_a = (int)((Q - cur_m0 < PD_BM) ? (Q - cur_m0) : PD_BM);
+        const int rows_b = (int)((N - cur_n0 < PD_BN) ? (N - cur_n0) : PD_BN);
+
         __syncthreads();  // LDS free: everyone finished the previous chunk's MFMAs
-        pd_store(sA, st.a);
-        pd_store(sB, st.b);
+        pd_store(sA, ra, rows_a, kc);
+        pd_store(sB, rb, rows_b, kc);
         __syncthreads();
 
         // ---- prefetch the next chunk (same tile or first chunk of the next tile) ----
         if (it + 1 < total) {
             const int nc = (c + 1 == nchunks) ? 0 : c + 1;
-            if (nc == 0) pd_tile_coords(band_beg + wg_in_xcd + ((it + 1) / nchunks) * wgs_per_xcd, tiles_m, tiles_n, m0, n0);
+            if (nc == 0) pd_tile_coords<SYM>(band_beg + wg_in_xcd + ((it + 1) / nchunks) * wgs_per_xcd, tiles_m, tiles_n, m0, n0);
             pd_chunk(nc, kbs, MULTI_KB, D, k0, kend, closes_kb);
-            pd_load(st.a, A, lda, m0, Q, k0, kend, vec_a && ((k0 & 3) == 0));
-            pd_load(st.b, Bm, ldb, n0, N, k0, kend, vec_b && ((k0 & 3) == 0));
+            PD_FETCH()
         }
 
-        // ---- MFMA over the chunk in LDS ----
-        const int steps = (kc + 1) >> 1;
-        for (int s = 0; s < steps; s += 4) {
-            const float4 a0 = *(const float4 *)(pa0 + s);
-            const float4 a1 = *(const float4 *)(pa1 + s);
+        // ---- MFMA over the chunk in LDS: 2 k per step, 4 steps per 16-byte operand read ----
+        const int steps = (flags & PDF_NO_MFMA) ? 0 : ((kc + 1) >> 1);
+        const int full = steps & ~3;
+#define PD_STEP(C)                                                                \
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.C, b0.C, acc[0], 0, 0, 0);   \
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.C, b1.C, acc[1], 0, 0, 0);
+        for (int s = 0; s < full; s += 4) {
+            const float4 a4 = *(const float4 *)(pa + s);
             const float4 b0 = *(const float4 *)(pb0 + s);
             const float4 b1 = *(const float4 *)(pb1 + s);
-#define PD_STEP(C)                                                                        \
-    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.C, b0.C, acc[0][0], 0, 0, 0);     \
-    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.C, b1.C, acc[0][1], 0, 0, 0);     \
-    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.C, b0.C, acc[1][0], 0, 0, 0);     \
-    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.C, b1.C, acc[1][1], 0, 0, 0);
-            PD_STEP(x)
-            if (s + 1 < steps) { PD_STEP(y) }
-            if (s + 2 < steps) { PD_STEP(z) }
-            if (s + 3 < steps) { PD_STEP(w) }
-#undef PD_STEP
+            PD_STEP(x) PD_STEP(y) PD_STEP(z) PD_STEP(w)
         }
+        if (steps & 3) {
+            const float4 a4 = *(const float4 *)(pa + full);
+            const float4 b0 = *(const float4 *)(pb0 + full);
+            const float4 b1 = *(const float4 *)(pb1 + full);
+            PD_STEP(x)
+            if ((steps & 3) > 1) { PD_STEP(y) }
+            if ((steps & 3) > 2) { PD_STEP(z) }
+        }
+#undef PD_STEP
 
         if (MULTI_KB && cur_closes) {
 #pragma unroll
-            for (int i = 0; i < 2; i++)
+            for (int j = 0; j < 2; j++)
 #pragma unroll
-                for (int j = 0; j < 2; j++)
-#pragma unroll
-                    for (int r = 0; r < 16; r++) {
-                        tot[i][j][r] = first_kb ? acc[i][j][r] : (tot[i][j][r] + acc[i][j][r]);
-                        acc[i][j][r] = 0.f;
-                    }
+                for (int r = 0; r < 16; r++) {
+                    tot[j][r] = first_kb ? acc[j][r] : (tot[j][r] + acc[j][r]);
+                    acc[j][r] = 0.f;
+                }
             first_kb = false;
         }
 
         // ---- tile finished: accumulators (col = lane & 31, row = (r&3) + 8*(r>>2) + 4*hi) -> global ----
         if (c + 1 == nchunks) {
+            if (flags & PDF_NO_STORE) {
 #pragma unroll
-            for (int j = 0; j < 2; j++) {
-                const int64_t gc = cur_n0 + wn * 64 + j * 32 + col;
-                float sb = 0.f;
-                if (METRIC == SE_METRIC_EUCLID && gc < N) sb = sqb[gc];
+                for (int j = 0; j < 2; j++)
 #pragma unroll
-                for (int i = 0; i < 2; i++) {
+                    for (int r = 0; r < 16; r++) asm volatile("" ::"v"(acc[j][r]));
+            } else {
+                const bool mirror = SYM && (cur_m0 != cur_n0);
+                // uniform 64-bit bases + 32-bit BYTE offsets (saddr + voffset addressing, one VGPR per address)
+                char *obase = (char *)(out + (cur_m0 * (int64_t)ldo + cur_n0));
+                char *tbase = (char *)(out + (cur_n0 * (int64_t)ldo + cur_m0));   // transposed tile
+                const int rows_here = (int)((Q - cur_m0 < PD_BM) ? (Q - cur_m0) : PD_BM);
+                const int cols_here = (int)((N - cur_n0 < PD_BN) ? (N - cur_n0) : PD_BN);
+                const bool interior = (rows_here == PD_BM) && (cols_here == PD_BN);
+                int lr0 = wm * 32 + 4 * hi;                                       // + (r&3) + 8*(r>>2)
+                asm volatile("" : "+v"(lr0));   // opaque per tile: stops LICM from hoisting (and spilling) 40 addresses
+                const uint32_t ldo4 = ldo * 4u;
 #pragma unroll
-                    for (int r = 0; r < 16; r++) {
-                        const int64_t gr = cur_m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                        if (gr < Q && gc < N) {
-                            float v = MULTI_KB ? tot[i][j][r] : acc[i][j][r];
-                            if (METRIC == SE_METRIC_COSINE) v = -v;
-                            else if (METRIC == SE_METRIC_EUCLID) v = (sqa[gr] + sb) - 2.0f * v;
-                            out[gr * ldo + gc] = v;
+                for (int j = 0; j < 2; j++) {
+                    const int lc = wn * 64 + j * 32 + col;
+                    const bool cok = lc < cols_here;
+                    float sb = 0.f;
+                    if (METRIC == SE_METRIC_EUCLID) sb = sqb[cur_n0 + (cok ? lc : cols_here - 1)];
+                    const uint32_t noff = (uint32_t)lr0 * ldo4 + (uint32_t)lc * 4u;    // normal orientation
+                    const uint32_t toff = (uint32_t)lc * ldo4 + (uint32_t)lr0 * 4u;    // transposed orientation
+#pragma unroll
+                    for (int g = 0; g < 4; g++) {
+                        float v4[4];
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            const int lr = lr0 + 8 * g + e;
+                            float sa = 0.f;
+                            if (METRIC == SE_METRIC_EUCLID) sa = sqa[cur_m0 + (lr < rows_here ? lr : rows_here - 1)];
+                            v4[e] = pd_finish<METRIC>(MULTI_KB ? tot[j][4 * g + e] : acc[j][4 * g + e], sa, sb);
+                            // per instruction: 2 rows x 128 contiguous bytes.  (A DPP quad-transposed dwordx4
+                            // variant -- 8 rows x 128 B per instruction -- measured SLOWER: the tile-shaped
+                            // write pattern, not the store width, bounds this path; tools/probes/store_patterns.hip)
+                            if (interior || (lr < rows_here && cok))
+                                *(float *)(obase + (noff + (uint32_t)(8 * g + e) * ldo4)) = v4[e];
+                        }
+                        if (mirror) {   // out[n0 + lc, m0 + lr0 + 8g + (0..3)]: 16 B per lane straight from the layout
+                            char *tp = tbase + (toff + (uint32_t)(32 * g));
+                            if (interior && vec_o) {
+                                *(float4 *)tp = make_float4(v4[0], v4[1], v4[2], v4[3]);
+                            } else if (cok) {
+#pragma unroll
+                                for (int e = 0; e < 4; e++)
+                                    if (lr0 + 8 * g + e < rows_here) ((float *)tp)[e] = v4[e];
+                            }
                         }
                     }
                 }
             }
 #pragma unroll
-            for (int i = 0; i < 2; i++)
+            for (int j = 0; j < 2; j++)
 #pragma unroll
-                for (int j = 0; j < 2; j++)
-#pragma unroll
-                    for (int r = 0; r < 16; r++) acc[i][j][r] = 0.f;
+                for (int r = 0; r < 16; r++) acc[j][r] = 0.f;
             first_kb = true;
         }
     }
+#undef PD_FETCH
 }
 
 static int pd_num_cus()
@@ -283,33 +357,57 @@ static int pd_num_cus()
     return cus;
 }
 
-template <int METRIC>
-static int launch_pdist(const float *a, int64_t lda, const float *b, int64_t ldb, const float *sqa,
-                        const float *sqb, int64_t q, int64_t n, int64_t d, const KBlocks &kbs, bool multi,
-                        float *out, int64_t ldo, hipStream_t s)
+template <int METRIC, bool MULTI, bool SYM, bool VEC>
+static int launch_pdist3(const float *a, int64_t lda, const float *b, int64_t ldb, const float *sqa, const float *sqb,
+                         int64_t q, int64_t n, int64_t d, const KBlocks &kbs, float *out, int64_t ldo, hipStream_t s)
 {
     const int tiles_m = (int)((q + PD_BM - 1) / PD_BM), tiles_n = (int)((n + PD_BN - 1) / PD_BN);
-    const int64_t nblk = (int64_t)tiles_m * tiles_n;
+    const int64_t ntiles = SYM ? ((int64_t)tiles_n * (tiles_n + 1) / 2) : ((int64_t)tiles_m * tiles_n);
     const size_t lds = (size_t)(PD_BM + PD_BN) * PD_LD * sizeof(float);
-    const int vec_a = (lda % 4 == 0) && ((((uintptr_t)a) & 15) == 0);
-    const int vec_b = (ldb % 4 == 0) && ((((uintptr_t)b) & 15) == 0);
+    int flags = 0;
+    if ((lda % 4 == 0) && ((((uintptr_t)a) & 15) == 0)) flags |= PDF_VEC_A;
+    if ((ldb % 4 == 0) && ((((uintptr_t)b) & 15) == 0)) flags |= PDF_VEC_B;
+    if ((ldo % 4 == 0) && ((((uintptr_t)out) & 15) == 0)) flags |= PDF_VEC_O;
+    if (const char *e = getenv("SE_PD_ABLATE")) flags |= (atoi(e) & 3) * PDF_NO_STORE;   // tuning aid: 1 = no stores, 2 = no MFMA
+    if (!getenv("SE_PD_NOSTAGGER")) flags |= PDF_STAGGER;
     int nchunks = 0;
     for (int i = 0; i < kbs.n; i++) nchunks += (kbs.len[i] + PD_BK - 1) / PD_BK;
     int64_t grid = (int64_t)pd_num_cus() * PD_WGS_PER_CU;
     grid = grid / 8 * 8;
-    if (grid > nblk) grid = nblk;
+    if (grid > ntiles) grid = ntiles;
     if (grid < 1) grid = 1;
-    if (multi) {
-        auto kern = pdist_kernel<METRIC, true>;
-        SE_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, s, a, lda, b, ldb, sqa, sqb, q, n, d, kbs, nchunks, out, ldo, tiles_m, tiles_n, vec_a, vec_b);
-    } else {
-        auto kern = pdist_kernel<METRIC, false>;
-        SE_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, s, a, lda, b, ldb, sqa, sqb, q, n, d, kbs, nchunks, out, ldo, tiles_m, tiles_n, vec_a, vec_b);
-    }
+    auto kern = pdist_kernel<METRIC, MULTI, SYM, VEC>;
+    SE_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(PD_THREADS), lds, s, a, (uint32_t)lda, b, (uint32_t)ldb, sqa, sqb, q, n,
+                       d, kbs, nchunks, out, (uint32_t)ldo, tiles_m, tiles_n, ntiles, flags);
     SE_LAUNCH_CHECK();
     return SE_OK;
+}
+
+template <int METRIC, bool MULTI, bool SYM>
+static int launch_pdist2(const float *a, int64_t lda, const float *b, int64_t ldb, const float *sqa, const float *sqb,
+                         int64_t q, int64_t n, int64_t d, const KBlocks &kbs, float *out, int64_t ldo, hipStream_t s)
+{
+    // 16-byte operand loads need aligned bases, row pitches that are multiples of 4 and K-blocks that start on
+    // multiples of 4 (chunk starts are then multiples of 4 as well)
+    bool vec = (lda % 4 == 0) && ((((uintptr_t)a) & 15) == 0) && (ldb % 4 == 0) && ((((uintptr_t)b) & 15) == 0);
+    int64_t beg = 0;
+    for (int i = 0; i < kbs.n; i++) { if (beg & 3) vec = false; beg += kbs.len[i]; }
+    return vec ? launch_pdist3<METRIC, MULTI, SYM, true>(a, lda, b, ldb, sqa, sqb, q, n, d, kbs, out, ldo, s)
+               : launch_pdist3<METRIC, MULTI, SYM, false>(a, lda, b, ldb, sqa, sqb, q, n, d, kbs, out, ldo, s);
+}
+
+template <int METRIC>
+static int launch_pdist(const float *a, int64_t lda, const float *b, int64_t ldb, const float *sqa, const float *sqb,
+                        int64_t q, int64_t n, int64_t d, const KBlocks &kbs, bool multi, float *out, int64_t ldo,
+                        hipStream_t s)
+{
+    // ssyrk case: same matrix on both sides (and, for the Euclidean epilogue, the same norms)
+    const bool sym = (a == b) && (lda == ldb) && (q == n) && (METRIC != SE_METRIC_EUCLID || sqa == sqb) && n > PD_BN;
+    if (sym) return multi ? launch_pdist2<METRIC, true, true>(a, lda, b, ldb, sqa, sqb, q, n, d, kbs, out, ldo, s)
+                          : launch_pdist2<METRIC, false, true>(a, lda, b, ldb, sqa, sqb, q, n, d, kbs, out, ldo, s);
+    return multi ? launch_pdist2<METRIC, true, false>(a, lda, b, ldb, sqa, sqb, q, n, d, kbs, out, ldo, s)
+                 : launch_pdist2<METRIC, false, false>(a, lda, b, ldb, sqa, sqb, q, n, d, kbs, out, ldo, s);
 }
 
 }  // namespace se
@@ -325,7 +423,8 @@ extern "C" int se_pairwise_dist(const float *a, int64_t lda, const float *b, int
     if (!a || !b || !out) return fail(SE_ERR_INVALID, "se_pairwise_dist: null pointer");
     if (lda < d || ldb < d || ldo < n) return fail(SE_ERR_INVALID, "se_pairwise_dist: leading dimension too small");
     if (metric == SE_METRIC_EUCLID && (!sqa || !sqb)) return fail(SE_ERR_INVALID, "se_pairwise_dist: SE_METRIC_EUCLID needs sqa and sqb");
-    if (d > 0x7FFFFFFFll) return fail(SE_ERR_UNSUPPORTED, "se_pairwise_dist: d too large");
+    if (lda >= PD_MAX_LD || ldb >= PD_MAX_LD || ldo >= PD_MAX_LD)
+        return fail(SE_ERR_UNSUPPORTED, "se_pairwise_dist: leading dimensions must be < %lld elements", (long long)PD_MAX_LD);
     KBlocks kbs;
     kbs.n = 1;
     kbs.len[0] = (int)d;

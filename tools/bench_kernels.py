@@ -1,0 +1,77 @@
+#!/usr/bin/env python
+"""Kernel-level microbenchmarks (HIP-event timing on the launch stream) used while tuning.
+    python tools/bench_kernels.py pdist|rank|loss|topk [--n 50000 --d 100 --reps 5]"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "semantic-embeddings_amd"))
+import sehip  # noqa: E402
+
+
+def timeit(fn, reps):
+    fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); fn(); b.record()
+        torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b))
+    return float(np.median(ts)), float(np.min(ts))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("what", choices=["pdist", "rank", "loss", "topk"])
+    ap.add_argument("--n", type=int, default=50000)
+    ap.add_argument("--q", type=int, default=None)
+    ap.add_argument("--d", type=int, default=100)
+    ap.add_argument("--k", type=int, default=251)
+    ap.add_argument("--reps", type=int, default=5)
+    args = ap.parse_args()
+    n, d = args.n, args.d
+    q = args.q or n
+    x = torch.from_numpy(np.random.default_rng(0).standard_normal((n, d)).astype(np.float32)).cuda()
+    sehip.normalize_rows_(x)
+    if args.what == "pdist":
+        out = torch.empty((q, n), dtype=torch.float32, device="cuda")
+        y = x.clone()
+        for name, b in (("symmetric(a==b)", x), ("general(a!=b)", y)):
+            med, mn = timeit(lambda: sehip.pairwise_dist(x[:q], b, metric=sehip.METRIC_COSINE, out=out), args.reps)
+            gb = (4.0 * q * n + 4.0 * (q + n) * d) / 1e9
+            print("pdist %-16s q=%d n=%d d=%d: median %.3f ms (min %.3f)  %.1f GB/s algorithmic, %.1f TFLOP/s useful" %
+                  (name, q, n, d, med, mn, gb / med * 1e3, 2.0 * q * n * d / med / 1e9))
+    elif args.what == "rank":
+        pd = sehip.pairwise_dist(x[:q], x, metric=sehip.METRIC_COSINE)
+        rk = torch.empty((q, n), dtype=torch.int32, device="cuda")
+        med, mn = timeit(lambda: sehip.rank_rows(pd, out=rk), args.reps)
+        print("rank q=%d n=%d: median %.3f ms (min %.3f)  %.1f GB/s algorithmic, %.1f Mkeys/s" % (q, n, med, mn, 8.0 * q * n / med / 1e6, q * n / med / 1e3))
+    elif args.what == "topk":
+        pd = sehip.pairwise_dist(x[:q], x, metric=sehip.METRIC_COSINE)
+        med, mn = timeit(lambda: sehip.topk_rows(pd, args.k), args.reps)
+        print("topk k=%d q=%d n=%d: median %.3f ms (min %.3f)  %.1f GB/s" % (args.k, q, n, med, mn, 4.0 * q * n / med / 1e6))
+    else:
+        B, D = 65536, 1000
+        xx = torch.randn(B, D, device="cuda")
+        E = torch.nn.functional.normalize(torch.randn(1000, D, device="cuda"), dim=-1)
+        yy = torch.randint(0, 1000, (B,), device="cuda")
+        med, mn = timeit(lambda: sehip.cosine_loss_forward(xx, yy, E), args.reps)
+        print("loss fwd B=%d D=%d f32: median %.3f ms  %.1f GB/s" % (B, D, med, (B * D * 12.0) / med / 1e6))
+        med, mn = timeit(lambda: sehip.cosine_loss_backward(xx, yy, E, grad_scale=1.0 / B), args.reps)
+        print("loss bwd B=%d D=%d f32: median %.3f ms  %.1f GB/s" % (B, D, med, (B * D * 12.0) / med / 1e6))
+        xb = xx.bfloat16()
+        med, mn = timeit(lambda: sehip.cosine_loss_forward(xb, yy, E, want_xhat=False), args.reps)
+        print("loss fwd (no xhat) bf16: median %.3f ms  %.1f GB/s" % (med, (B * D * 6.0) / med / 1e6))
+        B2 = 128
+        x2, y2, E2 = torch.randn(B2, 100, device="cuda"), torch.randint(0, 100, (B2,), device="cuda"), E[:100, :100].contiguous()
+        med, mn = timeit(lambda: sehip.cosine_loss_forward(x2, y2, E2), 20)
+        print("loss fwd B=128 D=100: median %.1f us" % (med * 1e3))
+
+
+if __name__ == "__main__":
+    main()
