@@ -21,6 +21,7 @@
 // the last pass writes the index matrix only.
 // HBM-side algorithmic traffic: 4 N bytes in (distances) + 4 N bytes out (int32 ranks) per row.
 #include "se_common.h"
+#include <stdlib.h>
 
 namespace se {
 
@@ -218,22 +219,350 @@ __global__ __launch_bounds__(RK_THREADS) void rank_rows_kernel(const float *__re
     }
 }
 
+
+// =================================================================================================
+// Register-resident variant (the fast path, N <= RR_MAX_N): one 512-thread workgroup holds a whole
+// row in registers (ITEMS keys per thread), so a row costs ONE HBM read of the distances and ONE HBM
+// write of the ranks -- the algorithmic minimum -- and no global round trip sits between the passes.
+//   * position p of the current arrangement lives in wave p / (64 ITEMS), step (p / 64) % ITEMS,
+//     lane p % 64; positions >= N hold padding keys 0xFFFFFFFF whose initial position is behind
+//     every real key, so stability keeps them last and they are never written out;
+//   * per pass: (R) stable within-wave rank of every key by wave multisplit (8 ballots) + one
+//     returning LDS add per digit group on the wave's private counters; (S) digit-major /
+//     wave-minor scan of the 8 x 256 counters; (X) in-place exchange through a 2-byte-per-key LDS
+//     buffer (160 KB of LDS cannot hold 4 B x 50k keys): the 16-bit index, then the key halves
+//     that later passes still need (pass 0: both, passes 1-2: the high half, pass 3: none) --
+//     8 two-byte exchanges per key instead of 12;
+//   * indices travel as 16 bits (N <= 65536 by construction) packed with the 16-bit destination;
+//   * after the last pass the exchange buffer IS the ranking: it is streamed to HBM with 16-byte
+//     stores.
+constexpr int RR_THREADS = 512;
+constexpr int RR_WAVES = RR_THREADS / WAVE;
+constexpr int RR_MAX_ITEMS = 104;
+constexpr int RR_G = 8;                               // steps ranked together (latency overlap vs live registers)
+constexpr int RR_MAX_N = RR_THREADS * RR_MAX_ITEMS;   // 53248
+
+// Wave multisplit on an 8-bit digit: bit mask of the lanes whose digit DIFFERS from this lane's, as
+// OR_b (ballot_b ^ own_bit_b): per bit one v_bfe_i32, one v_cmp (the ballot) and one v_bitop3 per mask half.
+__device__ __forceinline__ void differ_mask(uint32_t d, uint32_t &lo, uint32_t &hi)
+{
+    lo = 0;
+    hi = 0;
+#pragma unroll
+    for (int bb = 0; bb < 8; bb += 2) {
+        uint32_t s0 = (uint32_t)__builtin_amdgcn_sbfe((int)d, bb, 1);       // 0 or ~0
+        uint32_t s1 = (uint32_t)__builtin_amdgcn_sbfe((int)d, bb + 1, 1);
+        asm volatile("" : "+v"(s0), "+v"(s1));   // keep the ballot a plain compare of the extracted bit
+        const uint64_t m0 = __ballot(s0 != 0), m1 = __ballot(s1 != 0);
+        // acc | (ballot ^ own): v_bitop3_b32, truth table of a | (b ^ c) with a = 0xF0, b = 0xCC, c = 0xAA
+        lo = __builtin_amdgcn_bitop3_b32(lo, (uint32_t)m0, s0, 0xF6);
+        hi = __builtin_amdgcn_bitop3_b32(hi, (uint32_t)(m0 >> 32), s0, 0xF6);
+        lo = __builtin_amdgcn_bitop3_b32(lo, (uint32_t)m1, s1, 0xF6);
+        hi = __builtin_amdgcn_bitop3_b32(hi, (uint32_t)(m1 >> 32), s1, 0xF6);
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void opaque(T &x) { asm volatile("" : "+v"(x)); }   // value barrier: no CSE / hoisting across it
+
+__device__ __forceinline__ uint32_t lds_off(const void *p) { return (uint32_t)(uintptr_t)p; }   // LDS byte address of a __shared__ pointer
+// The exchange is written with explicit DS instructions: the 16-bit loads land IN PLACE in one half of a
+// live register (no temporaries, no merge VALU) and hipcc cannot cache 2 x ITEMS destination addresses.
+// hipcc does not count these toward its own s_waitcnt bookkeeping, hence the explicit lds_wait().
+__device__ __forceinline__ void lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void lds_st16_lo(uint32_t addr, uint32_t v) { asm volatile("ds_write_b16 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
+__device__ __forceinline__ void lds_st16_hi(uint32_t addr, uint32_t v) { asm volatile("ds_write_b16_d16_hi %0, %1" ::"v"(addr), "v"(v) : "memory"); }
+// (gfx950 runs with SRAM-ECC: a d16 load ZEROES the other register half, so the 16-bit loads go to a
+// small ring of temporaries and one v_perm_b32 merges each into the live register.)
+template <int OFF>
+__device__ __forceinline__ void lds_ld16(uint32_t &dst, uint32_t addr) { asm volatile("ds_read_u16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory"); }
+// wait until at most K DS operations are outstanding; `landed` is the register the awaited load writes -- naming
+// it as an in/out operand is what orders its consumers after the wait (the asm statements carry no other dependency)
+template <int K>
+__device__ __forceinline__ void lds_wait_le(uint32_t &landed) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(landed) : "n"(K) : "memory"); }
+
+constexpr int RR_RING = 12;   // 16-bit loads in flight per lane (lgkmcnt counts to 15)
+// Software-pipelined read of this lane's ITEMS new 16-bit values (read slot of step s = addr + 128 s)
+// into the HIGH (HI = true) or LOW half of a[s]: read i is issued RR_RING - 1 reads ahead of its merge.
+template <int ITEMS, bool HI, int I = 0>
+struct RRRead {
+    static __device__ __forceinline__ void run(uint32_t (&a)[ITEMS], uint32_t (&t)[RR_RING], uint32_t addr)
+    {
+        constexpr int D = RR_RING - 1;
+        if constexpr (I < ITEMS) lds_ld16<I * WAVE * 2>(t[I % RR_RING], addr);
+        if constexpr (I >= D) {
+            constexpr int J = I - D;
+            constexpr int newest = (I < ITEMS ? I : ITEMS - 1);
+            lds_wait_le<newest - J>(t[J % RR_RING]);
+            // HI: (t << 16) | (a & 0xFFFF)      LO: (a & 0xFFFF0000) | (t & 0xFFFF)
+            a[J] = __builtin_amdgcn_perm(t[J % RR_RING], a[J], HI ? 0x05040100u : 0x03020504u);
+        }
+        if constexpr (I + 1 < ITEMS + D) RRRead<ITEMS, HI, I + 1>::run(a, t, addr);
+    }
+};
+
+// ---- R phase, one group of V <= RR_G consecutive steps starting at step S0 -------------------------------
+// Per step: every lane READS its digit's counter (equal digits: one broadcast read), then the first lane of
+// each digit group ADDS the group size (no return value).  DS operations of one wave execute in program
+// order, so the read sees exactly the keys of earlier steps; nothing waits on the add, and the V reads of
+// the group are in flight together.  Explicit DS instructions: a volatile / atomic C++ access to the
+// counters would be emitted as a FLAT operation.
+template <int ITEMS, int V, int S0, int I = 0>
+struct RRRankFinish {   // read I of the group is followed by 2 (V-1-I) + 1 younger DS operations (every step issues both)
+    static __device__ __forceinline__ void run(uint32_t (&ir)[ITEMS], uint32_t (&key)[ITEMS], uint32_t (&rnk)[V], uint32_t (&base)[V])
+    {
+        lds_wait_le<2 * (V - 1 - I) + 1>(base[I]);
+        ir[S0 + I] = (ir[S0 + I] & 0xFFFF0000u) | (base[I] + rnk[I]);
+        opaque(ir[S0 + I]);    // materialise now: nothing but key/ir stays live per key
+        opaque(key[S0 + I]);   // (and no cached counter address either)
+        if constexpr (I + 1 < V) RRRankFinish<ITEMS, V, S0, I + 1>::run(ir, key, rnk, base);
+    }
+};
+
+template <int ITEMS, int S0 = 0>
+struct RRRank {
+    static __device__ __forceinline__ void run(uint32_t (&ir)[ITEMS], uint32_t (&key)[ITEMS], int shift, int lane, uint32_t cb)
+    {
+        constexpr int V = (ITEMS - S0 < RR_G) ? (ITEMS - S0) : RR_G;
+        static_assert(2 * V - 1 <= 15, "lgkmcnt counts to 15");
+        uint32_t rnk[V], base[V];
+#pragma unroll
+        for (int g = 0; g < V; g++) {
+            const uint32_t d = (key[S0 + g] >> shift) & 0xFFu;
+            uint32_t dlo, dhi;
+            differ_mask(d, dlo, dhi);
+            // lower lanes with the same digit = lower lanes - lower lanes that differ
+            rnk[g] = (uint32_t)lane - __builtin_amdgcn_mbcnt_hi(dhi, __builtin_amdgcn_mbcnt_lo(dlo, 0u));
+            const uint32_t ca = cb + (d << 2);
+            asm volatile("ds_read_b32 %0, %1" : "=v"(base[g]) : "v"(ca) : "memory");
+            if (rnk[g] == 0) {   // (lane 0 always leads a group, so the add is issued in every step)
+                const uint32_t np = 64u - (uint32_t)(__popc(dlo) + __popc(dhi));
+                asm volatile("ds_add_u32 %0, %1" ::"v"(ca), "v"(np) : "memory");
+            }
+        }
+        RRRankFinish<ITEMS, V, S0>::run(ir, key, rnk, base);
+        // the scheduling fence between groups keeps hipcc from hoisting all ITEMS steps' ballots at once
+        // (hundreds of live SGPR pairs -> spills)
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (S0 + V < ITEMS) RRRank<ITEMS, S0 + V>::run(ir, key, shift, lane, cb);
+    }
+};
+
+template <int ITEMS, bool PROF>
+__global__ __launch_bounds__(RR_THREADS, 2) void rank_rows_reg_kernel(const float *__restrict__ pdist, int64_t ldp, int64_t Q,
+                                                                    int N, void *rank, int64_t ldr, int idx64, int vec_ok,
+                                                                    unsigned long long *prof)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char rr_raw[];
+    uint32_t *wcnt = reinterpret_cast<uint32_t *>(rr_raw);              // [RR_WAVES][256]
+    uint32_t *wave_tot = wcnt + RR_WAVES * RK_NB;                       // [4] (+pad)
+    uint16_t *xbuf = reinterpret_cast<uint16_t *>(wave_tot + 16);       // [RR_THREADS * ITEMS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wpos0 = wave * (ITEMS * WAVE) + lane;                     // position of (step s) = wpos0 + 64 s
+    uint32_t *mycnt = wcnt + wave * RK_NB;
+    const uint32_t cb = lds_off(mycnt);                                 // this wave's digit counters, byte address
+    const uint32_t xb = lds_off(xbuf);                                  // exchange buffer, byte address
+    const uint32_t rb = xb + 2u * (uint32_t)wpos0;                      // this lane's read slot of step 0
+#define RR_DST(IR) (xb + (((IR) & 0xFFFFu) << 1))
+    // tuning aid (SE_RR_PROFILE=1): shader-clock cycles per phase, summed over every workgroup's wave 0
+    uint64_t t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last = PROF ? __builtin_amdgcn_s_memtime() : 0;
+#define RR_T(i) if constexpr (PROF) { const uint64_t now = __builtin_amdgcn_s_memtime(); t_acc[i] += now - t_last; t_last = now; }
+
+    for (int64_t row = blockIdx.x; row < Q; row += gridDim.x) {
+        const float *drow = pdist + row * ldp;
+        uint32_t key[ITEMS], ir[ITEMS];   // ir = (index << 16) | (within-wave rank, then destination)
+        uint32_t ring[RR_RING];
+        int wpos = wpos0;
+        opaque(wpos);   // per-row opaque: otherwise hipcc hoists ITEMS row-invariant clamps/masks out of the row loop and keeps them live
+#pragma unroll
+        for (int s = 0; s < ITEMS; s++) {
+            // unconditional loads (clamped index, padding applied arithmetically): a branch around a load
+            // makes hipcc wait for each load before issuing the next
+            const int pos = wpos + s * WAVE;
+            int gi = pos < N ? pos : N - 1;
+            opaque(gi);
+            key[s] = canon_key(drow[gi]) | (uint32_t)((N - 1 - pos) >> 31);   // pos >= N: all ones
+            ir[s] = (uint32_t)pos << 16;
+        }
+        RR_T(0)
+#pragma unroll 1
+        for (int p = 0; p < 4; p++) {
+            const int shift = p * 8;
+            // ---- R: stable rank inside the wave ----
+#pragma unroll
+            for (int j = 0; j < RK_NB / WAVE; j++) mycnt[j * WAVE + lane] = 0;
+            RRRank<ITEMS>::run(ir, key, shift, lane, cb);
+            lds_wait();
+            RR_T(1)
+            __syncthreads();
+            // ---- S: counters -> first destination of every (wave, digit) ----
+            uint32_t c[RR_WAVES], ex = 0;
+            if (tid < RK_NB) {
+                uint32_t run = 0;
+#pragma unroll
+                for (int w = 0; w < RR_WAVES; w++) { c[w] = run; run += wcnt[w * RK_NB + tid]; }
+                uint32_t wtot;
+                ex = wave_excl_scan(run, wtot);
+                if (lane == 63) wave_tot[wave] = wtot;
+            }
+            __syncthreads();
+            if (tid < RK_NB) {
+                for (int w = 0; w < wave; w++) ex += wave_tot[w];
+#pragma unroll
+                for (int w = 0; w < RR_WAVES; w++) wcnt[w * RK_NB + tid] = ex + c[w];
+            }
+            __syncthreads();
+            RR_T(2)
+            // ---- X: destinations, then the 2-byte exchanges ----
+#pragma unroll
+            for (int s0 = 0; s0 < ITEMS; s0 += 8) {
+                uint32_t first[8];
+#pragma unroll
+                for (int g = 0; g < 8; g++)
+                    if (s0 + g < ITEMS) first[g] = mycnt[(key[s0 + g] >> shift) & 0xFFu];
+#pragma unroll
+                for (int g = 0; g < 8; g++)
+                    if (s0 + g < ITEMS) {
+                        ir[s0 + g] += first[g];   // low half: rank -> destination (< 65536)
+                        opaque(ir[s0 + g]);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            RR_T(3)
+#pragma unroll
+            for (int s = 0; s < ITEMS; s++) { opaque(ir[s]); lds_st16_hi(RR_DST(ir[s]), ir[s]); }           // index
+            lds_wait();
+            __syncthreads();
+            RR_T(4)
+            if (p == 3) break;
+            RRRead<ITEMS, true>::run(ir, ring, rb);
+            lds_wait();
+            __syncthreads();
+            RR_T(5)
+#pragma unroll
+            for (int s = 0; s < ITEMS; s++) { opaque(ir[s]); lds_st16_hi(RR_DST(ir[s]), key[s]); }          // key bits 16-31  (opaque: no cached addresses)
+            lds_wait();
+            __syncthreads();
+            RRRead<ITEMS, true>::run(key, ring, rb);
+            lds_wait();
+            if (p == 0) {                                                                // key bits 0-15: only pass 1 reads them
+                __syncthreads();
+#pragma unroll
+                for (int s = 0; s < ITEMS; s++) { opaque(ir[s]); lds_st16_lo(RR_DST(ir[s]), key[s]); }      // (low half is still the old key's)
+                lds_wait();
+                __syncthreads();
+                RRRead<ITEMS, false>::run(key, ring, rb);
+                lds_wait();
+            }
+            RR_T(6)
+            // (the next pass's barriers order these reads before its first exchange write)
+        }
+#undef RR_DST
+        // ---- the exchange buffer now holds the ranking: stream it out ----
+        if (idx64) {
+            int64_t *o = (int64_t *)rank + row * ldr;
+            for (int j = tid * 4; j < N; j += RR_THREADS * 4) {
+                const uint2 v = *reinterpret_cast<const uint2 *>(xbuf + j);
+                const int64_t e0 = v.x & 0xFFFFu, e1 = v.x >> 16, e2 = v.y & 0xFFFFu, e3 = v.y >> 16;
+                if (vec_ok && j + 3 < N) {
+                    *reinterpret_cast<longlong2 *>(o + j) = make_longlong2(e0, e1);
+                    *reinterpret_cast<longlong2 *>(o + j + 2) = make_longlong2(e2, e3);
+                } else {
+                    o[j] = e0;
+                    if (j + 1 < N) o[j + 1] = e1;
+                    if (j + 2 < N) o[j + 2] = e2;
+                    if (j + 3 < N) o[j + 3] = e3;
+                }
+            }
+        } else {
+            int32_t *o = (int32_t *)rank + row * ldr;
+            for (int j = tid * 4; j < N; j += RR_THREADS * 4) {
+                const uint2 v = *reinterpret_cast<const uint2 *>(xbuf + j);
+                const int e0 = v.x & 0xFFFFu, e1 = v.x >> 16, e2 = v.y & 0xFFFFu, e3 = v.y >> 16;
+                if (vec_ok && j + 3 < N) {
+                    *reinterpret_cast<int4 *>(o + j) = make_int4(e0, e1, e2, e3);
+                } else {
+                    o[j] = e0;
+                    if (j + 1 < N) o[j + 1] = e1;
+                    if (j + 2 < N) o[j + 2] = e2;
+                    if (j + 3 < N) o[j + 3] = e3;
+                }
+            }
+        }
+        RR_T(7)
+        // (the next row's pass-0 barriers order these reads before its first exchange write)
+    }
+    if (PROF && tid == 0)
+        for (int i = 0; i < 8; i++) atomicAdd(&prof[i], (unsigned long long)t_acc[i]);
+#undef RR_T
+}
+
 }  // namespace se
 
 using namespace se;
 
 static int rank_grid(int64_t q)
 {
-    // resident workgroups: 256 CUs x 2 (512 threads, ~78 KB LDS each)
+    // resident workgroups of the tiled kernel: 256 CUs x 2 (512 threads, ~78 KB LDS each)
     const int64_t g = 512;
     return (int)(q < g ? q : g);
 }
 
 static int64_t rank_npad(int64_t n) { return (n + 63) / 64 * 64; }
 
+static bool rank_use_tiled(int64_t n)
+{
+    static const bool force = getenv("SE_RANK_TILED") != nullptr;   // tuning / test aid: always take the general kernel
+    return force || n > RR_MAX_N;
+}
+
+template <int ITEMS>
+static int launch_rank_reg(const float *pdist, int64_t ldp, int64_t q, int n, void *rank, int idx64, int64_t ldr, hipStream_t s)
+{
+    const size_t lds = (size_t)(RR_WAVES * RK_NB + 16) * sizeof(uint32_t) + (size_t)RR_THREADS * ITEMS * sizeof(uint16_t);
+    static const bool profile = getenv("SE_RR_PROFILE") != nullptr;   // tuning aid only: allocates, synchronises, prints
+    auto kern = profile ? rank_rows_reg_kernel<ITEMS, (ITEMS == 98)> : rank_rows_reg_kernel<ITEMS, false>;
+    static int per_cu = 0, cus = 0;   // per instantiation
+    if (per_cu == 0) {
+        SE_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        int dev = 0, occ = 0;
+        hipDeviceProp_t prop;
+        SE_HIP_CHECK(hipGetDevice(&dev));
+        SE_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+        SE_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)kern, RR_THREADS, lds));
+        cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        per_cu = occ > 0 ? occ : 1;
+    }
+    int64_t grid = (int64_t)cus * per_cu;
+    if (grid > q) grid = q;
+    const size_t esz = idx64 ? 8 : 4;
+    const int vec_ok = ((((uintptr_t)rank) & 15) == 0) && ((ldr * esz) % 16 == 0);
+    unsigned long long *prof = nullptr;
+    if (profile) {
+        SE_HIP_CHECK(hipMalloc((void **)&prof, 8 * sizeof(unsigned long long)));
+        SE_HIP_CHECK(hipMemsetAsync(prof, 0, 8 * sizeof(unsigned long long), s));
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(RR_THREADS), lds, s, pdist, ldp, q, n, rank, ldr, idx64, vec_ok, prof);
+    SE_LAUNCH_CHECK();
+    if (profile) {
+        unsigned long long h[8];
+        SE_HIP_CHECK(hipStreamSynchronize(s));
+        SE_HIP_CHECK(hipMemcpy(h, prof, sizeof(h), hipMemcpyDeviceToHost));
+        SE_HIP_CHECK(hipFree(prof));
+        static const char *names[8] = {"load", "rank", "scan", "dest", "idx-write", "idx-read", "key-exchange", "write-out"};
+        double tot = 0;
+        for (int i = 0; i < 8; i++) tot += (double)h[i];
+        fprintf(stderr, "[se_rank_rows profile] ITEMS=%d grid=%lld:", ITEMS, (long long)grid);
+        for (int i = 0; i < 8; i++) fprintf(stderr, " %s %.1f%%", names[i], 100.0 * (double)h[i] / tot);
+        fprintf(stderr, "  (%.0f cycles per row)\n", tot / (double)q);
+    }
+    return SE_OK;
+}
+
 extern "C" int64_t se_rank_rows_workspace_bytes(int64_t q, int64_t n)
 {
     if (q <= 0 || n <= 0) return 0;
+    if (!rank_use_tiled(n)) return 0;   // the register-resident kernel needs no scratch
     return (int64_t)rank_grid(q) * 4 * rank_npad(n) * (int64_t)sizeof(uint32_t);
 }
 
@@ -243,10 +572,16 @@ extern "C" int se_rank_rows(const float *pdist, int64_t ldp, int64_t q, int64_t 
     if (q < 0 || n < 0 || n > 0x7FFFFFFFll) return fail(SE_ERR_INVALID, "se_rank_rows: bad shape q=%lld n=%lld", (long long)q, (long long)n);
     if (q == 0 || n == 0) return SE_OK;
     if (!pdist || !rank || ldp < n || ldr < n) return fail(SE_ERR_INVALID, "se_rank_rows: bad argument");
-    const int64_t need = se_rank_rows_workspace_bytes(q, n);
+    hipStream_t s = (hipStream_t)stream;
+    if (!rank_use_tiled(n)) {
+        const int items = (int)((n + RR_THREADS - 1) / RR_THREADS);
+#define SE_RR_CASE(I) if (items <= I) return launch_rank_reg<I>(pdist, ldp, q, (int)n, rank, idx64, ldr, s);
+        SE_RR_CASE(2) SE_RR_CASE(8) SE_RR_CASE(20) SE_RR_CASE(40) SE_RR_CASE(64) SE_RR_CASE(80) SE_RR_CASE(98) SE_RR_CASE(104)
+#undef SE_RR_CASE
+    }
+    const int64_t need = (int64_t)rank_grid(q) * 4 * rank_npad(n) * (int64_t)sizeof(uint32_t);
     if (!workspace || workspace_bytes < need) return fail(SE_ERR_WORKSPACE, "se_rank_rows: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)need);
     const size_t lds = sizeof(RankLds);
-    hipStream_t s = (hipStream_t)stream;
     if (idx64) {
         SE_HIP_CHECK(hipFuncSetAttribute((const void *)rank_rows_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL(rank_rows_kernel<true>, dim3((unsigned)rank_grid(q)), dim3(RK_THREADS), lds, s, pdist, ldp, q, (int)n, rank, ldr, (uint32_t *)workspace, rank_npad(n));

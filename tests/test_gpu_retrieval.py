@@ -125,6 +125,39 @@ def test_rank_rows_ties_nan_negzero_int64(sehip):
     assert np.array_equal(got64, want)
 
 
+@pytest.mark.parametrize("n", [1023, 1025, 4096, 10000, 10241, 20481, 32768, 32769, 40961, 50000, 50177, 53248, 53249, 70001])
+def test_rank_rows_register_kernel_boundaries(sehip, n):
+    """Every instantiation of the register-resident kernel (keys per thread 2...104), its last
+    full / first ragged step, and the hand-over to the tiled kernel above 53248 columns; rows mix
+    gaussian keys with exact-tie runs, NaN, infinities and signed zeros."""
+    rng = np.random.default_rng(n)
+    pd = rng.standard_normal((3, n)).astype(np.float32)
+    pd[1] = rng.integers(-2, 3, size=n).astype(np.float32)          # five distinct values: long tie runs
+    pd[2, ::3] = pd[2, 0]
+    pd[2, 1:min(n, 9)] = np.array([np.nan, 0.0, -0.0, np.inf, -np.inf, np.nan, 1e-38, -1e-38], dtype=np.float32)[:max(0, min(n, 9) - 1)]
+    got = sehip.rank_rows(dev(pd)).cpu().numpy()
+    assert np.array_equal(got, ro.canon_rank_rows(pd))
+
+
+def test_rank_rows_strided_and_unaligned_output(sehip):
+    """Row pitches that are not multiples of 16 bytes (scalar write-out) and a strided input."""
+    pdw = gauss(6, 3001, seed=5)
+    pd = dev(pdw)[:, 1:2998]                                       # ld 3001, first element misaligned
+    out = torch.empty((6, 2999), dtype=torch.int32, device="cuda")[:, 1:2998]
+    sehip.rank_rows(pd, out=out)
+    assert np.array_equal(out.cpu().numpy(), ro.canon_rank_rows(np.ascontiguousarray(pdw[:, 1:2998])))
+    out64 = sehip.rank_rows(pd, idx64=True)
+    assert np.array_equal(out64.cpu().numpy(), ro.canon_rank_rows(np.ascontiguousarray(pdw[:, 1:2998])))
+
+
+def test_rank_rows_many_rows_persistent_grid(sehip):
+    """More rows than resident workgroups: the persistent row loop re-uses LDS across rows."""
+    pd = gauss(1500, 2500, seed=11)
+    pd[::2, ::5] = 0.25
+    got = sehip.rank_rows(dev(pd)).cpu().numpy()
+    assert np.array_equal(got, ro.canon_rank_rows(pd))
+
+
 @pytest.mark.parametrize("q,n,k", [(4, 10, 1), (4, 10, 10), (17, 300, 7), (9, 5000, 251), (3, 50000, 251), (5, 3000, 2048)])
 def test_topk_rows_equals_head_of_full_ranking(sehip, q, n, k):
     pd = gauss(q, n, seed=k)
