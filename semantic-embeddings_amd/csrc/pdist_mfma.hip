@@ -34,10 +34,13 @@
 namespace se {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int PD_BM = 128, PD_BN = 128, PD_BK = 64;
 constexpr int PD_THREADS = 512;
 constexpr int PD_LD = PD_BK + 4;  // padded LDS row pitch in floats
+constexpr int PD_SP = PD_BN + 4;  // row pitch of the epilogue stage (128 x 132 floats fit in the operand buffers)
+static_assert(PD_BM * PD_SP <= (PD_BM + PD_BN) * PD_LD, "epilogue stage must fit in the operand LDS");
 constexpr int PD_GROUP_M = 16;
 constexpr int PD_MAX_KB = 16;
 constexpr int PD_WGS_PER_CU = 2;
@@ -161,6 +164,32 @@ __device__ __forceinline__ void pd_tile_coords(int64_t t, int tiles_m, int tiles
     n0 = (in_g / gsz) * PD_BN;
 }
 
+
+// Stage [128][PD_SP] in LDS -> global rows: thread t moves 16 bytes, 32 lanes cover one 512-byte row segment.
+__device__ __forceinline__ void pd_stream_rows(const float *stage, float *gbase, uint32_t ldo, int nrows, int ncols, bool fast, bool nt, bool dry)
+{
+    const int tid = threadIdx.x;
+    const int r0 = tid >> 5, c4 = (tid & 31) * 4;
+    char *gb = (char *)gbase;                                    // uniform base + 32-bit byte offsets
+    const uint32_t ldo4 = ldo * 4u;
+#pragma unroll
+    for (int p = 0; p < PD_BM / 16; p++) {
+        const int row = p * 16 + r0;
+        const float4 v = *(const float4 *)&stage[row * PD_SP + c4];
+        if (dry) { asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w)); continue; }   // tuning aid: stage traffic without HBM writes
+        float *dp = (float *)(gb + ((uint32_t)row * ldo4 + (uint32_t)c4 * 4u));
+        if (fast) {
+            if (nt) __builtin_nontemporal_store((f32x4){v.x, v.y, v.z, v.w}, (f32x4 *)dp);
+            else *(float4 *)dp = v;
+        } else if (row < nrows) {
+            if (c4 < ncols) dp[0] = v.x;
+            if (c4 + 1 < ncols) dp[1] = v.y;
+            if (c4 + 2 < ncols) dp[2] = v.z;
+            if (c4 + 3 < ncols) dp[3] = v.w;
+        }
+    }
+}
+
 template <int METRIC>
 __device__ __forceinline__ float pd_finish(float v, float sa, float sb)
 {
@@ -170,7 +199,7 @@ __device__ __forceinline__ float pd_finish(float v, float sa, float sb)
 }
 
 // flags
-constexpr int PDF_VEC_A = 1, PDF_VEC_B = 2, PDF_VEC_O = 4, PDF_NO_STORE = 8, PDF_NO_MFMA = 16, PDF_STAGGER = 32;
+constexpr int PDF_VEC_A = 1, PDF_VEC_B = 2, PDF_VEC_O = 4, PDF_NO_STORE = 8, PDF_NO_MFMA = 16, PDF_STAGGER = 32, PDF_PLAIN_ST = 64, PDF_NO_GSTORE = 128;
 
 template <int METRIC, bool MULTI_KB, bool SYM, bool VEC>
 __global__ __launch_bounds__(PD_THREADS, 4) void pdist_kernel(
@@ -201,6 +230,7 @@ __global__ __launch_bounds__(PD_THREADS, 4) void pdist_kernel(
     const int wm = wave >> 1, wn = wave & 1;      // 4 x 2 waves: 32 rows x 64 cols each
     const int col = lane & 31, hi = lane >> 5;
     const bool vec_o = flags & PDF_VEC_O;
+    const bool nt = !(flags & PDF_PLAIN_ST);   // streaming (nontemporal) stores: the 10 GB result is never re-read by this kernel
 
     f32x16 acc[2], tot[2];
 #pragma unroll
@@ -254,6 +284,8 @@ __global__ __launch_bounds__(PD_THREADS, 4) void pdist_kernel(
 #define PD_STEP(C)                                                                \
     acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.C, b0.C, acc[0], 0, 0, 0);   \
     acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.C, b1.C, acc[1], 0, 0, 0);
+        // (Issuing the operand reads of group g+1 before the MFMAs of group g -- a register double buffer -- was
+        // measured and does not pay: with 4 waves per SIMD the LDS round trip is already covered; 3.5 -> 3.9 ms.)
         for (int s = 0; s < full; s += 4) {
             const float4 a4 = *(const float4 *)(pa + s);
             const float4 b0 = *(const float4 *)(pb0 + s);
@@ -289,51 +321,56 @@ __global__ __launch_bounds__(PD_THREADS, 4) void pdist_kernel(
 #pragma unroll
                     for (int r = 0; r < 16; r++) asm volatile("" ::"v"(acc[j][r]));
             } else {
+                // Staged epilogue: the finished tile goes through the (now idle) operand LDS so that HBM sees
+                // whole 512-byte row segments, two rows per wave instruction, as streaming (nontemporal) 16-byte
+                // stores -- 5.2 TB/s on this pattern vs 4.1 TB/s for any store straight from the accumulator
+                // layout and 3.7 TB/s for the transposed tile (tools/probes/store_patterns2.hip).
                 const bool mirror = SYM && (cur_m0 != cur_n0);
-                // uniform 64-bit bases + 32-bit BYTE offsets (saddr + voffset addressing, one VGPR per address)
-                char *obase = (char *)(out + (cur_m0 * (int64_t)ldo + cur_n0));
-                char *tbase = (char *)(out + (cur_n0 * (int64_t)ldo + cur_m0));   // transposed tile
                 const int rows_here = (int)((Q - cur_m0 < PD_BM) ? (Q - cur_m0) : PD_BM);
                 const int cols_here = (int)((N - cur_n0 < PD_BN) ? (N - cur_n0) : PD_BN);
-                const bool interior = (rows_here == PD_BM) && (cols_here == PD_BN);
+                const bool fast = (rows_here == PD_BM) && (cols_here == PD_BN) && vec_o;
                 int lr0 = wm * 32 + 4 * hi;                                       // + (r&3) + 8*(r>>2)
-                asm volatile("" : "+v"(lr0));   // opaque per tile: stops LICM from hoisting (and spilling) 40 addresses
-                const uint32_t ldo4 = ldo * 4u;
+                asm volatile("" : "+v"(lr0));   // opaque per tile: nothing of the epilogue is hoisted out of the tile loop
+                // (values are finished at the point of use: a [2][16] copy of the tile would cost 32 more VGPRs)
+#define PD_VAL(J, R)                                                                                                         \
+    pd_finish<METRIC>(MULTI_KB ? tot[J][R] : acc[J][R],                                                                        \
+                      METRIC == SE_METRIC_EUCLID ? sa_[((R) & 3) + 4 * ((R) >> 2)] : 0.f, METRIC == SE_METRIC_EUCLID ? sb_[J] : 0.f)
+                float sa_[16], sb_[2];   // Euclidean epilogue only: |a|^2 of this lane's 16 rows, |b|^2 of its 2 columns
+                if (METRIC == SE_METRIC_EUCLID) {
 #pragma unroll
-                for (int j = 0; j < 2; j++) {
-                    const int lc = wn * 64 + j * 32 + col;
-                    const bool cok = lc < cols_here;
-                    float sb = 0.f;
-                    if (METRIC == SE_METRIC_EUCLID) sb = sqb[cur_n0 + (cok ? lc : cols_here - 1)];
-                    const uint32_t noff = (uint32_t)lr0 * ldo4 + (uint32_t)lc * 4u;    // normal orientation
-                    const uint32_t toff = (uint32_t)lc * ldo4 + (uint32_t)lr0 * 4u;    // transposed orientation
+                    for (int j = 0; j < 2; j++) {
+                        const int lc = wn * 64 + j * 32 + col;
+                        sb_[j] = sqb[cur_n0 + (lc < cols_here ? lc : cols_here - 1)];
+                    }
 #pragma unroll
-                    for (int g = 0; g < 4; g++) {
-                        float v4[4];
-#pragma unroll
-                        for (int e = 0; e < 4; e++) {
-                            const int lr = lr0 + 8 * g + e;
-                            float sa = 0.f;
-                            if (METRIC == SE_METRIC_EUCLID) sa = sqa[cur_m0 + (lr < rows_here ? lr : rows_here - 1)];
-                            v4[e] = pd_finish<METRIC>(MULTI_KB ? tot[j][4 * g + e] : acc[j][4 * g + e], sa, sb);
-                            // per instruction: 2 rows x 128 contiguous bytes.  (A DPP quad-transposed dwordx4
-                            // variant -- 8 rows x 128 B per instruction -- measured SLOWER: the tile-shaped
-                            // write pattern, not the store width, bounds this path; tools/probes/store_patterns.hip)
-                            if (interior || (lr < rows_here && cok))
-                                *(float *)(obase + (noff + (uint32_t)(8 * g + e) * ldo4)) = v4[e];
-                        }
-                        if (mirror) {   // out[n0 + lc, m0 + lr0 + 8g + (0..3)]: 16 B per lane straight from the layout
-                            char *tp = tbase + (toff + (uint32_t)(32 * g));
-                            if (interior && vec_o) {
-                                *(float4 *)tp = make_float4(v4[0], v4[1], v4[2], v4[3]);
-                            } else if (cok) {
-#pragma unroll
-                                for (int e = 0; e < 4; e++)
-                                    if (lr0 + 8 * g + e < rows_here) ((float *)tp)[e] = v4[e];
-                            }
-                        }
+                    for (int r = 0; r < 16; r++) {
+                        const int lr = lr0 + (r & 3) + 8 * (r >> 2);
+                        sa_[r] = sqa[cur_m0 + (lr < rows_here ? lr : rows_here - 1)];
                     }
                 }
+                __syncthreads();   // every wave is done reading the last chunk's operands
+                // tile -> stage[row][col]: per instruction lanes 0-31 fill 32 consecutive floats of one row
+#pragma unroll
+                for (int j = 0; j < 2; j++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++)
+                        smem[(lr0 + (r & 3) + 8 * (r >> 2)) * PD_SP + wn * 64 + j * 32 + col] = PD_VAL(j, r);
+                __syncthreads();
+                pd_stream_rows(smem, out + (cur_m0 * (int64_t)ldo + cur_n0), ldo, rows_here, cols_here, fast, nt, flags & PDF_NO_GSTORE);
+                if (mirror) {
+                    // transposed tile -> stage[col][row]: a lane owns 4 consecutive rows of its column = 16 bytes
+                    __syncthreads();
+#pragma unroll
+                    for (int j = 0; j < 2; j++)
+#pragma unroll
+                        for (int g = 0; g < 4; g++)
+                            *(float4 *)&smem[(wn * 64 + j * 32 + col) * PD_SP + lr0 + 8 * g] =
+                                make_float4(PD_VAL(j, 4 * g), PD_VAL(j, 4 * g + 1), PD_VAL(j, 4 * g + 2), PD_VAL(j, 4 * g + 3));
+                    __syncthreads();
+                    pd_stream_rows(smem, out + (cur_n0 * (int64_t)ldo + cur_m0), ldo, cols_here, rows_here, fast, nt, flags & PDF_NO_GSTORE);
+                }
+                // (the barrier that opens the next chunk orders these LDS reads before the operands overwrite the stage)
+#undef PD_VAL
             }
 #pragma unroll
             for (int j = 0; j < 2; j++)
@@ -368,8 +405,9 @@ static int launch_pdist3(const float *a, int64_t lda, const float *b, int64_t ld
     if ((lda % 4 == 0) && ((((uintptr_t)a) & 15) == 0)) flags |= PDF_VEC_A;
     if ((ldb % 4 == 0) && ((((uintptr_t)b) & 15) == 0)) flags |= PDF_VEC_B;
     if ((ldo % 4 == 0) && ((((uintptr_t)out) & 15) == 0)) flags |= PDF_VEC_O;
-    if (const char *e = getenv("SE_PD_ABLATE")) flags |= (atoi(e) & 3) * PDF_NO_STORE;   // tuning aid: 1 = no stores, 2 = no MFMA
+    if (const char *e = getenv("SE_PD_ABLATE")) { const int a = atoi(e); flags |= (a & 3) * PDF_NO_STORE; if (a & 4) flags |= PDF_NO_GSTORE; }   // tuning aid: 1 = no epilogue, 2 = no MFMA, 4 = epilogue without global stores
     if (!getenv("SE_PD_NOSTAGGER")) flags |= PDF_STAGGER;
+    if (getenv("SE_PD_PLAIN_ST")) flags |= PDF_PLAIN_ST;
     int nchunks = 0;
     for (int i = 0; i < kbs.n; i++) nchunks += (kbs.len[i] + PD_BK - 1) / PD_BK;
     int64_t grid = (int64_t)pd_num_cus() * PD_WGS_PER_CU;
