@@ -46,7 +46,9 @@ def parse():
     ap.add_argument("--metric", default="cosine", choices=["cosine", "euclid"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-queries", type=int, default=3072)
-    ap.add_argument("--with-train", action="store_true", help="also time the training step (adds a 'train' object)")
+    ap.add_argument("--with-train", dest="with_train", action="store_true", default=True,
+                    help="also time the ResNet-110-fc training step (adds a 'train' object; default on)")
+    ap.add_argument("--no-train", dest="with_train", action="store_false")
     ap.add_argument("--batch", type=int, default=128, help="per-GPU batch (train)")
     ap.add_argument("--arch", default="resnet-110-fc")
     return ap.parse_args()
@@ -158,7 +160,7 @@ def bench_retrieval(args, rank, world):
     }
     dominant = max(("pairwise_dist", "rank_rows"), key=lambda k: kms[k])
     roofline = {"kernel": dominant, "bound": "hbm", "achieved": kernels[dominant]["GBps"], "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": kernels[dominant]["frac_hbm"], "traffic": None}
+                "unit": "GB/s", "frac": kernels[dominant]["frac_hbm"], "traffic": pmc_traffic_gb(dominant, q, n, d)}
     out = {
         "metric": "retrieval_Mpairs_per_sec", "value": value, "unit": "Mpairs/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -169,6 +171,21 @@ def bench_retrieval(args, rank, world):
         "roofline": roofline, "kernels": kernels,
     }
     return out, feats_h
+
+
+def pmc_traffic_gb(kernel, q, n, d):
+    """HBM-side bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json:
+    FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md, plus WRITE_SIZE, both in KB), or None when
+    no profile of this exact shape is committed.  bench.py cannot collect counters itself."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            rec = json.load(f)[kernel]
+        if [rec["q"], rec["n"], rec["d"]] != [q, n, d]:
+            return None
+        return {"unit": "GB", "read": rec["fetch_kb"] * 2 * 1024 / 1e9, "write": rec["write_kb"] * 1024 / 1e9,
+                "total": (rec["fetch_kb"] * 2 + rec["write_kb"]) * 1024 / 1e9, "source": rec["source"]}
+    except Exception:
+        return None
 
 
 def cpu_baseline_retrieval(args, feats_h):
@@ -194,8 +211,11 @@ def main():
     else:
         out, feats_h = bench_retrieval(args, rank, world)
         if args.with_train:
-            from train_bench import bench_train
-            out["train"] = bench_train(args, rank, world)
+            try:
+                from train_bench import bench_train
+                out["train"] = bench_train(args, rank, world)
+            except Exception as e:   # the retrieval line must survive a training-side failure
+                out["train"] = {"error": "%s: %s" % (type(e).__name__, e)}
         if rank == 0 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_retrieval(args, feats_h)
     if rank == 0:
