@@ -348,30 +348,78 @@ struct RRRank {
     }
 };
 
-template <int ITEMS, bool PROF>
+// ---- R phase, hardware-ordered variant -------------------------------------------------------------------
+// One RETURNING add per key on the wave's digit counter: the returned value is the within-wave rank directly,
+// PROVIDED the LDS serves the lanes of one ds_add_rtn that hit the same address in ascending lane order.
+// gfx950 does (tools/probes/lds_atomic_order.hip: 84 M returns under every conflict pattern, 8 waves per
+// workgroup hammering the LDS), but the ISA does not promise it, so this variant is only selected after the
+// same property has been re-verified on the device at first use (se_rank_rows: probe kernel) and can be
+// switched off with SE_RANK_SAFE=1.  ~5 VALU per key and pass instead of ~41.
+constexpr int RR_GH = 8;    // returning adds in flight per lane
+constexpr int RR_HW_BITS = 11;   // digit width of the hardware-ordered variant: 3 passes (11 + 11 + 10 bits) instead of 4
+// Counters are 16 bits wide, two per LDS word (8 waves x 2048 digits x 2 B = 32 KB next to the 100 KB exchange
+// buffer): a wave holds at most 64 x 104 keys and a destination is < 53,248, so neither half can carry into the
+// other.  The returning add is done on the word with the increment shifted into the digit's half.
+template <int ITEMS, int V, int S0, int I = 0>
+struct RRRankHWFinish {
+    static __device__ __forceinline__ void run(uint32_t (&ir)[ITEMS], uint32_t (&key)[ITEMS], uint32_t (&r)[V], uint32_t (&sh)[V])
+    {
+        lds_wait_le<V - 1 - I>(r[I]);
+        ir[S0 + I] = (ir[S0 + I] & 0xFFFF0000u) | ((r[I] >> sh[I]) & 0xFFFFu);
+        opaque(ir[S0 + I]);
+        opaque(key[S0 + I]);
+        if constexpr (I + 1 < V) RRRankHWFinish<ITEMS, V, S0, I + 1>::run(ir, key, r, sh);
+    }
+};
+template <int ITEMS, int S0 = 0>
+struct RRRankHW {
+    static __device__ __forceinline__ void run(uint32_t (&ir)[ITEMS], uint32_t (&key)[ITEMS], int shift, uint32_t dmask, uint32_t cb)
+    {
+        constexpr int V = (ITEMS - S0 < RR_GH) ? (ITEMS - S0) : RR_GH;
+        uint32_t r[V], sh[V];
+#pragma unroll
+        for (int g = 0; g < V; g++) {
+            const uint32_t d = (key[S0 + g] >> shift) & dmask;
+            sh[g] = (d & 1u) << 4;
+            const uint32_t ca = cb + ((d << 1) & ~3u), inc = 1u << sh[g];
+            asm volatile("ds_add_rtn_u32 %0, %1, %2" : "=v"(r[g]) : "v"(ca), "v"(inc) : "memory");
+        }
+        RRRankHWFinish<ITEMS, V, S0>::run(ir, key, r, sh);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (S0 + V < ITEMS) RRRankHW<ITEMS, S0 + V>::run(ir, key, shift, dmask, cb);
+    }
+};
+
+template <int ITEMS, bool PROF, bool HWORD>
 __global__ __launch_bounds__(RR_THREADS, 2) void rank_rows_reg_kernel(const float *__restrict__ pdist, int64_t ldp, int64_t Q,
                                                                     int N, void *rank, int64_t ldr, int idx64, int vec_ok,
                                                                     unsigned long long *prof)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char rr_raw[];
-    uint32_t *wcnt = reinterpret_cast<uint32_t *>(rr_raw);              // [RR_WAVES][256]
-    uint32_t *wave_tot = wcnt + RR_WAVES * RK_NB;                       // [4] (+pad)
+    constexpr int BITS = HWORD ? RR_HW_BITS : 8;                        // digit width
+    constexpr int NB = 1 << BITS;
+    constexpr int NPASS = (32 + BITS - 1) / BITS;                       // 3 (11 + 11 + 10) or 4
+    constexpr int CNT_WORDS = HWORD ? NB / 2 : NB;                      // LDS words per wave: packed 16-bit or 32-bit counters
+    uint32_t *wcnt = reinterpret_cast<uint32_t *>(rr_raw);              // [RR_WAVES][CNT_WORDS]
+    uint32_t *wave_tot = wcnt + RR_WAVES * CNT_WORDS;                   // [8] (+pad)
     uint16_t *xbuf = reinterpret_cast<uint16_t *>(wave_tot + 16);       // [RR_THREADS * ITEMS]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wpos0 = wave * (ITEMS * WAVE) + lane;                     // position of (step s) = wpos0 + 64 s
-    uint32_t *mycnt = wcnt + wave * RK_NB;
+    uint32_t *mycnt = wcnt + wave * CNT_WORDS;
     const uint32_t cb = lds_off(mycnt);                                 // this wave's digit counters, byte address
     const uint32_t xb = lds_off(xbuf);                                  // exchange buffer, byte address
     const uint32_t rb = xb + 2u * (uint32_t)wpos0;                      // this lane's read slot of step 0
 #define RR_DST(IR) (xb + (((IR) & 0xFFFFu) << 1))
     // tuning aid (SE_RR_PROFILE=1): shader-clock cycles per phase, summed over every workgroup's wave 0
     uint64_t t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last = PROF ? __builtin_amdgcn_s_memtime() : 0;
-#define RR_T(i) if constexpr (PROF) { const uint64_t now = __builtin_amdgcn_s_memtime(); t_acc[i] += now - t_last; t_last = now; }
+#define RR_T(i) if constexpr (PROF) { const uint64_t now = __builtin_amdgcn_s_memtime(); t_acc[i] += now - t_last; t_last = now; } else { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
 
+    uint32_t pf_sink = 0;
     for (int64_t row = blockIdx.x; row < Q; row += gridDim.x) {
         const float *drow = pdist + row * ldp;
         uint32_t key[ITEMS], ir[ITEMS];   // ir = (index << 16) | (within-wave rank, then destination)
         uint32_t ring[RR_RING];
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf_sink) : : "memory");   // the L2 prefetch of this row has landed (sink register free again)
         int wpos = wpos0;
         opaque(wpos);   // per-row opaque: otherwise hipcc hoists ITEMS row-invariant clamps/masks out of the row loop and keeps them live
 #pragma unroll
@@ -386,30 +434,70 @@ __global__ __launch_bounds__(RR_THREADS, 2) void rank_rows_reg_kernel(const floa
         }
         RR_T(0)
 #pragma unroll 1
-        for (int p = 0; p < 4; p++) {
-            const int shift = p * 8;
+        for (int p = 0; p < NPASS; p++) {
+            const int shift = p * BITS;
+            const int end = (shift + BITS < 32) ? shift + BITS : 32;        // bits [0, end) are sorted after this pass
+            const uint32_t dmask = (1u << (end - shift)) - 1u;
+            if (p == NPASS - 1 && row + gridDim.x < Q) {
+                // L2 prefetch of this workgroup's NEXT row (one workgroup per CU: nothing else hides its 200 KB of
+                // HBM latency): one dword per 128-byte line, all into one sink register that stays reserved until
+                // the s_waitcnt at the top of the row loop.
+                const char *nrow = (const char *)(pdist + (row + gridDim.x) * ldp);
+                const uint32_t row_bytes = (uint32_t)N * 4u;
+                for (uint32_t off = (uint32_t)tid * 128u; off < row_bytes; off += RR_THREADS * 128u)
+                    asm volatile("global_load_dword %0, %1, off" : "=v"(pf_sink) : "v"(nrow + off) : "memory");
+            }
             // ---- R: stable rank inside the wave ----
 #pragma unroll
-            for (int j = 0; j < RK_NB / WAVE; j++) mycnt[j * WAVE + lane] = 0;
-            RRRank<ITEMS>::run(ir, key, shift, lane, cb);
+            for (int j = 0; j < CNT_WORDS / WAVE; j++) mycnt[j * WAVE + lane] = 0;
+            if constexpr (HWORD) RRRankHW<ITEMS>::run(ir, key, shift, dmask, cb);
+            else RRRank<ITEMS>::run(ir, key, shift, lane, cb);
             lds_wait();
             RR_T(1)
             __syncthreads();
             // ---- S: counters -> first destination of every (wave, digit) ----
-            uint32_t c[RR_WAVES], ex = 0;
+            if constexpr (!HWORD) {
+            uint32_t ex = 0;
             if (tid < RK_NB) {
                 uint32_t run = 0;
 #pragma unroll
-                for (int w = 0; w < RR_WAVES; w++) { c[w] = run; run += wcnt[w * RK_NB + tid]; }
+                for (int w = 0; w < RR_WAVES; w++) run += wcnt[w * RK_NB + tid];
                 uint32_t wtot;
                 ex = wave_excl_scan(run, wtot);
                 if (lane == 63) wave_tot[wave] = wtot;
             }
             __syncthreads();
-            if (tid < RK_NB) {
+            if (tid < RK_NB) {   // (the per-wave counts are re-read rather than kept in 8 registers across the barrier)
                 for (int w = 0; w < wave; w++) ex += wave_tot[w];
 #pragma unroll
-                for (int w = 0; w < RR_WAVES; w++) wcnt[w * RK_NB + tid] = ex + c[w];
+                for (int w = 0; w < RR_WAVES; w++) {
+                    const uint32_t c = wcnt[w * RK_NB + tid];
+                    wcnt[w * RK_NB + tid] = ex;
+                    ex += c;
+                }
+            }
+            } else {
+                // 2048 digits x 8 waves of 16-bit counts: thread t owns digits 4t .. 4t+3 = one 8-byte LDS access per wave
+                uint32_t t0 = 0, t1 = 0, t2 = 0, t3 = 0;   // per-digit totals over the waves
+#pragma unroll
+                for (int w = 0; w < RR_WAVES; w++) {
+                    const uint2 v = *reinterpret_cast<const uint2 *>(wcnt + w * CNT_WORDS + 2 * tid);
+                    t0 += v.x & 0xFFFFu; t1 += v.x >> 16; t2 += v.y & 0xFFFFu; t3 += v.y >> 16;
+                }
+                uint32_t wtot;
+                uint32_t ex = wave_excl_scan(t0 + t1 + t2 + t3, wtot);
+                if (lane == 63) wave_tot[wave] = wtot;
+                __syncthreads();
+                for (int w = 0; w < wave; w++) ex += wave_tot[w];
+                // digit-major / wave-minor: counts -> first destination of (wave, digit), written back in place
+                uint32_t s0 = ex, s1 = s0 + t0, s2 = s1 + t1, s3 = s2 + t2;
+#pragma unroll
+                for (int w = 0; w < RR_WAVES; w++) {
+                    uint2 *wp = reinterpret_cast<uint2 *>(wcnt + w * CNT_WORDS + 2 * tid);
+                    const uint2 v = *wp;
+                    *wp = make_uint2(s0 | (s1 << 16), s2 | (s3 << 16));
+                    s0 += v.x & 0xFFFFu; s1 += v.x >> 16; s2 += v.y & 0xFFFFu; s3 += v.y >> 16;
+                }
             }
             __syncthreads();
             RR_T(2)
@@ -419,7 +507,10 @@ __global__ __launch_bounds__(RR_THREADS, 2) void rank_rows_reg_kernel(const floa
                 uint32_t first[8];
 #pragma unroll
                 for (int g = 0; g < 8; g++)
-                    if (s0 + g < ITEMS) first[g] = mycnt[(key[s0 + g] >> shift) & 0xFFu];
+                    if (s0 + g < ITEMS) {
+                        if constexpr (HWORD) first[g] = reinterpret_cast<const uint16_t *>(mycnt)[(key[s0 + g] >> shift) & dmask];
+                        else first[g] = mycnt[(key[s0 + g] >> shift) & 0xFFu];
+                    }
 #pragma unroll
                 for (int g = 0; g < 8; g++)
                     if (s0 + g < ITEMS) {
@@ -434,7 +525,7 @@ __global__ __launch_bounds__(RR_THREADS, 2) void rank_rows_reg_kernel(const floa
             lds_wait();
             __syncthreads();
             RR_T(4)
-            if (p == 3) break;
+            if (end >= 32) break;   // last pass: the index buffer is the ranking
             RRRead<ITEMS, true>::run(ir, ring, rb);
             lds_wait();
             __syncthreads();
@@ -445,7 +536,7 @@ __global__ __launch_bounds__(RR_THREADS, 2) void rank_rows_reg_kernel(const floa
             __syncthreads();
             RRRead<ITEMS, true>::run(key, ring, rb);
             lds_wait();
-            if (p == 0) {                                                                // key bits 0-15: only pass 1 reads them
+            if (end < 16) {                                                              // key bits 0-15: still needed by a later pass
                 __syncthreads();
 #pragma unroll
                 for (int s = 0; s < ITEMS; s++) { opaque(ir[s]); lds_st16_lo(RR_DST(ir[s]), key[s]); }      // (low half is still the old key's)
@@ -517,13 +608,15 @@ static bool rank_use_tiled(int64_t n)
 }
 
 template <int ITEMS>
-static int launch_rank_reg(const float *pdist, int64_t ldp, int64_t q, int n, void *rank, int idx64, int64_t ldr, hipStream_t s)
+static int launch_rank_reg(const float *pdist, int64_t ldp, int64_t q, int n, void *rank, int idx64, int64_t ldr, bool hw, hipStream_t s)
 {
-    const size_t lds = (size_t)(RR_WAVES * RK_NB + 16) * sizeof(uint32_t) + (size_t)RR_THREADS * ITEMS * sizeof(uint16_t);
+    const size_t cnt_words = hw ? (size_t)(1 << RR_HW_BITS) / 2 : (size_t)RK_NB;   // per wave (packed 16-bit vs 32-bit counters)
+    const size_t lds = (RR_WAVES * cnt_words + 16) * sizeof(uint32_t) + (size_t)RR_THREADS * ITEMS * sizeof(uint16_t);
     static const bool profile = getenv("SE_RR_PROFILE") != nullptr;   // tuning aid only: allocates, synchronises, prints
-    auto kern = profile ? rank_rows_reg_kernel<ITEMS, (ITEMS == 98)> : rank_rows_reg_kernel<ITEMS, false>;
-    static int per_cu = 0, cus = 0;   // per instantiation
-    if (per_cu == 0) {
+    auto kern = hw ? (profile ? rank_rows_reg_kernel<ITEMS, (ITEMS == 98), true> : rank_rows_reg_kernel<ITEMS, false, true>)
+                   : (profile ? rank_rows_reg_kernel<ITEMS, (ITEMS == 98), false> : rank_rows_reg_kernel<ITEMS, false, false>);
+    static int per_cu[2] = {0, 0}, cus = 0;   // per instantiation, [hw]
+    if (per_cu[hw] == 0) {
         SE_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         int dev = 0, occ = 0;
         hipDeviceProp_t prop;
@@ -531,20 +624,20 @@ static int launch_rank_reg(const float *pdist, int64_t ldp, int64_t q, int n, vo
         SE_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
         SE_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)kern, RR_THREADS, lds));
         cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-        per_cu = occ > 0 ? occ : 1;
+        per_cu[hw] = occ > 0 ? occ : 1;
     }
-    int64_t grid = (int64_t)cus * per_cu;
+    int64_t grid = (int64_t)cus * per_cu[hw];
     if (grid > q) grid = q;
     const size_t esz = idx64 ? 8 : 4;
     const int vec_ok = ((((uintptr_t)rank) & 15) == 0) && ((ldr * esz) % 16 == 0);
     unsigned long long *prof = nullptr;
-    if (profile) {
+    if (profile && ITEMS == 98) {
         SE_HIP_CHECK(hipMalloc((void **)&prof, 8 * sizeof(unsigned long long)));
         SE_HIP_CHECK(hipMemsetAsync(prof, 0, 8 * sizeof(unsigned long long), s));
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(RR_THREADS), lds, s, pdist, ldp, q, n, rank, ldr, idx64, vec_ok, prof);
     SE_LAUNCH_CHECK();
-    if (profile) {
+    if (prof) {
         unsigned long long h[8];
         SE_HIP_CHECK(hipStreamSynchronize(s));
         SE_HIP_CHECK(hipMemcpy(h, prof, sizeof(h), hipMemcpyDeviceToHost));
@@ -559,10 +652,67 @@ static int launch_rank_reg(const float *pdist, int64_t ldp, int64_t q, int n, vo
     return SE_OK;
 }
 
+// ---- capability probe for the hardware-ordered ranking --------------------------------------------------
+// Every wave of 64 workgroups issues returning LDS adds under four conflict patterns (one address, 4, 16,
+// 256 addresses) while its 7 sibling waves do the same, and compares each returned value with the stable rank
+// computed by the ballot multisplit.  res[0] = mismatches, res[1] = waves that reported.
+constexpr int RR_PROBE_BLOCKS = 64, RR_PROBE_STEPS = 48;
+__global__ __launch_bounds__(RR_THREADS) void rank_order_probe_kernel(uint32_t *res)
+{
+    __shared__ uint32_t cnt[RR_WAVES][RK_NB], ref[RR_WAVES][RK_NB];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = lane; i < RK_NB; i += WAVE) { cnt[wave][i] = 0; ref[wave][i] = 0; }
+    __syncthreads();
+    const uint32_t cb = lds_off(&cnt[wave][0]);
+    uint32_t bad = 0, seed = (blockIdx.x * RR_THREADS + threadIdx.x) * 2654435761u + 12345u;
+    const int mode = blockIdx.x & 3;
+    for (int s = 0; s < RR_PROBE_STEPS; s++) {
+        seed = seed * 1664525u + 1013904223u;
+        const uint32_t rnd = seed >> 24;
+        const uint32_t d = mode == 0 ? 7u : mode == 1 ? (rnd & 3u) : mode == 2 ? (rnd & 15u) * 16u : rnd;
+        uint32_t got;
+        const uint32_t ca = cb + (d << 2), one = 1u;
+        asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(got) : "v"(ca), "v"(one) : "memory");
+        uint32_t dlo, dhi;
+        differ_mask(d, dlo, dhi);
+        const uint32_t rnk = (uint32_t)lane - __builtin_amdgcn_mbcnt_hi(dhi, __builtin_amdgcn_mbcnt_lo(dlo, 0u));
+        const uint32_t want = ref[wave][d] + rnk;
+        if (rnk == 0) ref[wave][d] += 64u - (uint32_t)(__popc(dlo) + __popc(dhi));   // one lane per digit group
+        bad += (got != want);
+    }
+    for (int off = 32; off > 0; off >>= 1) bad += __shfl_xor(bad, off, 64);
+    if (lane == 0) { atomicAdd(&res[0], bad); atomicAdd(&res[1], 1u); }
+}
+
+// 1 = the hardware-ordered kernel may be used on the current device, 0 = it may not.  The first call per device
+// runs the probe (needs 256 bytes of caller workspace, synchronises the stream once); SE_RANK_SAFE=1 forces 0.
+static int rank_hw_order_ok(void *workspace, int64_t workspace_bytes, hipStream_t s)
+{
+    static const bool forced_safe = getenv("SE_RANK_SAFE") != nullptr;
+    if (forced_safe) return 0;
+    static int state[64] = {0};   // per device: 0 unknown, 1 verified, -1 refuted
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    if (state[dev] == 0) {
+        if (!workspace || workspace_bytes < 256) return 0;   // cannot probe without scratch: stay on the safe kernel
+        uint32_t *res = (uint32_t *)workspace, h[2] = {1u, 0u};
+        if (hipMemsetAsync(res, 0, 8, s) != hipSuccess) return 0;
+        hipLaunchKernelGGL(rank_order_probe_kernel, dim3(RR_PROBE_BLOCKS), dim3(RR_THREADS), 0, s, res);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess ||
+            hipMemcpy(h, res, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess)
+            return 0;
+        state[dev] = (h[0] == 0u && h[1] == (uint32_t)(RR_PROBE_BLOCKS * RR_WAVES)) ? 1 : -1;
+        if (getenv("SE_RANK_VERBOSE"))
+            fprintf(stderr, "[se_rank_rows] LDS returning-add order probe on device %d: %u mismatches, %u waves -> %s kernel\n", dev,
+                    h[0], h[1], state[dev] == 1 ? "hardware-ordered" : "ballot");
+    }
+    return state[dev] == 1;
+}
+
 extern "C" int64_t se_rank_rows_workspace_bytes(int64_t q, int64_t n)
 {
     if (q <= 0 || n <= 0) return 0;
-    if (!rank_use_tiled(n)) return 0;   // the register-resident kernel needs no scratch
+    if (!rank_use_tiled(n)) return 256;   // register-resident kernel: only the first-use capability probe writes here
     return (int64_t)rank_grid(q) * 4 * rank_npad(n) * (int64_t)sizeof(uint32_t);
 }
 
@@ -575,7 +725,8 @@ extern "C" int se_rank_rows(const float *pdist, int64_t ldp, int64_t q, int64_t 
     hipStream_t s = (hipStream_t)stream;
     if (!rank_use_tiled(n)) {
         const int items = (int)((n + RR_THREADS - 1) / RR_THREADS);
-#define SE_RR_CASE(I) if (items <= I) return launch_rank_reg<I>(pdist, ldp, q, (int)n, rank, idx64, ldr, s);
+        const bool hw = rank_hw_order_ok(workspace, workspace_bytes, s) != 0;
+#define SE_RR_CASE(I) if (items <= I) return launch_rank_reg<I>(pdist, ldp, q, (int)n, rank, idx64, ldr, hw, s);
         SE_RR_CASE(2) SE_RR_CASE(8) SE_RR_CASE(20) SE_RR_CASE(40) SE_RR_CASE(64) SE_RR_CASE(80) SE_RR_CASE(98) SE_RR_CASE(104)
 #undef SE_RR_CASE
     }

@@ -14,6 +14,9 @@ from oracle import retrieval_oracle as ro
 
 pytestmark = pytest.mark.gpu
 
+ROOT_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG_DIR = os.path.join(ROOT_DIR, 'semantic-embeddings_amd')
+
 
 @pytest.fixture(scope="module")
 def sehip():
@@ -148,6 +151,31 @@ def test_rank_rows_strided_and_unaligned_output(sehip):
     assert np.array_equal(out.cpu().numpy(), ro.canon_rank_rows(np.ascontiguousarray(pdw[:, 1:2998])))
     out64 = sehip.rank_rows(pd, idx64=True)
     assert np.array_equal(out64.cpu().numpy(), ro.canon_rank_rows(np.ascontiguousarray(pdw[:, 1:2998])))
+
+
+def test_rank_rows_ballot_kernel_in_subprocess():
+    """The guaranteed-order (ballot multisplit) variant stays covered although the capability probe selects
+    the hardware-ordered variant on MI355X: SE_RANK_SAFE is read once per process, hence the subprocess."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np, torch\n"
+        "sys.path[:0] = %r\n"
+        "import sehip\n"
+        "from oracle import retrieval_oracle as ro\n"
+        "rng = np.random.default_rng(3)\n"
+        "for n in (777, 5000, 20481, 50000):\n"
+        "    pd = rng.standard_normal((3, n)).astype(np.float32)\n"
+        "    pd[1] = rng.integers(-2, 3, size=n).astype(np.float32)\n"
+        "    pd[2, ::3] = np.nan\n"
+        "    got = sehip.rank_rows(torch.from_numpy(pd).cuda()).cpu().numpy()\n"
+        "    assert np.array_equal(got, ro.canon_rank_rows(pd)), n\n"
+        "print('ballot-ok')\n"
+    ) % ([PKG_DIR, ROOT_DIR],)
+    env = dict(os.environ, SE_RANK_SAFE="1", SE_RANK_VERBOSE="1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert out.returncode == 0 and "ballot-ok" in out.stdout, out.stdout
+    assert "hardware-ordered" not in out.stdout
 
 
 def test_rank_rows_many_rows_persistent_grid(sehip):
