@@ -117,6 +117,29 @@ int se_nn_accuracy(const float *y_pred, int64_t ldp, const int64_t *labels, cons
                    int64_t lde, int64_t B, int64_t D, int64_t C, int dot_prod_sim, int k,
                    float *acc, float *scores, int64_t lds, int32_t *best, se_stream_t stream);
 
+/*
+ * Label-embedding baseline loss (Sun et al.), forward and backward.
+ * Replaces: labelembed_loss(out1, out2, tar, targets, tau, alpha, beta) and cross_entropy
+ *           (learn_labelembedding.py:17-37); the backward is what TF autodiff derives from it
+ *           (softmax(out2 / tau), softmax(tar) inside L_o1_emb and the arg-max mask are stop_gradient).
+ *   out1, out2, tar [B, C] f32 logits (ld* elements between rows); targets [B] int64
+ *   loss_i [B] f32 out (the reference returns it as [B, 1], learn_labelembedding.py:54)
+ *   aux    se_labelembed_aux_floats(B) floats, caller-owned: per-sample log-sum-exps, the mask and the
+ *          batch scale B / (sum mask + 1e-8); written by fwd, read by bwd
+ *   bwd: grad_loss_i [B] f32 upstream gradient (NULL: grad_scale for every sample);
+ *        d_out1, d_out2, d_tar [B, C] f32 out, any of them may be NULL
+ */
+int64_t se_labelembed_aux_floats(int64_t B);
+int se_labelembed_loss_fwd(const float *out1, int64_t ld1, const float *out2, int64_t ld2,
+                           const float *tar, int64_t ldt, const int64_t *targets, int64_t B, int64_t C,
+                           float tau, float alpha, float beta, float *loss_i, float *aux,
+                           se_stream_t stream);
+int se_labelembed_loss_bwd(const float *out1, int64_t ld1, const float *out2, int64_t ld2,
+                           const float *tar, int64_t ldt, const int64_t *targets,
+                           const float *grad_loss_i, float grad_scale, int64_t B, int64_t C, float tau,
+                           float alpha, float beta, const float *aux, float *d_out1, int64_t ldd1,
+                           float *d_out2, int64_t ldd2, float *d_tar, int64_t lddt, se_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Retrieval side  (evaluate_retrieval.pairwise_retrieval, evaluate_retrieval.py:22-73)
  * ------------------------------------------------------------------------------------------ */

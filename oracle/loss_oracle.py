@@ -177,3 +177,31 @@ def labelembed_loss(out1, out2, tar, targets, tau=2.0, alpha=0.9, beta=0.5, dtyp
     l_emb_o2 = -np.sum(tau2_prob * _log_softmax(tar), axis=1) * mask * (b / (mask.sum() + 1e-8))
     l_re = np.maximum(out2_prob[rows, targets] - alpha, 0)
     return beta * l_o1_y + (1 - beta) * l_o1_emb + l_o2_y + l_emb_o2 + l_re
+
+
+def labelembed_loss_bwd(out1, out2, tar, targets, grad_loss_i, tau=2.0, alpha=0.9, beta=0.5, dtype=np.float64):
+    """Closed-form gradient of `labelembed_loss` w.r.t. (out1, out2, tar) as TF autodiff derives it from
+    learn_labelembedding.py:21-37: softmax(out2 / tau), softmax(tar) inside L_o1_emb and the arg-max mask are
+    stop_gradient; clip_by_value passes gradient only strictly inside [1e-7, 1 - 1e-7].  Checked against torch
+    autograd of the same expression in tests/test_oracle.py."""
+    out1 = np.asarray(out1, dtype=dtype)
+    out2 = np.asarray(out2, dtype=dtype)
+    tar = np.asarray(tar, dtype=dtype)
+    targets = np.asarray(targets).astype(np.int64)
+    g = np.asarray(grad_loss_i, dtype=dtype)[:, None]
+    b, c = out1.shape
+    rows = np.arange(b)
+    keps = 1e-7
+    hot = np.zeros((b, c), dtype=dtype)
+    hot[rows, targets] = 1
+    sm1, sm2, smt, sm2t = _softmax(out1), _softmax(out2), _softmax(tar), _softmax(out2 / tau)
+    p1y, p2y = sm1[rows, targets][:, None], sm2[rows, targets][:, None]
+    k1 = ((p1y > keps) & (p1y < 1 - keps)).astype(dtype) * beta
+    k2 = ((p2y > keps) & (p2y < 1 - keps)).astype(dtype)
+    kre = np.where(p2y > alpha, p2y, 0.0)
+    mask = (out2.argmax(axis=-1) == targets).astype(dtype)
+    scale = b / (mask.sum() + 1e-8)
+    d1 = g * (k1 * (sm1 - hot) + (1 - beta) * (sm1 - smt))
+    d2 = g * (k2 * (sm2 - hot) + kre * (hot - sm2))
+    dt = g * (mask * scale)[:, None] * (smt - sm2t)
+    return d1, d2, dt

@@ -21,6 +21,7 @@ TOPK_MAX = 2048
 EXPORTS = (
     "se_version", "se_last_error", "se_build_arch",
     "se_cosine_loss_fwd", "se_cosine_loss_bwd", "se_l2norm_fwd", "se_l2norm_bwd", "se_nn_accuracy",
+    "se_labelembed_aux_floats", "se_labelembed_loss_fwd", "se_labelembed_loss_bwd",
     "se_row_sqnorm", "se_normalize_rows", "se_pairwise_dist",
     "se_rank_rows_workspace_bytes", "se_rank_rows",
     "se_topk_rows", "se_topk_merge",
@@ -71,6 +72,11 @@ def lib():
     L.se_l2norm_fwd.argtypes = [vp, c_int, c_i64, c_i64, c_i64, vp, c_i64, vp, vp]
     L.se_l2norm_bwd.argtypes = [vp, c_i64, vp, c_i64, vp, c_i64, c_i64, vp, c_i64, vp]
     L.se_nn_accuracy.argtypes = [vp, c_i64, vp, vp, c_i64, c_i64, c_i64, c_i64, c_int, c_int, vp, vp, c_i64, vp, vp]
+    L.se_labelembed_aux_floats.argtypes = [c_i64]
+    L.se_labelembed_aux_floats.restype = c_i64
+    L.se_labelembed_loss_fwd.argtypes = [vp, c_i64, vp, c_i64, vp, c_i64, vp, c_i64, c_i64, c_f, c_f, c_f, vp, vp, vp]
+    L.se_labelembed_loss_bwd.argtypes = [vp, c_i64, vp, c_i64, vp, c_i64, vp, vp, c_f, c_i64, c_i64, c_f, c_f, c_f, vp,
+                                         vp, c_i64, vp, c_i64, vp, c_i64, vp]
     L.se_row_sqnorm.argtypes = [vp, c_i64, c_i64, c_i64, vp, vp]
     L.se_normalize_rows.argtypes = [vp, c_i64, c_i64, c_i64, vp]
     L.se_pairwise_dist.argtypes = [vp, c_i64, vp, c_i64, vp, vp, c_i64, c_i64, c_i64, c_int,

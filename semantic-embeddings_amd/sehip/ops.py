@@ -13,7 +13,7 @@ from ._lib import (DTYPE_BF16, DTYPE_F32, METRIC_COSINE, METRIC_DOT, METRIC_EUCL
                    require_gpu, stream_ptr)
 
 __all__ = [
-    "cosine_embedding_loss", "cosine_loss_forward", "cosine_loss_backward", "l2norm", "nn_accuracy",
+    "cosine_embedding_loss", "cosine_loss_forward", "cosine_loss_backward", "l2norm", "nn_accuracy", "labelembed_loss",
     "row_sqnorm", "normalize_rows_", "pairwise_dist", "rank_rows", "topk_rows", "topk_merge", "retrieve_topk",
     "METRIC_COSINE", "METRIC_EUCLID", "METRIC_DOT",
 ]
@@ -164,6 +164,49 @@ def nn_accuracy(y_pred, labels, embedding, dot_prod_sim=False, k=1, want_scores=
     if want_best:
         out += (best,)
     return out if len(out) > 1 else acc
+
+
+class _LabelEmbedLoss(torch.autograd.Function):
+    """reference: labelembed_loss (learn_labelembedding.py:21-37) and its TF-autodiff backward."""
+
+    @staticmethod
+    def forward(ctx, out1, out2, tar, targets, tau, alpha, beta):
+        require_gpu(out1, out2, tar, targets)
+        for t, name in ((out1, "out1"), (out2, "out2"), (tar, "tar")):
+            _f32_rows(t, name)
+        B, C = out1.shape
+        if out2.shape != (B, C) or tar.shape != (B, C):
+            raise SehipError("out1, out2 and tar must share the shape [B, C]")
+        if targets.dtype != torch.int64 or targets.numel() != B or not targets.is_contiguous():
+            raise SehipError("targets must be a contiguous int64 [B] tensor")
+        loss_i = torch.empty((B,), dtype=torch.float32, device=out1.device)
+        aux = torch.empty((max(int(lib().se_labelembed_aux_floats(B)), 1),), dtype=torch.float32, device=out1.device)
+        check(lib().se_labelembed_loss_fwd(ptr(out1), out1.stride(0), ptr(out2), out2.stride(0), ptr(tar), tar.stride(0),
+                                           ptr(targets), B, C, float(tau), float(alpha), float(beta), ptr(loss_i), ptr(aux),
+                                           stream_ptr()), "se_labelembed_loss_fwd")
+        ctx.save_for_backward(out1, out2, tar, targets, aux)
+        ctx.hyper = (float(tau), float(alpha), float(beta))
+        return loss_i
+
+    @staticmethod
+    def backward(ctx, grad):
+        out1, out2, tar, targets, aux = ctx.saved_tensors
+        tau, alpha, beta = ctx.hyper
+        B, C = out1.shape
+        grad = grad.contiguous().to(torch.float32)
+        need = ctx.needs_input_grad
+        d1 = torch.empty_like(out1, memory_format=torch.contiguous_format) if need[0] else None
+        d2 = torch.empty_like(out2, memory_format=torch.contiguous_format) if need[1] else None
+        dt = torch.empty_like(tar, memory_format=torch.contiguous_format) if need[2] else None
+        check(lib().se_labelembed_loss_bwd(ptr(out1), out1.stride(0), ptr(out2), out2.stride(0), ptr(tar), tar.stride(0),
+                                           ptr(targets), ptr(grad), 0.0, B, C, tau, alpha, beta, ptr(aux),
+                                           ptr(d1), C, ptr(d2), C, ptr(dt), C, stream_ptr()), "se_labelembed_loss_bwd")
+        return d1, d2, dt, None, None, None, None
+
+
+def labelembed_loss(out1, out2, tar, targets, tau=2.0, alpha=0.9, beta=0.5):
+    """Per-sample label-embedding loss [B] (learn_labelembedding.py:21-37), differentiable w.r.t. out1, out2, tar."""
+    return _LabelEmbedLoss.apply(out1, out2, tar, targets, tau, alpha, beta)
 
 
 # --------------------------------------------------------------------------------------------

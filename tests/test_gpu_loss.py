@@ -147,3 +147,37 @@ def test_nn_accuracy_on_reference_embeddings(sehip, emb, name, dot, k):
     gap = (top2[:, -1] - top2[:, -2]) if dot else (top2[:, 1] - top2[:, 0])
     clear = gap > 1e-4 * max(1.0, np.abs(scores64).max())
     assert np.array_equal(best.cpu().numpy()[clear], want_best[clear])
+
+
+@pytest.mark.parametrize("b,c", [(1, 1), (7, 5), (128, 100), (33, 1000), (300, 64)])
+def test_labelembed_loss_fwd_bwd_vs_oracle(b, c):
+    """se_labelembed_loss_fwd/bwd (learn_labelembedding.py:21-37) vs the fp64 oracle: 1e-4 on the loss
+    (north_star tolerance), 1e-5 on the gradients; includes samples with mask = 1 and an active relu term."""
+    import sehip
+    from oracle import loss_oracle as lo
+    rng = np.random.default_rng(b * 1000 + c)
+    o1, o2, tr = (rng.standard_normal((b, c)).astype(np.float32) * 2 for _ in range(3))
+    y = rng.integers(0, c, size=b)
+    o2[np.arange(b)[::2], y[::2]] += 7.0       # correct + confident: mask = 1, relu(p - alpha) > 0
+    g = rng.standard_normal(b).astype(np.float32)
+    t1, t2, t3 = (torch.from_numpy(a).cuda().requires_grad_(True) for a in (o1, o2, tr))
+    loss = sehip.labelembed_loss(t1, t2, t3, torch.from_numpy(y).cuda())
+    want = lo.labelembed_loss(o1, o2, tr, y)
+    assert loss.shape == (b,)
+    assert np.abs(loss.detach().cpu().numpy() - want).max() <= 1e-4 * max(1.0, np.abs(want).max())
+    loss.backward(torch.from_numpy(g).cuda())
+    d1, d2, dt = lo.labelembed_loss_bwd(o1, o2, tr, y, g)
+    for got, ref in ((t1.grad, d1), (t2.grad, d2), (t3.grad, dt)):
+        assert np.abs(got.cpu().numpy() - ref).max() <= 1e-5 * max(1.0, np.abs(ref).max())
+
+
+def test_labelembed_mirror_module_signature():
+    """semantic-embeddings_amd/learn_labelembedding.labelembed_loss keeps the reference signature."""
+    import learn_labelembedding as ll
+    from oracle import loss_oracle as lo
+    rng = np.random.default_rng(9)
+    b, c = 32, 100
+    o1, o2, tr = (rng.standard_normal((b, c)).astype(np.float32) for _ in range(3))
+    y = rng.integers(0, c, size=(b, 1))
+    got = ll.labelembed_loss(*(torch.from_numpy(a).cuda() for a in (o1, o2, tr)), torch.from_numpy(y).cuda(), tau=2., alpha=0.9, beta=0.5, num_classes=c)
+    assert np.abs(got.cpu().numpy() - lo.labelembed_loss(o1, o2, tr, y.ravel())).max() <= 1e-4

@@ -138,3 +138,36 @@ def test_labelembed_loss_matches_torch():
            + -(F.softmax(O2 / 2, -1) * F.log_softmax(T, -1)).sum(1) * mask * (B / (mask.sum() + 1e-8))
            + torch.relu(p2[torch.arange(B), tt] - 0.9))
     assert np.allclose(got, ref.numpy(), atol=1e-6)
+
+
+def test_labelembed_oracle_backward_matches_torch_autograd():
+    """The closed-form label-embedding gradient of the oracle == autograd of the reference expression
+    (learn_labelembedding.py:21-37 restated in torch with detach() for stop_gradient)."""
+    import torch
+    from oracle import loss_oracle as lo
+    rng = np.random.default_rng(5)
+    b, c = 16, 37
+    o1, o2, tr = (rng.standard_normal((b, c)) * 2 for _ in range(3))
+    y = rng.integers(0, c, size=b)
+    o2[np.arange(b)[::2], y[::2]] += 6.0           # half of the samples are classified correctly by out2 (mask = 1)
+    g = rng.standard_normal(b)
+    t1, t2, t3 = (torch.tensor(a, dtype=torch.float64, requires_grad=True) for a in (o1, o2, tr))
+    ty = torch.tensor(y)
+    tau, alpha, beta = 2.0, 0.9, 0.5
+    out2_prob = torch.softmax(t2, dim=1)
+    tau2_prob = torch.softmax(t2 / tau, dim=1).detach()
+    soft_tar = torch.softmax(t3, dim=1).detach()
+    rows = torch.arange(b)
+    l_o1_y = -torch.log(torch.clamp(torch.softmax(t1, dim=1), 1e-7, 1 - 1e-7)[rows, ty])
+    mask = (t2.argmax(dim=1) == ty).double().detach()
+    l_o1_emb = -torch.sum(soft_tar * torch.log_softmax(t1, dim=1), dim=1)
+    l_o2_y = -torch.log(torch.clamp(out2_prob, 1e-7, 1 - 1e-7)[rows, ty])
+    l_emb_o2 = -torch.sum(tau2_prob * torch.log_softmax(t3, dim=1), dim=1) * mask * (b / (mask.sum() + 1e-8))
+    l_re = torch.relu(out2_prob[rows, ty] - alpha)
+    loss = beta * l_o1_y + (1 - beta) * l_o1_emb + l_o2_y + l_emb_o2 + l_re
+    assert np.allclose(loss.detach().numpy(), lo.labelembed_loss(o1, o2, tr, y, tau, alpha, beta), atol=1e-12)
+    loss.backward(torch.tensor(g))
+    d1, d2, dt = lo.labelembed_loss_bwd(o1, o2, tr, y, g, tau, alpha, beta)
+    assert np.allclose(t1.grad.numpy(), d1, atol=1e-12)
+    assert np.allclose(t2.grad.numpy(), d2, atol=1e-12)
+    assert np.allclose(t3.grad.numpy(), dt, atol=1e-12)
