@@ -207,7 +207,8 @@ template <int METRIC, bool MULTI_KB, bool SYM, bool VEC>
 __global__ __launch_bounds__(PD_THREADS, 4) void pdist_kernel(
     const float *__restrict__ A, uint32_t lda, const float *__restrict__ Bm, uint32_t ldb,
     const float *__restrict__ sqa, const float *__restrict__ sqb, int64_t Q, int64_t N, int64_t D,
-    KBlocks kbs, int nchunks, float *__restrict__ out, uint32_t ldo, int tiles_m, int tiles_n, int64_t ntiles, int flags)
+    KBlocks kbs, int nchunks, float *__restrict__ out, uint32_t ldo, int tiles_m, int tiles_n, int64_t ntiles, int flags,
+    unsigned long long *prof)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *sA = smem;
@@ -256,6 +257,9 @@ __global__ __launch_bounds__(PD_THREADS, 4) void pdist_kernel(
     PD_FETCH()
     bool first_kb = true;
 
+    // tuning aid (SE_PD_PROFILE=1): shader-clock cycles per phase of every workgroup's wave 0
+    uint64_t t_acc[6] = {0, 0, 0, 0, 0, 0}, t_last = prof ? __builtin_amdgcn_s_memtime() : 0;
+#define PD_T(i) if (prof) { const uint64_t now = __builtin_amdgcn_s_memtime(); t_acc[i] += now - t_last; t_last = now; }
     const int64_t total = my_tiles * nchunks;
 #pragma unroll 1
     for (int64_t it = 0; it < total; it++) {
@@ -268,11 +272,18 @@ __global__ __launch_bounds__(PD_THREADS, 4) void pdist_kernel(
         const int rows_b = (int)((N - cur_n0 < PD_BN) ? (N - cur_n0) : PD_BN);
 
         __syncthreads();  // LDS free: everyone finished the previous chunk's MFMAs
+        PD_T(0)
         pd_store(sA, ra, rows_a, kc);
         pd_store(sB, rb, rows_b, kc);
+        PD_T(1)
         __syncthreads();
+        PD_T(2)
 
         // ---- prefetch the next chunk (same tile or first chunk of the next tile) ----
+        // (Spreading these 8 loads over the first four MFMA groups instead -- the burst costs each wave ~3k cycles of
+        // VMEM issue per chunk, SE_PD_PROFILE=1 -- was measured and is slower, 3.5 -> 3.75 ms: a load that blocks
+        // inside the MFMA loop stalls the matrix pipe of its wave; so was a register double buffer of the LDS
+        // operand reads, 3.5 -> 3.9 ms.)
         if (it + 1 < total) {
             const int nc = (c + 1 == nchunks) ? 0 : c + 1;
             if (nc == 0) pd_tile_coords<SYM>(band_beg + wg_in_xcd + ((it + 1) / nchunks) * wgs_per_xcd, tiles_m, tiles_n, m0, n0);
@@ -280,14 +291,13 @@ __global__ __launch_bounds__(PD_THREADS, 4) void pdist_kernel(
             PD_FETCH()
         }
 
+        PD_T(3)
         // ---- MFMA over the chunk in LDS: 2 k per step, 4 steps per 16-byte operand read ----
         const int steps = (flags & PDF_NO_MFMA) ? 0 : ((kc + 1) >> 1);
         const int full = steps & ~3;
 #define PD_STEP(C)                                                                \
     acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.C, b0.C, acc[0], 0, 0, 0);   \
     acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.C, b1.C, acc[1], 0, 0, 0);
-        // (Issuing the operand reads of group g+1 before the MFMAs of group g -- a register double buffer -- was
-        // measured and does not pay: with 4 waves per SIMD the LDS round trip is already covered; 3.5 -> 3.9 ms.)
         for (int s = 0; s < full; s += 4) {
             const float4 a4 = *(const float4 *)(pa + s);
             const float4 b0 = *(const float4 *)(pb0 + s);
@@ -304,6 +314,7 @@ __global__ __launch_bounds__(PD_THREADS, 4) void pdist_kernel(
         }
 #undef PD_STEP
 
+        PD_T(4)
         if (MULTI_KB && cur_closes) {
 #pragma unroll
             for (int j = 0; j < 2; j++)
@@ -379,8 +390,12 @@ __global__ __launch_bounds__(PD_THREADS, 4) void pdist_kernel(
 #pragma unroll
                 for (int r = 0; r < 16; r++) acc[j][r] = 0.f;
             first_kb = true;
+            PD_T(5)
         }
     }
+    if (prof && threadIdx.x == 0)
+        for (int i = 0; i < 6; i++) atomicAdd(&prof[i], (unsigned long long)t_acc[i]);
+#undef PD_T
 #undef PD_FETCH
 }
 
@@ -418,9 +433,27 @@ static int launch_pdist3(const float *a, int64_t lda, const float *b, int64_t ld
     if (grid < 1) grid = 1;
     auto kern = pdist_kernel<METRIC, MULTI, SYM, VEC>;
     SE_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    static const bool profile = getenv("SE_PD_PROFILE") != nullptr;   // tuning aid only: allocates, synchronises, prints
+    unsigned long long *prof = nullptr;
+    if (profile) {
+        SE_HIP_CHECK(hipMalloc((void **)&prof, 6 * sizeof(unsigned long long)));
+        SE_HIP_CHECK(hipMemsetAsync(prof, 0, 6 * sizeof(unsigned long long), s));
+    }
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(PD_THREADS), lds, s, a, (uint32_t)lda, b, (uint32_t)ldb, sqa, sqb, q, n,
-                       d, kbs, nchunks, out, (uint32_t)ldo, tiles_m, tiles_n, ntiles, flags);
+                       d, kbs, nchunks, out, (uint32_t)ldo, tiles_m, tiles_n, ntiles, flags, prof);
     SE_LAUNCH_CHECK();
+    if (profile) {
+        unsigned long long h[6];
+        SE_HIP_CHECK(hipStreamSynchronize(s));
+        SE_HIP_CHECK(hipMemcpy(h, prof, sizeof(h), hipMemcpyDeviceToHost));
+        SE_HIP_CHECK(hipFree(prof));
+        static const char *names[6] = {"wait-barrier", "stage-operands", "barrier", "prefetch-issue", "mfma", "epilogue"};
+        double tot = 0;
+        for (int i = 0; i < 6; i++) tot += (double)h[i];
+        fprintf(stderr, "[se_pairwise_dist profile] sym=%d grid=%lld tiles=%lld:", (int)SYM, (long long)grid, (long long)ntiles);
+        for (int i = 0; i < 6; i++) fprintf(stderr, " %s %.1f%%", names[i], 100.0 * (double)h[i] / tot);
+        fprintf(stderr, "  (%.0f cycles per tile per workgroup)\n", tot / (double)ntiles);
+    }
     return SE_OK;
 }
 
