@@ -9,8 +9,8 @@ One JSON line on stdout (rank 0).  See DESIGN.md section 6 for what a "step" is:
   one step = the whole ``pairwise_retrieval`` device path on synthetic float32 features already
   resident in HBM -- row normalisation, all-pairs cosine distance matrix, full canonical ranking.
   value = query x gallery pairs ranked per second (Mpairs/s), summed over ranks.  With N > 1 every
-  rank ranks its own 50k-query shard against the replicated 50k gallery (weak scaling, no data-path
-  collective: rows of the ranking are independent -- SURVEY.md section 8e row 2).
+  rank evaluates its own 50k x 50k feature set (weak scaling, no data-path collective: retrieval jobs
+  and the rows of a ranking are independent -- SURVEY.md section 8e row 2).
 * train (BASELINE.json configs[1]): ResNet-110-fc cosine-embedding training step, images/s
   (reported in the ``train`` object of the same line when --with-train is given, or as the primary
   metric with --workload train).
@@ -101,12 +101,13 @@ def bench_retrieval(args, rank, world):
     n, d = args.n, args.d
     q = args.q or n
     metric = sehip.METRIC_COSINE if args.metric == "cosine" else sehip.METRIC_EUCLID
-    rng = np.random.default_rng(0)
-    feats_h = rng.standard_normal((n, d)).astype(np.float32)     # SURVEY.md 8d synthetic features
+    # SURVEY.md 8d synthetic features.  Weak scaling: every rank evaluates its OWN feature file of the same shape
+    # (rank r: seed r), i.e. N independent `evaluate_retrieval` jobs -- identical work per rank, no data-path collective.
+    rng = np.random.default_rng(rank)
+    feats_h = rng.standard_normal((n, d)).astype(np.float32)
     gallery0 = torch.from_numpy(feats_h).cuda()
-    # rank r's queries: its own seeded set (weak scaling); rank 0 at N=1 uses the gallery itself
-    if world == 1 and q == n:
-        queries0 = None
+    if q == n:
+        queries0 = None        # all-pairs within the feature set (the reference's only mode): symmetric kernel
     else:
         qrng = np.random.default_rng(100 + rank)
         queries0 = torch.from_numpy(qrng.standard_normal((q, d)).astype(np.float32)).cuda()
@@ -167,7 +168,8 @@ def bench_retrieval(args, rank, world):
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "CIFAR-100-sized retrieval: %d queries/GPU x %d gallery, D=%d, %s, "
                                "normalise + all-pairs distance + full canonical ranking" % (q, n, d, args.metric),
-                   "queries_per_gpu": q, "gallery": n, "dim": d, "parallelism": "query-sharded x%d" % world},
+                   "queries_per_gpu": q, "gallery": n, "dim": d,
+                   "parallelism": "%d independent feature sets, one per GPU (no collective)" % world},
         "roofline": roofline, "kernels": kernels,
     }
     return out, feats_h
