@@ -36,15 +36,25 @@ namespace se {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int PD_BM = 128, PD_BN = 128, PD_BK = 64;
+#ifndef SE_PD_BK
+#define SE_PD_BK 64
+#endif
+#ifndef SE_PD_WGS
+#define SE_PD_WGS 2
+#endif
+constexpr int PD_BM = 128, PD_BN = 128, PD_BK = SE_PD_BK;   // K-chunk staged per barrier pair: 64 or 32
 constexpr int PD_THREADS = 512;
 constexpr int PD_LD = PD_BK + 4;  // padded LDS row pitch in floats
-constexpr int PD_SP = PD_BN + 4;  // row pitch of the epilogue stage (128 x 132 floats fit in the operand buffers)
-static_assert(PD_BM * PD_SP <= (PD_BM + PD_BN) * PD_LD, "epilogue stage must fit in the operand LDS");
+constexpr int PD_SP = PD_BN + 4;  // row pitch of the epilogue stage
+// rows of the output tile staged at a time: the whole tile when the operand buffers can hold it (BK = 64), else half
+constexpr int PD_SR = (PD_BM * PD_SP <= (PD_BM + PD_BN) * PD_LD) ? PD_BM : PD_BM / 2;
+static_assert(PD_SR * PD_SP <= (PD_BM + PD_BN) * PD_LD, "epilogue stage must fit in the operand LDS");
 constexpr int PD_GROUP_M = 16;
 constexpr int PD_MAX_KB = 16;
-constexpr int PD_WGS_PER_CU = 2;
-constexpr int PD_NLOAD = PD_BM * (PD_BK / 4) / PD_THREADS;  // float4 per operand per thread = 4
+constexpr int PD_WGS_PER_CU = SE_PD_WGS;
+constexpr int PD_F4R = PD_BK / 4;                            // 16-byte pieces per operand row of a chunk
+constexpr int PD_RPP = PD_THREADS / PD_F4R;                  // operand rows covered by one piece per thread
+constexpr int PD_NLOAD = PD_BM / PD_RPP;                     // pieces per operand per thread (4 at BK = 64, 2 at BK = 32)
 constexpr int64_t PD_MAX_LD = (int64_t)1 << 23;              // 128 rows * ld must fit 32-bit offsets
 
 struct KBlocks {
@@ -65,7 +75,7 @@ __device__ __forceinline__ void pd_load(float4 (&v)[PD_NLOAD], const float *__re
                                         int64_t nrows, int64_t k0, int64_t kend)
 {
     const int tid = threadIdx.x;
-    const int r0 = tid >> 4, kq = (tid & 15) * 4;
+    const int r0 = tid / PD_F4R, kq = (tid % PD_F4R) * 4;
     const float *base = src + row0 * (int64_t)ld;                 // uniform
     const int rows_here = (int)((nrows - row0 < PD_BM) ? (nrows - row0) : PD_BM);   // >= 1
     const int klen = (int)(kend - k0);                            // valid k in this chunk (may exceed 64)
@@ -74,14 +84,14 @@ __device__ __forceinline__ void pd_load(float4 (&v)[PD_NLOAD], const float *__re
         const uint32_t kc = (uint32_t)(k0 + (kq < kmax ? kq : kmax));
 #pragma unroll
         for (int it = 0; it < PD_NLOAD; it++) {
-            const int r = it * 32 + r0;
+            const int r = it * PD_RPP + r0;
             const int rc = r < rows_here ? r : rows_here - 1;
             v[it] = *(const float4 *)(base + ((uint32_t)rc * ld + kc));
         }
     } else {
 #pragma unroll
         for (int it = 0; it < PD_NLOAD; it++) {
-            const int r = it * 32 + r0;
+            const int r = it * PD_RPP + r0;
             const int rc = r < rows_here ? r : rows_here - 1;
             float e[4];
 #pragma unroll
@@ -100,14 +110,14 @@ __device__ __forceinline__ void pd_load(float4 (&v)[PD_NLOAD], const float *__re
 __device__ __forceinline__ void pd_store(float *lds, const float4 (&v)[PD_NLOAD], int rows_here, int klen)
 {
     const int tid = threadIdx.x;
-    const int r0 = tid >> 4, kq = (tid & 15) * 4;
+    const int r0 = tid / PD_F4R, kq = (tid % PD_F4R) * 4;
     const int nvalid = klen - kq;
     float *o = lds + r0 * PD_LD + (kq >> 1);
 #pragma unroll
     for (int it = 0; it < PD_NLOAD; it++) {
-        const bool rok = (it * 32 + r0) < rows_here;
-        *(float2 *)(o + it * 32 * PD_LD) = make_float2(mask_f(v[it].x, rok && nvalid > 0), mask_f(v[it].z, rok && nvalid > 2));
-        *(float2 *)(o + it * 32 * PD_LD + 32) = make_float2(mask_f(v[it].y, rok && nvalid > 1), mask_f(v[it].w, rok && nvalid > 3));
+        const bool rok = (it * PD_RPP + r0) < rows_here;
+        *(float2 *)(o + it * PD_RPP * PD_LD) = make_float2(mask_f(v[it].x, rok && nvalid > 0), mask_f(v[it].z, rok && nvalid > 2));
+        *(float2 *)(o + it * PD_RPP * PD_LD + PD_BK / 2) = make_float2(mask_f(v[it].y, rok && nvalid > 1), mask_f(v[it].w, rok && nvalid > 3));
     }
 }
 
@@ -167,7 +177,7 @@ __device__ __forceinline__ void pd_tile_coords(int64_t t, int tiles_m, int tiles
 }
 
 
-// Stage [128][PD_SP] in LDS -> global rows: thread t moves 16 bytes, 32 lanes cover one 512-byte row segment.
+// Stage [PD_SR][PD_SP] in LDS -> global rows: thread t moves 16 bytes, 32 lanes cover one 512-byte row segment.
 __device__ __forceinline__ void pd_stream_rows(const float *stage, float *gbase, uint32_t ldo, int nrows, int ncols, bool fast, bool nt, bool dry)
 {
     const int tid = threadIdx.x;
@@ -175,7 +185,7 @@ __device__ __forceinline__ void pd_stream_rows(const float *stage, float *gbase,
     char *gb = (char *)gbase;                                    // uniform base + 32-bit byte offsets
     const uint32_t ldo4 = ldo * 4u;
 #pragma unroll
-    for (int p = 0; p < PD_BM / 16; p++) {
+    for (int p = 0; p < PD_SR / 16; p++) {
         const int row = p * 16 + r0;
         const float4 v = *(const float4 *)&stage[row * PD_SP + c4];
         if (dry) { asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w)); continue; }   // tuning aid: stage traffic without HBM writes
@@ -204,7 +214,7 @@ __device__ __forceinline__ float pd_finish(float v, float sa, float sb)
 constexpr int PDF_VEC_A = 1, PDF_VEC_B = 2, PDF_VEC_O = 4, PDF_NO_STORE = 8, PDF_NO_MFMA = 16, PDF_STAGGER = 32, PDF_PLAIN_ST = 64, PDF_NO_GSTORE = 128;
 
 template <int METRIC, bool MULTI_KB, bool SYM, bool VEC>
-__global__ __launch_bounds__(PD_THREADS, 4) void pdist_kernel(
+__global__ __launch_bounds__(PD_THREADS, 2 * PD_WGS_PER_CU) void pdist_kernel(
     const float *__restrict__ A, uint32_t lda, const float *__restrict__ Bm, uint32_t ldb,
     const float *__restrict__ sqa, const float *__restrict__ sqb, int64_t Q, int64_t N, int64_t D,
     KBlocks kbs, int nchunks, float *__restrict__ out, uint32_t ldo, int tiles_m, int tiles_n, int64_t ntiles, int flags,
@@ -241,8 +251,8 @@ __global__ __launch_bounds__(PD_THREADS, 4) void pdist_kernel(
 #pragma unroll
         for (int r = 0; r < 16; r++) { acc[j][r] = 0.f; if (MULTI_KB) tot[j][r] = 0.f; }
 
-    const float *pa = sA + (wm * 32 + col) * PD_LD + hi * 32;
-    const float *pb0 = sB + (wn * 64 + col) * PD_LD + hi * 32;
+    const float *pa = sA + (wm * 32 + col) * PD_LD + hi * (PD_BK / 2);
+    const float *pb0 = sB + (wn * 64 + col) * PD_LD + hi * (PD_BK / 2);
     const float *pb1 = pb0 + 32 * PD_LD;
 
     // ---- prologue: fetch (tile 0, chunk 0) ----
@@ -361,26 +371,39 @@ __global__ __launch_bounds__(PD_THREADS, 4) void pdist_kernel(
                         sa_[r] = sqa[cur_m0 + (lr < rows_here ? lr : rows_here - 1)];
                     }
                 }
-                __syncthreads();   // every wave is done reading the last chunk's operands
-                // tile -> stage[row][col]: per instruction lanes 0-31 fill 32 consecutive floats of one row
 #pragma unroll
-                for (int j = 0; j < 2; j++)
+                for (int h = 0; h < PD_BM / PD_SR; h++) {
+                    __syncthreads();   // operands of the last chunk / the previous stage contents are no longer needed
+                    // tile rows [h SR, (h+1) SR) -> stage[row][col]: per instruction lanes 0-31 fill 32 consecutive floats of one row
+                    if ((wm * 32) / PD_SR == h) {
 #pragma unroll
-                    for (int r = 0; r < 16; r++)
-                        smem[(lr0 + (r & 3) + 8 * (r >> 2)) * PD_SP + wn * 64 + j * 32 + col] = PD_VAL(j, r);
-                __syncthreads();
-                pd_stream_rows(smem, out + (cur_m0 * (int64_t)ldo + cur_n0), ldo, rows_here, cols_here, fast, nt, flags & PDF_NO_GSTORE);
+                        for (int j = 0; j < 2; j++)
+#pragma unroll
+                            for (int r = 0; r < 16; r++)
+                                smem[(lr0 - h * PD_SR + (r & 3) + 8 * (r >> 2)) * PD_SP + wn * 64 + j * 32 + col] = PD_VAL(j, r);
+                    }
+                    __syncthreads();
+                    pd_stream_rows(smem, out + ((cur_m0 + h * PD_SR) * (int64_t)ldo + cur_n0), ldo, rows_here - h * PD_SR, cols_here, fast, nt,
+                                   flags & PDF_NO_GSTORE);
+                }
                 if (mirror) {
-                    // transposed tile -> stage[col][row]: a lane owns 4 consecutive rows of its column = 16 bytes
-                    __syncthreads();
 #pragma unroll
-                    for (int j = 0; j < 2; j++)
+                    for (int h = 0; h < PD_BN / PD_SR; h++) {
+                        // transposed tile rows (= tile columns) [h SR, (h+1) SR) -> stage[col][row]: a lane owns 4 consecutive
+                        // rows of its column = 16 bytes
+                        __syncthreads();
+                        if ((wn * 64) / PD_SR == h) {
 #pragma unroll
-                        for (int g = 0; g < 4; g++)
-                            *(float4 *)&smem[(wn * 64 + j * 32 + col) * PD_SP + lr0 + 8 * g] =
-                                make_float4(PD_VAL(j, 4 * g), PD_VAL(j, 4 * g + 1), PD_VAL(j, 4 * g + 2), PD_VAL(j, 4 * g + 3));
-                    __syncthreads();
-                    pd_stream_rows(smem, out + (cur_n0 * (int64_t)ldo + cur_m0), ldo, cols_here, rows_here, fast, nt, flags & PDF_NO_GSTORE);
+                            for (int j = 0; j < 2; j++)
+#pragma unroll
+                                for (int g = 0; g < 4; g++)
+                                    *(float4 *)&smem[(wn * 64 - h * PD_SR + j * 32 + col) * PD_SP + lr0 + 8 * g] =
+                                        make_float4(PD_VAL(j, 4 * g), PD_VAL(j, 4 * g + 1), PD_VAL(j, 4 * g + 2), PD_VAL(j, 4 * g + 3));
+                        }
+                        __syncthreads();
+                        pd_stream_rows(smem, out + ((cur_n0 + h * PD_SR) * (int64_t)ldo + cur_m0), ldo, cols_here - h * PD_SR, rows_here, fast, nt,
+                                       flags & PDF_NO_GSTORE);
+                    }
                 }
                 // (the barrier that opens the next chunk orders these LDS reads before the operands overwrite the stage)
 #undef PD_VAL

@@ -10,7 +10,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
-LIB_PATH = os.path.join(_HERE, "libsehip.so")
+LIB_PATH = os.environ.get("SEHIP_LIB") or os.path.join(_HERE, "libsehip.so")   # SEHIP_LIB: tuning builds only
 
 SE_OK = 0
 DTYPE_F32, DTYPE_BF16 = 0, 1
