@@ -206,6 +206,27 @@ int se_retrieve_topk(const float *queries, int64_t ldq, const float *gallery, in
                      int metric, int64_t col_offset, int k, float *out_d, int32_t *out_i,
                      void *workspace, int64_t workspace_bytes, se_stream_t stream);
 
+/*
+ * Hierarchical retrieval metrics of every query from its ranking (the consumer of se_rank_rows / se_retrieve_topk).
+ * Replaces: the per-query loop of ClassHierarchy.hierarchical_precision (class_hierarchy.py:211-316):
+ *           P@k (WUP / LCS_HEIGHT), AHP or AHP@K (np.trapz of cum / best, :303-309), AP (:310-314), with the
+ *           reference's handling of the query inside its own ranking (:280-290).
+ *   rank      [q, list_len] int32 gallery indices, best first (ldr elements between rows)
+ *   cls       [gallery] int32 class index of every gallery item;  qcls [q] class index of every query
+ *   qidx      [q] int32 gallery index of the query itself (dropped from its ranking), NULL = keep everything
+ *   wup, lcs  [C, C] f64 class similarity tables (Wu-Palmer, 1 - LCS height / max height)
+ *   best_*    [C, ldb] f64: for query class c, cumulative sum of the descending-sorted similarities of the
+ *             WHOLE gallery to c (class_hierarchy.py:266,275) -- host-side, once per gallery
+ *   ks        [nk] int32 cut-offs; ahp_len: -1 no AHP, 0 whole list, K > 0 clipped AHP@K; want_ap: 0 / 1
+ *   out       [q, 2 nk + 3] f64: P@k WUP x nk, P@k LCS x nk, AHP WUP, AHP LCS, AP (ldo elements between rows)
+ */
+int se_hierarchical_precision(const int32_t *rank, int64_t ldr, int64_t q, int64_t list_len,
+                              const int32_t *cls, const int32_t *qcls, const int32_t *qidx,
+                              const double *wup, const double *lcs, int num_classes,
+                              const double *best_wup, const double *best_lcs, int64_t ldb,
+                              const int32_t *ks, int nk, int64_t ahp_len, int want_ap, double *out,
+                              int64_t ldo, se_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -272,6 +272,68 @@ class ClassHierarchy(object):
         return {metric: sum(values.values()) / len(values) for metric, values in prec.items()}, prec
 
 
+    def hierarchical_precision_device(self, features, labels, ks=[1, 10, 50, 100], compute_ahp=False, compute_ap=False,
+                                      normalize=False, ids=None, tile_rows=None):
+        """``hierarchical_precision(pairwise_retrieval(features, normalize), labels, ...)`` (ignore_qids = True, every
+        image is query and gallery item) without leaving the GPU: the rankings stay device tensors
+        (``evaluate_retrieval.ranking_tiles``) and the per-query gather + prefix sums run in
+        ``se_hierarchical_precision`` instead of the reference's Python loop (class_hierarchy.py:257-314, ~0.6 h at
+        N = 50k) -- and the 330 s ``.tolist()`` hand-off of evaluate_retrieval.py:69-73 disappears.
+
+        ``features``: float32 ``[N, D]`` array (normalised in place on the device copy when ``normalize``);
+        ``labels``: class label of image ``ids[i]`` (``ids`` defaults to ``range(N)``), as a sequence or a mapping.
+        Returns ``(means, per_query)`` exactly like ``hierarchical_precision``."""
+        import torch
+        import sehip
+        from evaluate_retrieval import ranking_tiles
+
+        ks = [ks] if isinstance(ks, int) else list(ks)
+        ahp_clip = None if isinstance(compute_ahp, bool) else int(compute_ahp)
+        n = int(features.shape[0])
+        ids = list(range(n)) if ids is None else list(ids)
+        lab = [labels[i] for i in ids]
+        class_list = sorted(set(lab), key=lambda c: (str(type(c)), c))
+        pos = {c: i for i, c in enumerate(class_list)}
+        cls_h = np.array([pos[c] for c in lab], dtype=np.int32)
+        wup_t, lcs_t = self.similarity_tables(class_list)
+        # best-possible cumulative similarity per query class: descending-sorted similarities of the whole gallery
+        counts = np.bincount(cls_h, minlength=len(class_list))
+        best_w = np.empty((len(class_list), n))
+        best_l = np.empty((len(class_list), n))
+        for c in range(len(class_list)):
+            for table, best in ((wup_t, best_w), (lcs_t, best_l)):
+                vals = table[c]
+                order = np.argsort(-vals, kind='stable')
+                best[c] = np.cumsum(np.repeat(vals[order], counts[order]))
+
+        dev = torch.device('cuda', torch.cuda.current_device())
+        feats = torch.from_numpy(np.ascontiguousarray(features, dtype=np.float32)).to(dev)
+        cls_d = torch.from_numpy(cls_h).to(dev)
+        qidx_d = torch.arange(n, dtype=torch.int32, device=dev)
+        args_d = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (wup_t, lcs_t, best_w, best_l)]
+        ks_d = torch.tensor(ks, dtype=torch.int32, device=dev)
+        ahp_len = -1 if not compute_ahp else (0 if ahp_clip is None else ahp_clip)
+        outs = []
+        for r0, tile in ranking_tiles(feats, normalize, tile_rows=tile_rows):
+            rows = tile.shape[0]
+            outs.append(sehip.hierarchical_precision(tile, cls_d, cls_d[r0:r0 + rows].contiguous(), qidx_d[r0:r0 + rows].contiguous(),
+                                                     *args_d, ks_d, ahp_len=ahp_len, want_ap=compute_ap))
+        res = torch.cat(outs).cpu().numpy()
+
+        nk = len(ks)
+        prec = {}
+        for t, k in enumerate(ks):
+            prec['P@{} (WUP)'.format(k)] = dict(zip(ids, res[:, t].tolist()))
+            prec['P@{} (LCS_HEIGHT)'.format(k)] = dict(zip(ids, res[:, nk + t].tolist()))
+        if compute_ahp:
+            sfx = '' if ahp_clip is None else '@{}'.format(ahp_clip)
+            prec['AHP{} (WUP)'.format(sfx)] = dict(zip(ids, res[:, 2 * nk].tolist()))
+            prec['AHP{} (LCS_HEIGHT)'.format(sfx)] = dict(zip(ids, res[:, 2 * nk + 1].tolist()))
+        if compute_ap:
+            prec['AP'] = dict(zip(ids, res[:, 2 * nk + 2].tolist()))
+        return {metric: sum(values.values()) / len(values) for metric, values in prec.items()}, prec
+
+
 def _average_precision(relevant):
     """AP of a ranking with distinct scores: mean over the relevant items of precision at their
     rank (== sklearn.metrics.average_precision_score for tie-free scores; 0 if nothing is relevant)."""

@@ -227,10 +227,12 @@ def main(argv=None):
     for i, feat_dump in tqdm(enumerate(args.feat), total=len(args.feat)):
         feat_name = args.label[i] if (args.label is not None) and (i < len(args.label)) else os.path.splitext(os.path.basename(feat_dump))[0]
         normalize = args.norm[i] if (args.norm is not None) and (i < len(args.norm)) else False
-        perf[feat_name] = hierarchy.hierarchical_precision(
-            pairwise_retrieval(feat_dump, normalize), labels_test, ks,
-            compute_ahp=args.clip_ahp if args.clip_ahp else True, compute_ap=True,
-            all_ids=list(range(data_generator.num_test)))[0]
+        # reference: hierarchy.hierarchical_precision(pairwise_retrieval(feat_dump, normalize), labels_test, ks, ...)
+        # (evaluate_retrieval.py:197-201).  Here rankings and metrics stay on the GPU: no N x N Python lists.
+        features, ind2id, _ = _as_feature_matrix(feat_dump)
+        perf[feat_name] = hierarchy.hierarchical_precision_device(
+            features, labels_test, ks, compute_ahp=args.clip_ahp if args.clip_ahp else True, compute_ap=True,
+            normalize=normalize, ids=None if ind2id is None else ind2id.tolist())[0]
 
     metrics = list(METRICS)
     if args.clip_ahp:

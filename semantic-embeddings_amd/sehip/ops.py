@@ -15,6 +15,7 @@ from ._lib import (DTYPE_BF16, DTYPE_F32, METRIC_COSINE, METRIC_DOT, METRIC_EUCL
 __all__ = [
     "cosine_embedding_loss", "cosine_loss_forward", "cosine_loss_backward", "l2norm", "nn_accuracy", "labelembed_loss",
     "row_sqnorm", "normalize_rows_", "pairwise_dist", "rank_rows", "topk_rows", "topk_merge", "retrieve_topk",
+    "hierarchical_precision",
     "METRIC_COSINE", "METRIC_EUCLID", "METRIC_DOT",
 ]
 
@@ -330,3 +331,28 @@ def retrieve_topk(queries, gallery, k, metric=METRIC_COSINE, col_offset=0, sqq=N
                                  q, n, d, int(metric), int(col_offset), int(k), ptr(od), ptr(oi), ptr(ws), ws.numel(),
                                  stream_ptr()), "se_retrieve_topk")
     return od, oi
+
+
+def hierarchical_precision(rank, cls, qcls, qidx, wup, lcs, best_wup, best_lcs, ks, ahp_len=-1, want_ap=False, list_len=None):
+    """Per-query hierarchical precision metrics from device rankings (class_hierarchy.py:211-316).
+
+    rank [Q, >=L] int32, cls [N] int32, qcls [Q] int32, qidx [Q] int32 | None, wup / lcs [C, C] f64,
+    best_* [C, >=L] f64, ks [nk] int32.  Returns f64 [Q, 2 nk + 3]: P@k (WUP), P@k (LCS_HEIGHT), AHP (WUP), AHP (LCS_HEIGHT), AP."""
+    require_gpu(rank, cls, qcls, wup, lcs, best_wup, best_lcs, ks)
+    if rank.dtype != torch.int32 or rank.stride(1) != 1:
+        raise SehipError("rank must be int32 with contiguous rows")
+    for t, name in ((cls, "cls"), (qcls, "qcls"), (ks, "ks")):
+        if t.dtype != torch.int32 or not t.is_contiguous():
+            raise SehipError("%s must be contiguous int32" % name)
+    for t, name in ((wup, "wup"), (lcs, "lcs"), (best_wup, "best_wup"), (best_lcs, "best_lcs")):
+        if t.dtype != torch.float64 or t.dim() != 2 or t.stride(1) != 1:
+            raise SehipError("%s must be a float64 matrix with contiguous rows" % name)
+    Q = rank.shape[0]
+    L = rank.shape[1] if list_len is None else int(list_len)
+    C = wup.shape[0]
+    nk = ks.numel()
+    out = torch.zeros((Q, 2 * nk + 3), dtype=torch.float64, device=rank.device)
+    check(lib().se_hierarchical_precision(ptr(rank), rank.stride(0), Q, L, ptr(cls), ptr(qcls), ptr(qidx), ptr(wup), ptr(lcs), C,
+                                          ptr(best_wup), ptr(best_lcs), best_wup.stride(0), ptr(ks), nk, int(ahp_len), int(bool(want_ap)),
+                                          ptr(out), out.stride(0), stream_ptr()), "se_hierarchical_precision")
+    return out

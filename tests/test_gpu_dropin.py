@@ -113,3 +113,61 @@ def test_training_step_resnet110_fc_uses_hip_loss_and_learns():
     assert set(ev) == {"loss", "max_sim_acc"}
     feats = tr.predict(gen.test_sequence(32))
     assert feats.shape == (64, 100)
+
+
+def test_hierarchical_precision_device_matches_reference_values():
+    """se_hierarchical_precision + device rankings vs the values the REFERENCE's class_hierarchy produced on its own
+    rankings (tests/golden/hierarchy_cifar.npz), both branches, whole-list and clipped AHP, AP; per-query values also
+    agree with the host mirror (float64: 1e-10)."""
+    import tempfile
+    from class_hierarchy import ClassHierarchy
+    from oracle import retrieval_oracle as ro
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "hierarchy_cifar.npz"))
+    with tempfile.NamedTemporaryFile("w", suffix=".txt", delete=False) as f:
+        for p, c in g["edges"]:
+            f.write("%d %d\n" % (p, c))
+    h = ClassHierarchy.from_file(f.name, id_type=int)
+    os.unlink(f.name)
+    labels = g["labels"].tolist()
+    ks = g["ks"].tolist()
+    want = dict(zip(g["metric_names"].tolist(), g["metric_values"].tolist()))
+    for norm in (True, False):
+        _, rk = ro.canon_retrieval(g["features"], norm)
+        ret = {i: rk[i].tolist() for i in range(len(labels))}
+        for ahp in (True, 50):
+            avg, per_q = h.hierarchical_precision_device(g["features"].copy(), labels, ks, compute_ahp=ahp, compute_ap=True, normalize=norm)
+            for m, v in avg.items():
+                assert v == pytest.approx(want["%s|norm=%d|ahp=%s" % (m, norm, ahp)], rel=1e-10, abs=1e-10), (m, norm, ahp)
+            _, host_q = h.hierarchical_precision(ret, labels, ks, compute_ahp=ahp, compute_ap=True, all_ids=list(range(len(labels))))
+            for m in host_q:
+                a = np.array([per_q[m][i] for i in range(len(labels))])
+                b = np.array([host_q[m][i] for i in range(len(labels))])
+                assert np.abs(a - b).max() <= 1e-10, m
+
+
+def test_hierarchical_precision_device_multi_chunk_and_tiles():
+    """Lists longer than one 2048-rank chunk, several query tiles, clustered classes: device == host mirror."""
+    import tempfile
+    from class_hierarchy import ClassHierarchy
+    from oracle import retrieval_oracle as ro
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "hierarchy_cifar.npz"))
+    with tempfile.NamedTemporaryFile("w", suffix=".txt", delete=False) as f:
+        for p, c in g["edges"]:
+            f.write("%d %d\n" % (p, c))
+    h = ClassHierarchy.from_file(f.name, id_type=int)
+    os.unlink(f.name)
+    rng = np.random.default_rng(12)
+    n, d = 5000, 16
+    labels = rng.integers(0, 100, size=n).tolist()
+    centers = rng.standard_normal((100, d)).astype(np.float32)
+    feats = (centers[labels] + 0.7 * rng.standard_normal((n, d))).astype(np.float32)
+    ks = [1, 10, 50, 100, 250]
+    avg, per_q = h.hierarchical_precision_device(feats.copy(), labels, ks, compute_ahp=True, compute_ap=True, normalize=True, tile_rows=1536)
+    _, rk = ro.canon_retrieval(feats, True)
+    sample = list(range(0, n, 97))
+    ret = {i: rk[i].tolist() for i in sample}
+    _, host_q = h.hierarchical_precision(ret, labels, ks, compute_ahp=True, compute_ap=True)
+    for m in host_q:
+        a = np.array([per_q[m][i] for i in sample])
+        b = np.array([host_q[m][i] for i in sample])
+        assert np.abs(a - b).max() <= 1e-10, m

@@ -27,7 +27,7 @@ def timeit(fn, reps):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["pdist", "rank", "loss", "topk"])
+    ap.add_argument("what", choices=["pdist", "rank", "loss", "topk", "hprec"])
     ap.add_argument("--n", type=int, default=50000)
     ap.add_argument("--q", type=int, default=None)
     ap.add_argument("--d", type=int, default=100)
@@ -51,6 +51,24 @@ def main():
         rk = torch.empty((q, n), dtype=torch.int32, device="cuda")
         med, mn = timeit(lambda: sehip.rank_rows(pd, out=rk), args.reps)
         print("rank q=%d n=%d: median %.3f ms (min %.3f)  %.1f GB/s algorithmic, %.1f Mkeys/s" % (q, n, med, mn, 8.0 * q * n / med / 1e6, q * n / med / 1e3))
+    elif args.what == "hprec":
+        C = 100
+        rng = np.random.default_rng(1)
+        cls = torch.from_numpy(rng.integers(0, C, size=n).astype(np.int32)).cuda()
+        tab = rng.random((C, C)); tab = (tab + tab.T) / 2; np.fill_diagonal(tab, 1.0)
+        counts = np.bincount(cls.cpu().numpy(), minlength=C)
+        best = np.stack([np.cumsum(np.repeat(tab[c][np.argsort(-tab[c], kind="stable")], counts[np.argsort(-tab[c], kind="stable")])) for c in range(C)])
+        tab_d, best_d = torch.from_numpy(tab).cuda(), torch.from_numpy(best).cuda()
+        qq = min(q, 8192)
+        pd = sehip.pairwise_dist(x[:qq], x, metric=sehip.METRIC_COSINE)
+        rk = sehip.rank_rows(pd)
+        ks = torch.arange(1, 251, dtype=torch.int32, device="cuda")
+        qidx = torch.arange(qq, dtype=torch.int32, device="cuda")
+        for name, ahp in (("whole-list AHP + AP", 0), ("AHP@250, no AP", 250)):
+            med, mn = timeit(lambda: sehip.hierarchical_precision(rk, cls, cls[:qq].contiguous(), qidx, tab_d, tab_d, best_d, best_d, ks,
+                                                                  ahp_len=ahp, want_ap=(ahp == 0)), args.reps)
+            print("hprec %-22s q=%d n=%d: median %.3f ms (min %.3f)  %.1f GB/s of ranks, %.1f Mranks/s" %
+                  (name, qq, n, med, mn, 4.0 * qq * n / med / 1e6, qq * n / med / 1e3))
     elif args.what == "topk":
         pd = sehip.pairwise_dist(x[:q], x, metric=sehip.METRIC_COSINE)
         med, mn = timeit(lambda: sehip.topk_rows(pd, args.k), args.reps)
