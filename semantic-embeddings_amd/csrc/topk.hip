@@ -9,6 +9,8 @@
 // se_topk_merge: the k-way merge that follows the RCCL all-gather of per-shard lists: all
 //                parts*k candidates of a query are sorted in LDS on (key, global index).
 #include "se_common.h"
+#include <math.h>
+#include <stdlib.h>
 
 namespace se {
 
@@ -16,6 +18,7 @@ constexpr int TK_THREADS = 512;
 constexpr int TK_WAVES = TK_THREADS / WAVE;
 constexpr int TK_BITS = 11;
 constexpr int TK_NB = 1 << TK_BITS;
+constexpr int32_t TK_REDO = -1;   // out_i[row, 0] marker: row to be redone by the exact radix-select kernel
 
 __device__ __forceinline__ float key_to_float(uint32_t key)
 {
@@ -43,7 +46,7 @@ __device__ __forceinline__ void bitonic_sort_u64(uint64_t *v, int P, int nthread
 
 __global__ __launch_bounds__(TK_THREADS) void topk_rows_kernel(const float *__restrict__ pdist, int64_t ldp,
                                                                int64_t Q, int N, int64_t col_offset, int k, int P,
-                                                               float *__restrict__ out_d, int32_t *__restrict__ out_i)
+                                                               float *__restrict__ out_d, int32_t *__restrict__ out_i, int only_flagged)
 {
     extern __shared__ __attribute__((aligned(16))) uint64_t tk_lds64[];
     uint64_t *cand = tk_lds64;                          // [P]
@@ -59,6 +62,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_rows_kernel(const float *__re
 
     for (int64_t row = blockIdx.x; row < Q; row += gridDim.x) {
         const float *drow = pdist + row * ldp;
+        if (only_flagged && out_i[row * k] != TK_REDO) continue;   // repair pass behind topk_sample_kernel (uniform per workgroup)
 
         // ---------- radix select: find the canonical key of the k-th smallest ----------
         uint32_t prefix = 0, prefix_mask = 0;
@@ -152,6 +156,184 @@ __global__ __launch_bounds__(TK_THREADS) void topk_rows_kernel(const float *__re
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Register-blocked bitonic sort of P = TK_THREADS * PER values held PER per thread (value e = tid * PER + r):
+// partners closer than PER live in the same thread, closer than 64 * PER in the same wave (shuffle, no barrier);
+// only the log2(P / (64 PER))-deep far strides go through LDS.  A 2048-value sort needs 6 barrier stages
+// instead of the 66 of the all-LDS version above.
+template <typename T>
+__device__ __forceinline__ T shfl_xor_any(T v, int mask)
+{
+    if constexpr (sizeof(T) == 8) {
+        const uint32_t lo = (uint32_t)v, hi = (uint32_t)((uint64_t)v >> 32);
+        return (T)(((uint64_t)(uint32_t)__shfl_xor((int)hi, mask, 64) << 32) | (uint32_t)__shfl_xor((int)lo, mask, 64));
+    } else {
+        return (T)__shfl_xor((int)v, mask, 64);
+    }
+}
+
+template <typename T, int PER>
+__device__ __forceinline__ void blocked_bitonic_sort(T (&v)[PER], T *lds)
+{
+    constexpr int P = TK_THREADS * PER;
+    const int tid = threadIdx.x;
+#define TK_CE_REMOTE(O, R)                                                     \
+    {                                                                          \
+        const int e = tid * PER + (R);                                         \
+        const bool take_min = (((e & k) == 0) == ((e & j) == 0));              \
+        v[R] = take_min ? ((O) < v[R] ? (O) : v[R]) : ((O) > v[R] ? (O) : v[R]); \
+    }
+#pragma unroll 1
+    for (int k = 2; k <= P; k <<= 1) {
+        int j = k >> 1;
+#pragma unroll 1
+        for (; j >= 64 * PER; j >>= 1) {               // partner in another wave: through LDS
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < PER; r++) lds[tid * PER + r] = v[r];
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < PER; r++) {
+                const T o = lds[(tid * PER + r) ^ j];
+                TK_CE_REMOTE(o, r)
+            }
+        }
+#pragma unroll 1
+        for (; j >= PER; j >>= 1) {                    // partner thread in the same wave: shuffle, no barrier
+            const int lm = j / PER;
+#pragma unroll
+            for (int r = 0; r < PER; r++) {
+                const T o = shfl_xor_any(v[r], lm);
+                TK_CE_REMOTE(o, r)
+            }
+        }
+#pragma unroll
+        for (int jj = PER >> 1; jj > 0; jj >>= 1) {    // partner register of the same thread (static indices)
+            if (jj <= j) {
+#pragma unroll
+                for (int r = 0; r < PER; r++) {
+                    if ((r & jj) == 0) {
+                        const bool up = (((tid * PER + r) & k) == 0);
+                        const T a = v[r], b = v[r | jj];
+                        const bool sw = (a > b) == up;
+                        v[r] = sw ? b : a;
+                        v[r | jj] = sw ? a : b;
+                    }
+                }
+            }
+        }
+    }
+#undef TK_CE_REMOTE
+}
+
+// ------------------------------------------------------------------------------------------------
+// Sample-select variant (the fast path for long rows): the k smallest of N keys with ONE streaming read of
+// the row and almost no atomics.
+//   1. 2048 evenly spaced keys of the row are sorted in LDS; the sample at rank r(k, N) -- chosen 4 sigma above
+//      the k/N quantile -- is the pivot, so that   k <= #{key <= pivot} <= TK_CAP   with overwhelming probability;
+//   2. one coalesced pass over the row collects every (key, index) with key <= pivot (about 2 % of the row takes
+//      the one LDS atomic; the radix select above does 3 atomics per key on a handful of hot histogram bins);
+//   3. the candidates are sorted on the 64-bit (key, index) composite -- exactly the canonical order -- and the
+//      first k are written out.
+// A row whose candidate count misses [k, TK_CAP] (a huge tie group straddling rank k, or bad luck) is flagged
+// with out_i[row, 0] = TK_REDO and redone by the exact radix-select kernel launched right behind this one.
+constexpr int TK_SAMPLES = 2048;
+constexpr int TK_CAP = 8192;
+
+__device__ __forceinline__ void bitonic_sort_u32(uint32_t *v, int P, int nthreads)
+{
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            __syncthreads();
+            for (int t = threadIdx.x; t < P / 2; t += nthreads) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                const int l = i | j;
+                const bool up = ((i & k) == 0);
+                const uint32_t a = v[i], b = v[l];
+                if ((a > b) == up) { v[i] = b; v[l] = a; }
+            }
+        }
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(TK_THREADS, 4) void topk_sample_kernel(const float *__restrict__ pdist, int64_t ldp, int64_t Q, int N,
+                                                                 int64_t col_offset, int k, int pivot_rank,
+                                                                 float *__restrict__ out_d, int32_t *__restrict__ out_i)
+{
+    extern __shared__ __attribute__((aligned(16))) uint64_t ts_lds64[];
+    uint64_t *cand = ts_lds64;                                  // [TK_CAP]
+    uint32_t *smp = (uint32_t *)(ts_lds64 + TK_CAP);            // [TK_SAMPLES]
+    uint32_t *ctl = smp + TK_SAMPLES;                           // [2]
+    const int tid = threadIdx.x;
+    for (int64_t row = blockIdx.x; row < Q; row += gridDim.x) {
+        const float *drow = pdist + row * ldp;
+        __syncthreads();
+        {   // 2048 evenly spaced sample keys, 4 per thread, sorted in registers (+ 2 LDS stages); rank r is the pivot
+            uint32_t sv[TK_SAMPLES / TK_THREADS];
+#pragma unroll
+            for (int r = 0; r < TK_SAMPLES / TK_THREADS; r++)
+                sv[r] = canon_key(drow[(int64_t)(tid * (TK_SAMPLES / TK_THREADS) + r) * N / TK_SAMPLES]);
+            blocked_bitonic_sort<uint32_t, TK_SAMPLES / TK_THREADS>(sv, smp);
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < TK_SAMPLES / TK_THREADS; r++) smp[tid * (TK_SAMPLES / TK_THREADS) + r] = sv[r];
+            if (tid == 0) ctl[0] = 0;
+            __syncthreads();
+        }
+        const uint32_t pivot = smp[pivot_rank];
+        // ---- one pass: collect (key, index) with key <= pivot ----
+        // (16 coalesced loads in flight per thread: with 4 the pass is HBM-latency-bound, 25 round trips per row)
+        constexpr int TK_PF = 16;
+        for (int i0 = 0; i0 < N; i0 += TK_THREADS * TK_PF) {
+            uint32_t key[TK_PF];
+#pragma unroll
+            for (int e = 0; e < TK_PF; e++) {
+                const int i = i0 + e * TK_THREADS + tid;
+                key[e] = canon_key(drow[i < N ? i : N - 1]);
+            }
+#pragma unroll
+            for (int e = 0; e < TK_PF; e++) {
+                const int i = i0 + e * TK_THREADS + tid;
+                if (i < N && key[e] <= pivot) {
+                    const uint32_t slot = atomicAdd(&ctl[0], 1u);
+                    if (slot < TK_CAP) cand[slot] = ((uint64_t)key[e] << 32) | (uint32_t)i;
+                }
+            }
+        }
+        __syncthreads();
+        const uint32_t total = ctl[0];
+        if (total < (uint32_t)k || total > (uint32_t)TK_CAP) {      // uniform: hand the row to the exact kernel
+            if (tid == 0) out_i[row * k] = TK_REDO;
+            continue;
+        }
+        // sort the candidates on (key, index): registers + shuffles, padded with ~0 to TK_THREADS * PER
+#define TK_SORT_CAND(PER)                                                                     \
+    {                                                                                         \
+        uint64_t cv[PER];                                                                     \
+        _Pragma("unroll") for (int r = 0; r < PER; r++) {                                     \
+            const int e = tid * PER + r;                                                      \
+            cv[r] = (e < (int)total) ? cand[e] : ~0ull;                                       \
+        }                                                                                     \
+        blocked_bitonic_sort<uint64_t, PER>(cv, cand);                                        \
+        __syncthreads();                                                                      \
+        _Pragma("unroll") for (int r = 0; r < PER; r++) cand[tid * PER + r] = cv[r];          \
+        __syncthreads();                                                                      \
+    }
+        if (total <= TK_THREADS) TK_SORT_CAND(1)
+        else if (total <= 2 * TK_THREADS) TK_SORT_CAND(2)
+        else if (total <= 4 * TK_THREADS) TK_SORT_CAND(4)
+        else if (total <= 8 * TK_THREADS) TK_SORT_CAND(8)
+        else TK_SORT_CAND(16)
+#undef TK_SORT_CAND
+        for (int r = tid; r < k; r += TK_THREADS) {
+            const uint64_t c = cand[r];
+            out_d[row * k + r] = key_to_float((uint32_t)(c >> 32));
+            out_i[row * k + r] = (int32_t)(col_offset + (int64_t)(uint32_t)c);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void topk_merge_kernel(const float *__restrict__ d, const int32_t *__restrict__ idx,
                                                          int parts, int64_t Q, int k, int P,
                                                          float *__restrict__ out_d, int32_t *__restrict__ out_i)
@@ -194,8 +376,25 @@ extern "C" int se_topk_rows(const float *pdist, int64_t ldp, int64_t q, int64_t 
     const int P = next_pow2(k);
     const size_t lds = (size_t)P * 8 + (TK_NB + TK_WAVES + 1 + 4) * sizeof(uint32_t);
     const int64_t grid = q < 2048 ? q : 2048;
-    hipLaunchKernelGGL(topk_rows_kernel, dim3((unsigned)grid), dim3(TK_THREADS), lds, (hipStream_t)stream,
-                       pdist, ldp, q, (int)n, col_offset, k, P, out_d, out_i);
+    hipStream_t s = (hipStream_t)stream;
+    // sample-select fast path: pivot = sample of rank r, r - 4 sqrt(r) >= m = k S / N  (r = (2 + sqrt(4 + m))^2 + 4);
+    // taken when the 4-sigma upper bound of the candidate count fits the LDS candidate buffer
+    static const bool exact_only = getenv("SE_TOPK_EXACT") != nullptr;   // test / tuning aid
+    const double m = (double)k * TK_SAMPLES / (double)n;
+    const double rr = (2.0 + sqrt(4.0 + m)) * (2.0 + sqrt(4.0 + m)) + 4.0;
+    const int r = (int)ceil(rr);
+    const double upper = (rr + 4.0 * sqrt(rr) + 8.0) / TK_SAMPLES * (double)n;
+    int only_flagged = 0;
+    if (!exact_only && n >= 4 * TK_SAMPLES && r < TK_SAMPLES && upper <= (double)TK_CAP) {
+        const size_t lds2 = (size_t)TK_CAP * 8 + (TK_SAMPLES + 4) * sizeof(uint32_t);
+        SE_HIP_CHECK(hipFuncSetAttribute((const void *)topk_sample_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+        const int64_t grid2 = q < 1024 ? q : 1024;
+        hipLaunchKernelGGL(topk_sample_kernel, dim3((unsigned)grid2), dim3(TK_THREADS), lds2, s, pdist, ldp, q, (int)n, col_offset, k, r, out_d, out_i);
+        SE_LAUNCH_CHECK();
+        only_flagged = 1;
+    }
+    hipLaunchKernelGGL(topk_rows_kernel, dim3((unsigned)grid), dim3(TK_THREADS), lds, s,
+                       pdist, ldp, q, (int)n, col_offset, k, P, out_d, out_i, only_flagged);
     SE_LAUNCH_CHECK();
     return SE_OK;
 }

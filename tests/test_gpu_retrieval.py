@@ -195,6 +195,23 @@ def test_topk_rows_equals_head_of_full_ranking(sehip, q, n, k):
     assert np.array_equal(d.cpu().numpy(), wd)
 
 
+@pytest.mark.parametrize("n,k", [(8192, 1), (50000, 251), (50000, 2048), (20000, 100), (131072, 251)])
+def test_topk_sample_select_and_repair_pass(sehip, n, k):
+    """Long rows take the sample-select kernel; rows it cannot finish (all-equal row, a tie group of thousands
+    straddling rank k, NaN-heavy row) are flagged and redone by the exact radix-select kernel behind it.  Every
+    row must equal the head of the canonical full ranking."""
+    rng = np.random.default_rng(n + k)
+    pd = rng.standard_normal((6, n)).astype(np.float32)
+    pd[1] = 0.5                                                      # one value: n candidates > capacity -> repair
+    pd[2] = rng.integers(0, 3, size=n).astype(np.float32)            # three values: ties straddle rank k -> repair
+    pd[3, ::2] = np.nan                                              # half NaN (sorted last)
+    pd[4, : n // 2] = -np.abs(pd[4, : n // 2]) - 10.0                # low half far below the rest
+    d, i = sehip.topk_rows(dev(pd), k, col_offset=7)
+    wd, wi = ro.canon_topk_rows(pd, k, col_offset=7)
+    assert np.array_equal(i.cpu().numpy(), wi)
+    assert np.array_equal(d.cpu().numpy(), wd, equal_nan=True)
+
+
 def test_topk_rows_ties(sehip):
     pd = tie_heavy(30, 900, seed=3)
     pd[np.isnan(pd)] = 9.0
