@@ -95,6 +95,8 @@ class BucketedAllReduce(object):
 
     def _make_hook(self, idx):
         def hook(param):
+            if not self.enabled:      # graph mode: one eager all-reduce between the captured graphs instead
+                return
             b = self.bucket_of[idx]
             self.pending[b] -= 1
             if self.pending[b] == 0:
@@ -142,6 +144,7 @@ class Trainer(object):
         self.flat = FlatState(model, l2_of)
         self.reducer = BucketedAllReduce(self.flat, bucket_bytes)
         self.stop_training = False
+        self._graph = None
 
     # ---------------------------------------------------------------- one step
 
@@ -174,6 +177,8 @@ class Trainer(object):
         return total
 
     def train_step(self, X, y, logs):
+        if self._graph is not None:
+            return self._graph_step(X, y, logs)
         flat = self.flat
         flat.flat_g.zero_()
         outs = self._forward(X)
@@ -183,8 +188,83 @@ class Trainer(object):
         self.apply_update(scale)
         return loss
 
-    def apply_update(self, grad_scale=1.0):
-        """Keras-SGD update on the flat buffers (regulariser -> clip -> decayed lr -> momentum)."""
+    # ---------------------------------------------------------------- HIP-graph replay of the step
+
+    def enable_graphs(self, X, y, warmup=3):
+        """Capture the training step into two HIP graphs (``torch.cuda.CUDAGraph``): A = zero grads + forward + fused
+        loss/metric + backward, B = the whole-buffer SGD update; the RCCL all-reduce of the flat gradient buffer stays
+        an eager call between them (one message per step), so 1-GPU and N-GPU runs replay identical graphs.
+        A ResNet-110 step is ~1500 small launches and launch-bound in eager mode.  Batches must keep the shape of
+        ``(X, y)``.  Returns False (and stays eager) if the capture fails.
+
+        EXPERIMENTAL: on torch 2.10 + ROCm 7.0 the replayed backward of the ResNet backbones goes non-finite after a
+        few replays (reproduced with a pure-PyTorch loss and no HIP kernels of this package: tools/debug_graph.py), so
+        nothing enables this by default."""
+        if not X.is_cuda:
+            return False
+        ys = y if isinstance(y, (tuple, list)) else (y,)
+        try:
+            self._sX = X.clone()
+            self._sy = [t.clone() for t in ys]
+            self._lr_t = torch.full((), float(self.lr), dtype=torch.float32, device=X.device)
+            hooks_were = self.reducer.enabled
+            self.reducer.enabled = False          # no collectives inside the capture: all-reduce runs between the graphs
+            self._hooks_off = True
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(warmup):           # MIOpen / hipBLASLt algorithm searches must happen before the capture
+                    self._eager_core(self._sX, self._sy if len(self._sy) > 1 else self._sy[0], {})
+                    self._allreduce_flat(hooks_were)
+                    self.apply_update(1.0 / self.world if hooks_were else 1.0, lr_tensor=self._lr_t)
+            torch.cuda.current_stream().wait_stream(side)
+            self._g_logs = {}
+            ga = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(ga):
+                self._g_loss = self._eager_core(self._sX, self._sy if len(self._sy) > 1 else self._sy[0], self._g_logs)
+            gb = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gb):
+                self.apply_update(1.0 / self.world if hooks_were else 1.0, lr_tensor=self._lr_t, count=False)
+            self._graph = (ga, gb)
+            self._graph_allreduce = hooks_were
+            return True
+        except Exception as e:                    # stay eager, loudly
+            print('[engine] HIP-graph capture failed, staying eager: %s: %s' % (type(e).__name__, e), flush=True)
+            self._graph = None
+            self.reducer.enabled = self.world > 1
+            self._hooks_off = False
+            return False
+
+    def _eager_core(self, X, y, logs):
+        self.flat.flat_g.zero_()
+        outs = self._forward(X)
+        loss = self._loss_and_metrics(outs, y, logs)
+        loss.backward()
+        return loss.detach()
+
+    def _allreduce_flat(self, on):
+        if on and self.world > 1:
+            dist.all_reduce(self.flat.flat_g, op=dist.ReduceOp.SUM)
+
+    def _graph_step(self, X, y, logs):
+        ys = y if isinstance(y, (tuple, list)) else (y,)
+        self._sX.copy_(X, non_blocking=True)
+        for dst, src in zip(self._sy, ys):
+            dst.copy_(src, non_blocking=True)
+        lr = self.lr / (1.0 + self.decay * self.iterations) if self.decay > 0 else self.lr
+        self._lr_t.fill_(float(lr))
+        ga, gb = self._graph
+        ga.replay()
+        self._allreduce_flat(self._graph_allreduce)
+        gb.replay()
+        self.iterations += 1
+        for k, v in self._g_logs.items():      # static device scalars written by graph A
+            logs[k] = logs.get(k, 0) + v.clone()
+        return self._g_loss
+
+    def apply_update(self, grad_scale=1.0, lr_tensor=None, count=True):
+        """Keras-SGD update on the flat buffers (regulariser -> clip -> decayed lr -> momentum).  With ``lr_tensor``
+        (a device scalar) the learning rate is read on the device, so the launches can be captured in a HIP graph."""
         flat = self.flat
         g = flat.flat_g
         if grad_scale != 1.0:
@@ -194,14 +274,23 @@ class Trainer(object):
         if self.clipnorm:
             norm = torch.linalg.vector_norm(g)
             g.mul_(torch.clamp(self.clipnorm / (norm + 1e-12), max=1.0))   # stays on the device
-        lr = self.lr / (1.0 + self.decay * self.iterations) if self.decay > 0 else self.lr
         v = flat.flat_v
-        v.mul_(self.momentum).add_(g, alpha=-lr)
-        if self.nesterov:
-            flat.flat_p.add_(v, alpha=self.momentum).add_(g, alpha=-lr)
+        if lr_tensor is not None:
+            step = g * lr_tensor                      # lr lives on the device (graph replay)
+            v.mul_(self.momentum).sub_(step)
+            if self.nesterov:
+                flat.flat_p.add_(v, alpha=self.momentum).sub_(step)
+            else:
+                flat.flat_p.add_(v)
         else:
-            flat.flat_p.add_(v)
-        self.iterations += 1
+            lr = self.lr / (1.0 + self.decay * self.iterations) if self.decay > 0 else self.lr
+            v.mul_(self.momentum).add_(g, alpha=-lr)
+            if self.nesterov:
+                flat.flat_p.add_(v, alpha=self.momentum).add_(g, alpha=-lr)
+            else:
+                flat.flat_p.add_(v)
+        if count:
+            self.iterations += 1
 
     # ---------------------------------------------------------------- loops
 
