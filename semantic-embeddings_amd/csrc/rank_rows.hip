@@ -360,41 +360,78 @@ constexpr int RR_HW_BITS = 11;   // digit width of the hardware-ordered variant:
 // Counters are 16 bits wide, two per LDS word (8 waves x 2048 digits x 2 B = 32 KB next to the 100 KB exchange
 // buffer): a wave holds at most 64 x 104 keys and a destination is < 53,248, so neither half can carry into the
 // other.  The returning add is done on the word with the increment shifted into the digit's half.
-template <int ITEMS, int V, int S0, int I = 0>
+// PEEL (used for the most significant digit): the lanes that share lane 0's digit are ranked by one ballot and ONE
+// add of the group size issued by lane 0; only the other lanes issue their own returning add.  The top digit of
+// real distance rows is heavily skewed -- all-positive Euclidean distances put every key of a wave step on one
+// counter, i.e. a 64-way same-address conflict per instruction (16.9 ms instead of 11 ms on the CLI-default branch).
+template <int ITEMS, bool PEEL, int V, int S0, int I = 0>
 struct RRRankHWFinish {
-    static __device__ __forceinline__ void run(uint32_t (&ir)[ITEMS], uint32_t (&key)[ITEMS], uint32_t (&r)[V], uint32_t (&sh)[V])
+    static __device__ __forceinline__ void run(uint32_t (&ir)[ITEMS], uint32_t (&key)[ITEMS], uint32_t (&r)[V], uint32_t (&sh)[V],
+                                               uint32_t (&grp)[V])
     {
         lds_wait_le<V - 1 - I>(r[I]);
-        ir[S0 + I] = (ir[S0 + I] & 0xFFFF0000u) | ((r[I] >> sh[I]) & 0xFFFFu);
+        uint32_t rank = (r[I] >> sh[I]) & 0xFFFFu;
+        if constexpr (PEEL) {
+            const uint32_t lead = (uint32_t)__builtin_amdgcn_readfirstlane((int)r[I]);   // lane 0's counter word before its add
+            const uint32_t own = (grp[I] != 0xFFFFFFFFu) ? lead : r[I];                     // group members use lane 0's word (same digit => same half)
+            rank = ((own >> sh[I]) & 0xFFFFu) + (grp[I] != 0xFFFFFFFFu ? grp[I] : 0u);
+        }
+        ir[S0 + I] = (ir[S0 + I] & 0xFFFF0000u) | rank;
         opaque(ir[S0 + I]);
         opaque(key[S0 + I]);
-        if constexpr (I + 1 < V) RRRankHWFinish<ITEMS, V, S0, I + 1>::run(ir, key, r, sh);
+        if constexpr (I + 1 < V) RRRankHWFinish<ITEMS, PEEL, V, S0, I + 1>::run(ir, key, r, sh, grp);
     }
 };
-template <int ITEMS, int S0 = 0>
+template <int ITEMS, bool PEEL, int S0 = 0>
 struct RRRankHW {
-    static __device__ __forceinline__ void run(uint32_t (&ir)[ITEMS], uint32_t (&key)[ITEMS], int shift, uint32_t dmask, uint32_t cb)
+    // `peel` is wave-uniform (one code instance for all passes: two instances of this unrolled body make hipcc spill)
+    static __device__ __forceinline__ void run(uint32_t (&ir)[ITEMS], uint32_t (&key)[ITEMS], int shift, uint32_t dmask, uint32_t cb, int lane,
+                                               bool peel)
     {
         constexpr int V = (ITEMS - S0 < RR_GH) ? (ITEMS - S0) : RR_GH;
-        uint32_t r[V], sh[V];
+        uint32_t r[V], sh[V], grp[V];
 #pragma unroll
         for (int g = 0; g < V; g++) {
             const uint32_t d = (key[S0 + g] >> shift) & dmask;
             sh[g] = (d & 1u) << 4;
-            const uint32_t ca = cb + ((d << 1) & ~3u), inc = 1u << sh[g];
-            asm volatile("ds_add_rtn_u32 %0, %1, %2" : "=v"(r[g]) : "v"(ca), "v"(inc) : "memory");
+            const uint32_t ca = cb + ((d << 1) & ~3u);
+            uint32_t inc = 1u << sh[g];
+            grp[g] = 0xFFFFFFFFu;
+            if constexpr (PEEL) {
+                uint64_t m = 0;                      // lanes sharing lane 0's digit (most significant pass only)
+                if (peel) {                          // wave-uniform branch: the other passes skip the group bookkeeping
+                    const bool in = (d == (uint32_t)__builtin_amdgcn_readfirstlane((int)d));
+                    m = __ballot(in);
+                    if (in) grp[g] = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    if (lane == 0) inc = (uint32_t)__popcll(m) << sh[g];
+                }
+                // Only lane 0 and the lanes outside its group issue the add.  The exec mask is narrowed INSIDE the asm
+                // statement: a C++ `if` around an asynchronous DS return lets hipcc copy the (not yet landed) result
+                // register at the join.  Lane 0 always takes part: exactly one DS operation per step for the wait counts.
+                const uint64_t part = ~m | 1ull;
+                uint64_t saved;
+                r[g] = 0;
+                asm volatile("s_and_saveexec_b64 %0, %4\n\tds_add_rtn_u32 %1, %2, %3\n\ts_mov_b64 exec, %0"
+                             : "=&s"(saved), "+v"(r[g])
+                             : "v"(ca), "v"(inc), "s"(part)
+                             : "memory");
+            } else {
+                asm volatile("ds_add_rtn_u32 %0, %1, %2" : "=v"(r[g]) : "v"(ca), "v"(inc) : "memory");
+            }
         }
-        RRRankHWFinish<ITEMS, V, S0>::run(ir, key, r, sh);
+        RRRankHWFinish<ITEMS, PEEL, V, S0>::run(ir, key, r, sh, grp);
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (S0 + V < ITEMS) RRRankHW<ITEMS, S0 + V>::run(ir, key, shift, dmask, cb);
+        if constexpr (S0 + V < ITEMS) RRRankHW<ITEMS, PEEL, S0 + V>::run(ir, key, shift, dmask, cb, lane, peel);
     }
 };
 
-template <int ITEMS, bool PROF, bool HWORD>
+template <int ITEMS, bool PROF, bool HWORD, bool PEEL>
 __global__ __launch_bounds__(RR_THREADS, 2) void rank_rows_reg_kernel(const float *__restrict__ pdist, int64_t ldp, int64_t Q,
                                                                     int N, void *rank, int64_t ldr, int idx64, int vec_ok,
-                                                                    unsigned long long *prof)
+                                                                    unsigned long long *prof, const uint32_t *skew_flag)
 {
+    // two launches per call when the detector is used: the variant that does not match the flag leaves at once
+    if (skew_flag && ((*skew_flag != 0) != PEEL)) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char rr_raw[];
     constexpr int BITS = HWORD ? RR_HW_BITS : 8;                        // digit width
     constexpr int NB = 1 << BITS;
@@ -450,7 +487,7 @@ __global__ __launch_bounds__(RR_THREADS, 2) void rank_rows_reg_kernel(const floa
             // ---- R: stable rank inside the wave ----
 #pragma unroll
             for (int j = 0; j < CNT_WORDS / WAVE; j++) mycnt[j * WAVE + lane] = 0;
-            if constexpr (HWORD) RRRankHW<ITEMS>::run(ir, key, shift, dmask, cb);
+            if constexpr (HWORD) RRRankHW<ITEMS, PEEL>::run(ir, key, shift, dmask, cb, lane, p == NPASS - 1);
             else RRRank<ITEMS>::run(ir, key, shift, lane, cb);
             lds_wait();
             RR_T(1)
@@ -607,16 +644,45 @@ static bool rank_use_tiled(int64_t n)
     return force || n > RR_MAX_N;
 }
 
-template <int ITEMS>
-static int launch_rank_reg(const float *pdist, int64_t ldp, int64_t q, int n, void *rank, int idx64, int64_t ldr, bool hw, hipStream_t s)
+// Skew detector for the hardware-ordered variant: do the keys share their most significant 10-bit digit (e.g.
+// all-positive Euclidean distances: every lane of a wave step would hit ONE or two counters)?  Histogram of that
+// digit over 3 rows x 1024 evenly spaced columns; flag = 1 when one value holds >= 30 % of them.  The two kernel variants launched
+// behind it read the flag and the one it does not select returns immediately -- no host round trip.
+__global__ __launch_bounds__(256) void rank_skew_detect_kernel(const float *__restrict__ pdist, int64_t ldp, int64_t Q, int N,
+                                                               uint32_t *__restrict__ flag)
 {
-    const size_t cnt_words = hw ? (size_t)(1 << RR_HW_BITS) / 2 : (size_t)RK_NB;   // per wave (packed 16-bit vs 32-bit counters)
+    constexpr int NBIN = 1 << (32 - 2 * RR_HW_BITS);   // values of the most significant digit (1024)
+    __shared__ uint32_t hist[NBIN];
+    __shared__ uint32_t best;
+    for (int i = threadIdx.x; i < NBIN; i += 256) hist[i] = 0;
+    if (threadIdx.x == 0) best = 0;
+    __syncthreads();
+    const int shift = 2 * RR_HW_BITS;                  // first bit of the most significant digit (22)
+    const int cols = N < 1024 ? N : 1024;
+    for (int r = 0; r < 3; r++) {
+        const int64_t row = (r == 0) ? 0 : (r == 1 ? Q / 2 : Q - 1);
+        const float *drow = pdist + row * ldp;
+        for (int i = threadIdx.x; i < cols; i += 256) atomicAdd(&hist[canon_key(drow[(int64_t)i * N / cols]) >> shift], 1u);
+    }
+    __syncthreads();
+    uint32_t mine = 0;
+    for (int i = threadIdx.x; i < NBIN; i += 256) mine = hist[i] > mine ? hist[i] : mine;
+    atomicMax(&best, mine);
+    __syncthreads();
+    // peeling pays from roughly a 30 % share of one digit (two-valued Euclidean rows: ~50 %; mixed-sign cosine rows: ~10 %)
+    if (threadIdx.x == 0) *flag = (10u * best >= 3u * 3u * (uint32_t)cols) ? 1u : 0u;
+}
+
+template <int ITEMS, bool HW, bool PEEL>
+static int launch_rank_reg_variant(const float *pdist, int64_t ldp, int64_t q, int n, void *rank, int idx64, int64_t ldr,
+                                   const uint32_t *skew_flag, hipStream_t s)
+{
+    const size_t cnt_words = HW ? (size_t)(1 << RR_HW_BITS) / 2 : (size_t)RK_NB;   // per wave (packed 16-bit vs 32-bit counters)
     const size_t lds = (RR_WAVES * cnt_words + 16) * sizeof(uint32_t) + (size_t)RR_THREADS * ITEMS * sizeof(uint16_t);
     static const bool profile = getenv("SE_RR_PROFILE") != nullptr;   // tuning aid only: allocates, synchronises, prints
-    auto kern = hw ? (profile ? rank_rows_reg_kernel<ITEMS, (ITEMS == 98), true> : rank_rows_reg_kernel<ITEMS, false, true>)
-                   : (profile ? rank_rows_reg_kernel<ITEMS, (ITEMS == 98), false> : rank_rows_reg_kernel<ITEMS, false, false>);
-    static int per_cu[2] = {0, 0}, cus = 0;   // per instantiation, [hw]
-    if (per_cu[hw] == 0) {
+    auto kern = profile ? rank_rows_reg_kernel<ITEMS, (ITEMS == 98), HW, PEEL> : rank_rows_reg_kernel<ITEMS, false, HW, PEEL>;
+    static int per_cu = 0, cus = 0;   // per instantiation
+    if (per_cu == 0) {
         SE_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         int dev = 0, occ = 0;
         hipDeviceProp_t prop;
@@ -624,9 +690,9 @@ static int launch_rank_reg(const float *pdist, int64_t ldp, int64_t q, int n, vo
         SE_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
         SE_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)kern, RR_THREADS, lds));
         cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-        per_cu[hw] = occ > 0 ? occ : 1;
+        per_cu = occ > 0 ? occ : 1;
     }
-    int64_t grid = (int64_t)cus * per_cu[hw];
+    int64_t grid = (int64_t)cus * per_cu;
     if (grid > q) grid = q;
     const size_t esz = idx64 ? 8 : 4;
     const int vec_ok = ((((uintptr_t)rank) & 15) == 0) && ((ldr * esz) % 16 == 0);
@@ -635,7 +701,7 @@ static int launch_rank_reg(const float *pdist, int64_t ldp, int64_t q, int n, vo
         SE_HIP_CHECK(hipMalloc((void **)&prof, 8 * sizeof(unsigned long long)));
         SE_HIP_CHECK(hipMemsetAsync(prof, 0, 8 * sizeof(unsigned long long), s));
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(RR_THREADS), lds, s, pdist, ldp, q, n, rank, ldr, idx64, vec_ok, prof);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(RR_THREADS), lds, s, pdist, ldp, q, n, rank, ldr, idx64, vec_ok, prof, skew_flag);
     SE_LAUNCH_CHECK();
     if (prof) {
         unsigned long long h[8];
@@ -645,11 +711,33 @@ static int launch_rank_reg(const float *pdist, int64_t ldp, int64_t q, int n, vo
         static const char *names[8] = {"load", "rank", "scan", "dest", "idx-write", "idx-read", "key-exchange", "write-out"};
         double tot = 0;
         for (int i = 0; i < 8; i++) tot += (double)h[i];
-        fprintf(stderr, "[se_rank_rows profile] ITEMS=%d grid=%lld:", ITEMS, (long long)grid);
-        for (int i = 0; i < 8; i++) fprintf(stderr, " %s %.1f%%", names[i], 100.0 * (double)h[i] / tot);
-        fprintf(stderr, "  (%.0f cycles per row)\n", tot / (double)q);
+        if (tot > 0) {
+            fprintf(stderr, "[se_rank_rows profile] ITEMS=%d hw=%d peel=%d grid=%lld:", ITEMS, (int)HW, (int)PEEL, (long long)grid);
+            for (int i = 0; i < 8; i++) fprintf(stderr, " %s %.1f%%", names[i], 100.0 * (double)h[i] / tot);
+            fprintf(stderr, "  (%.0f cycles per row)\n", tot / (double)q);
+        }
     }
     return SE_OK;
+}
+
+// hw: hardware-ordered variant allowed (capability probe passed).  scratch: >= 256 bytes of caller workspace or NULL;
+// with scratch the skew detector picks between the plain and the group-peeling hardware-ordered kernels.
+template <int ITEMS>
+static int launch_rank_reg(const float *pdist, int64_t ldp, int64_t q, int n, void *rank, int idx64, int64_t ldr, bool hw, void *scratch,
+                           hipStream_t s)
+{
+    if (!hw) return launch_rank_reg_variant<ITEMS, false, false>(pdist, ldp, q, n, rank, idx64, ldr, nullptr, s);
+    static const char *force = getenv("SE_RANK_PEEL");   // tuning aid: "0" / "1" pins the variant
+    if (force || !scratch) {
+        if (force && force[0] == '1') return launch_rank_reg_variant<ITEMS, true, true>(pdist, ldp, q, n, rank, idx64, ldr, nullptr, s);
+        return launch_rank_reg_variant<ITEMS, true, false>(pdist, ldp, q, n, rank, idx64, ldr, nullptr, s);
+    }
+    uint32_t *flag = (uint32_t *)scratch + 16;   // (words 0-1 belong to the capability probe)
+    hipLaunchKernelGGL(rank_skew_detect_kernel, dim3(1), dim3(256), 0, s, pdist, ldp, q, n, flag);
+    SE_LAUNCH_CHECK();
+    int rc = launch_rank_reg_variant<ITEMS, true, false>(pdist, ldp, q, n, rank, idx64, ldr, flag, s);
+    if (rc != SE_OK) return rc;
+    return launch_rank_reg_variant<ITEMS, true, true>(pdist, ldp, q, n, rank, idx64, ldr, flag, s);
 }
 
 // ---- capability probe for the hardware-ordered ranking --------------------------------------------------
@@ -726,7 +814,8 @@ extern "C" int se_rank_rows(const float *pdist, int64_t ldp, int64_t q, int64_t 
     if (!rank_use_tiled(n)) {
         const int items = (int)((n + RR_THREADS - 1) / RR_THREADS);
         const bool hw = rank_hw_order_ok(workspace, workspace_bytes, s) != 0;
-#define SE_RR_CASE(I) if (items <= I) return launch_rank_reg<I>(pdist, ldp, q, (int)n, rank, idx64, ldr, hw, s);
+        void *scratch = (workspace && workspace_bytes >= 256) ? workspace : nullptr;
+#define SE_RR_CASE(I) if (items <= I) return launch_rank_reg<I>(pdist, ldp, q, (int)n, rank, idx64, ldr, hw, scratch, s);
         SE_RR_CASE(2) SE_RR_CASE(8) SE_RR_CASE(20) SE_RR_CASE(40) SE_RR_CASE(64) SE_RR_CASE(80) SE_RR_CASE(98) SE_RR_CASE(104)
 #undef SE_RR_CASE
     }

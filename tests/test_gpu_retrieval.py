@@ -142,6 +142,23 @@ def test_rank_rows_register_kernel_boundaries(sehip, n):
     assert np.array_equal(got, ro.canon_rank_rows(pd))
 
 
+@pytest.mark.parametrize("n", [700, 4097, 50000])
+def test_rank_rows_skewed_top_digit_rows(sehip, n):
+    """All-positive (Euclidean-like) rows put every key on one counter of the most significant digit: the skew
+    detector routes the call to the group-peeling kernel; rows it sampled vs rows it did not may differ in sign mix."""
+    rng = np.random.default_rng(n)
+    pd = (200.0 + 20.0 * rng.standard_normal((7, n))).astype(np.float32)     # detector rows 0, Q/2, Q-1: skewed
+    pd[1] = rng.standard_normal(n).astype(np.float32)                          # a mixed-sign row inside a "skewed" call
+    pd[2, ::5] = pd[2, 0]                                                      # ties
+    pd[4] = 3.0                                                                # one value
+    got = sehip.rank_rows(dev(pd)).cpu().numpy()
+    assert np.array_equal(got, ro.canon_rank_rows(pd))
+    pd2 = rng.standard_normal((5, n)).astype(np.float32)                      # detector says "not skewed" ...
+    pd2[2] = np.abs(pd2[2]) + 100.0                                            # ... but one row is
+    got2 = sehip.rank_rows(dev(pd2)).cpu().numpy()
+    assert np.array_equal(got2, ro.canon_rank_rows(pd2))
+
+
 def test_rank_rows_strided_and_unaligned_output(sehip):
     """Row pitches that are not multiples of 16 bytes (scalar write-out) and a strided input."""
     pdw = gauss(6, 3001, seed=5)
