@@ -1,5 +1,9 @@
 #!/bin/bash
 set -u
-OUT=gpurun_out/s7; mkdir -p $OUT; export TMPDIR=/tmp
-( timeout 900 python -m pytest tests/test_gpu_retrieval.py -m gpu -q -x -k "rank or golden or full_size" ) 2>&1 | tail -2
-for m in cosine euclid; do timeout 300 python bench.py --steps 5 --warmup 1 --metric $m --no-train --no-cpu-baseline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$m step ms', d['ms_per_step'], {k:v['ms'] for k,v in d['kernels'].items()})"; done | tee $OUT/rank_peel.log
+OUT=gpurun_out/s2; mkdir -p $OUT; export TMPDIR=/tmp
+( timeout 900 python -m pytest tests/test_gpu_retrieval.py tests/test_gpu_dropin.py -q -x -k "topk or retrieve or sharded" ) 2>&1 | tail -4
+timeout 300 python tools/bench_kernels.py topk 2>&1 | grep -v amdgpu | tee $OUT/topk.log
+SE_TOPK_STREAM=1 timeout 300 python tools/bench_kernels.py topk 2>&1 | grep -v amdgpu | tee -a $OUT/topk.log
+timeout 300 python tools/bench_kernels.py topk --k 10 2>&1 | grep -v amdgpu | tee -a $OUT/topk.log
+timeout 300 python tools/bench_kernels.py topk --k 1000 2>&1 | grep -v amdgpu | tee -a $OUT/topk.log
+timeout 300 python tools/bench_kernels.py topk --n 10000 2>&1 | grep -v amdgpu | tee -a $OUT/topk.log
