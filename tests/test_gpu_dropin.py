@@ -171,3 +171,36 @@ def test_hierarchical_precision_device_multi_chunk_and_tiles():
         a = np.array([per_q[m][i] for i in sample])
         b = np.array([host_q[m][i] for i in sample])
         assert np.abs(a - b).max() <= 1e-10, m
+
+
+def test_evaluate_retrieval_cli_end_to_end(tmp_path, capsys):
+    """evaluate_retrieval.main with the reference's flags: feature pickle ({'feat': {id: vec}}) + hierarchy file +
+    a synthetic dataset's test labels -> table of metrics; values equal the host mirror fed with oracle rankings."""
+    import evaluate_retrieval as er
+    from class_hierarchy import ClassHierarchy
+    from datasets import get_data_generator
+    g = np.load(os.path.join(GOLDEN, "hierarchy_cifar.npz"))
+    hpath = tmp_path / "cifar.parent-child.txt"
+    with open(hpath, "w") as f:
+        for p, c in g["edges"]:
+            f.write("%d %d\n" % (p, c))
+    ds = "synthetic:100x8x64x300"
+    gen = get_data_generator(ds, None)
+    labels = list(gen.labels_test)
+    rng = np.random.default_rng(4)
+    centers = rng.standard_normal((100, 24)).astype(np.float32)
+    feats = (centers[labels] + 0.8 * rng.standard_normal((len(labels), 24))).astype(np.float32)
+    dump = tmp_path / "feat.pickle"
+    with open(dump, "wb") as f:
+        pickle.dump({"feat": {i: feats[i] for i in range(len(labels))}}, f)
+    csv = tmp_path / "perf.csv"
+    perf = er.main(["--dataset", ds, "--data_root", str(tmp_path), "--hierarchy", str(hpath), "--feat", str(dump), "--label", "run", "--norm", "yes",
+                    "--plot_max", "0", "--csv", str(csv)])
+    out = capsys.readouterr().out
+    assert "AHP (WUP)" in out and os.path.exists(csv)
+    h = ClassHierarchy.from_file(str(hpath), id_type=int)
+    _, rk = ro.canon_retrieval(feats, True)
+    want, _ = h.hierarchical_precision({i: rk[i].tolist() for i in range(len(labels))}, labels, [1, 10, 50, 100], compute_ahp=True,
+                                       compute_ap=True, all_ids=list(range(len(labels))))
+    for m, v in want.items():
+        assert perf["run"][m] == pytest.approx(v, rel=1e-10, abs=1e-10), m
