@@ -268,7 +268,7 @@ __global__ __launch_bounds__(PD_THREADS, 2 * PD_WGS_PER_CU) void pdist_kernel(
     bool first_kb = true;
 
     // tuning aid (SE_PD_PROFILE=1): shader-clock cycles per phase of every workgroup's wave 0
-    uint64_t t_acc[6] = {0, 0, 0, 0, 0, 0}, t_last = prof ? __builtin_amdgcn_s_memtime() : 0;
+    uint64_t t_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_last = prof ? __builtin_amdgcn_s_memtime() : 0;
 #define PD_T(i) if (prof) { const uint64_t now = __builtin_amdgcn_s_memtime(); t_acc[i] += now - t_last; t_last = now; }
     const int64_t total = my_tiles * nchunks;
 #pragma unroll 1
@@ -374,6 +374,7 @@ __global__ __launch_bounds__(PD_THREADS, 2 * PD_WGS_PER_CU) void pdist_kernel(
 #pragma unroll
                 for (int h = 0; h < PD_BM / PD_SR; h++) {
                     __syncthreads();   // operands of the last chunk / the previous stage contents are no longer needed
+                    PD_T(6)
                     // tile rows [h SR, (h+1) SR) -> stage[row][col]: per instruction lanes 0-31 fill 32 consecutive floats of one row
                     if ((wm * 32) / PD_SR == h) {
 #pragma unroll
@@ -382,9 +383,12 @@ __global__ __launch_bounds__(PD_THREADS, 2 * PD_WGS_PER_CU) void pdist_kernel(
                             for (int r = 0; r < 16; r++)
                                 smem[(lr0 - h * PD_SR + (r & 3) + 8 * (r >> 2)) * PD_SP + wn * 64 + j * 32 + col] = PD_VAL(j, r);
                     }
+                    PD_T(7)
                     __syncthreads();
+                    PD_T(8)
                     pd_stream_rows(smem, out + ((cur_m0 + h * PD_SR) * (int64_t)ldo + cur_n0), ldo, rows_here - h * PD_SR, cols_here, fast, nt,
                                    flags & PDF_NO_GSTORE);
+                    PD_T(9)
                 }
                 if (mirror) {
 #pragma unroll
@@ -392,6 +396,7 @@ __global__ __launch_bounds__(PD_THREADS, 2 * PD_WGS_PER_CU) void pdist_kernel(
                         // transposed tile rows (= tile columns) [h SR, (h+1) SR) -> stage[col][row]: a lane owns 4 consecutive
                         // rows of its column = 16 bytes
                         __syncthreads();
+                        PD_T(6)
                         if ((wn * 64) / PD_SR == h) {
 #pragma unroll
                             for (int j = 0; j < 2; j++)
@@ -400,9 +405,12 @@ __global__ __launch_bounds__(PD_THREADS, 2 * PD_WGS_PER_CU) void pdist_kernel(
                                     *(float4 *)&smem[(wn * 64 - h * PD_SR + j * 32 + col) * PD_SP + lr0 + 8 * g] =
                                         make_float4(PD_VAL(j, 4 * g), PD_VAL(j, 4 * g + 1), PD_VAL(j, 4 * g + 2), PD_VAL(j, 4 * g + 3));
                         }
+                        PD_T(7)
                         __syncthreads();
+                        PD_T(8)
                         pd_stream_rows(smem, out + ((cur_n0 + h * PD_SR) * (int64_t)ldo + cur_m0), ldo, cols_here - h * PD_SR, rows_here, fast, nt,
                                        flags & PDF_NO_GSTORE);
+                        PD_T(9)
                     }
                 }
                 // (the barrier that opens the next chunk orders these LDS reads before the operands overwrite the stage)
@@ -417,7 +425,7 @@ __global__ __launch_bounds__(PD_THREADS, 2 * PD_WGS_PER_CU) void pdist_kernel(
         }
     }
     if (prof && threadIdx.x == 0)
-        for (int i = 0; i < 6; i++) atomicAdd(&prof[i], (unsigned long long)t_acc[i]);
+        for (int i = 0; i < 12; i++) atomicAdd(&prof[i], (unsigned long long)t_acc[i]);
 #undef PD_T
 #undef PD_FETCH
 }
@@ -459,22 +467,23 @@ static int launch_pdist3(const float *a, int64_t lda, const float *b, int64_t ld
     static const bool profile = getenv("SE_PD_PROFILE") != nullptr;   // tuning aid only: allocates, synchronises, prints
     unsigned long long *prof = nullptr;
     if (profile) {
-        SE_HIP_CHECK(hipMalloc((void **)&prof, 6 * sizeof(unsigned long long)));
-        SE_HIP_CHECK(hipMemsetAsync(prof, 0, 6 * sizeof(unsigned long long), s));
+        SE_HIP_CHECK(hipMalloc((void **)&prof, 12 * sizeof(unsigned long long)));
+        SE_HIP_CHECK(hipMemsetAsync(prof, 0, 12 * sizeof(unsigned long long), s));
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(PD_THREADS), lds, s, a, (uint32_t)lda, b, (uint32_t)ldb, sqa, sqb, q, n,
                        d, kbs, nchunks, out, (uint32_t)ldo, tiles_m, tiles_n, ntiles, flags, prof);
     SE_LAUNCH_CHECK();
     if (profile) {
-        unsigned long long h[6];
+        unsigned long long h[12];
         SE_HIP_CHECK(hipStreamSynchronize(s));
         SE_HIP_CHECK(hipMemcpy(h, prof, sizeof(h), hipMemcpyDeviceToHost));
         SE_HIP_CHECK(hipFree(prof));
-        static const char *names[6] = {"wait-barrier", "stage-operands", "barrier", "prefetch-issue", "mfma", "epilogue"};
+        static const char *names[12] = {"wait-barrier", "stage-operands", "barrier", "prefetch-issue", "mfma", "epilogue-rest",
+                                        "epi-barrier-in", "epi-stage-write", "epi-barrier", "epi-stream-out", "-", "-"};
         double tot = 0;
-        for (int i = 0; i < 6; i++) tot += (double)h[i];
+        for (int i = 0; i < 12; i++) tot += (double)h[i];
         fprintf(stderr, "[se_pairwise_dist profile] sym=%d grid=%lld tiles=%lld:", (int)SYM, (long long)grid, (long long)ntiles);
-        for (int i = 0; i < 6; i++) fprintf(stderr, " %s %.1f%%", names[i], 100.0 * (double)h[i] / tot);
+        for (int i = 0; i < 10; i++) fprintf(stderr, " %s %.1f%%", names[i], 100.0 * (double)h[i] / tot);
         fprintf(stderr, "  (%.0f cycles per tile per workgroup)\n", tot / (double)ntiles);
     }
     return SE_OK;
