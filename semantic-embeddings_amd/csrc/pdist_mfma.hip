@@ -517,6 +517,12 @@ static int launch_pdist(const float *a, int64_t lda, const float *b, int64_t ldb
 
 }  // namespace se
 
+namespace se {
+// pdist_ws.hip: wave-specialised variant; SE_OK = done, 1 = not applicable (use the kernel in this file)
+int pdist_ws_try(const float *a, int64_t lda, const float *b, int64_t ldb, const float *sqa, const float *sqb, int64_t q, int64_t n,
+                 int64_t d, int metric, float *out, int64_t ldo, hipStream_t s);
+}
+
 using namespace se;
 
 extern "C" int se_pairwise_dist(const float *a, int64_t lda, const float *b, int64_t ldb, const float *sqa,
@@ -547,6 +553,10 @@ extern "C" int se_pairwise_dist(const float *a, int64_t lda, const float *b, int
         multi = true;
     }
     hipStream_t s = (hipStream_t)stream;
+    if (!multi && (metric == SE_METRIC_COSINE || metric == SE_METRIC_EUCLID || metric == SE_METRIC_DOT)) {
+        const int rc = pdist_ws_try(a, lda, b, ldb, sqa, sqb, q, n, d, metric, out, ldo, s);
+        if (rc != 1) return rc;
+    }
     switch (metric) {
         case SE_METRIC_COSINE: return launch_pdist<SE_METRIC_COSINE>(a, lda, b, ldb, sqa, sqb, q, n, d, kbs, multi, out, ldo, s);
         case SE_METRIC_EUCLID: return launch_pdist<SE_METRIC_EUCLID>(a, lda, b, ldb, sqa, sqb, q, n, d, kbs, multi, out, ldo, s);

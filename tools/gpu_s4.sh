@@ -1,4 +1,4 @@
 #!/bin/bash
 export TMPDIR=/tmp
-SE_PD_PROFILE=1 timeout 300 python tools/bench_kernels.py pdist --reps 1 2>&1 | grep "profile" | head -1
-SE_PD_ABLATE=4 SE_PD_PROFILE=1 timeout 300 python tools/bench_kernels.py pdist --reps 1 2>&1 | grep "profile" | head -1
+timeout 900 python -m pytest tests/test_gpu_retrieval.py -m gpu -q -x -k "pairwise or golden or full_size" 2>&1 | tail -3
+timeout 300 python tools/bench_kernels.py pdist 2>&1 | grep "pdist"
