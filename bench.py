@@ -160,8 +160,11 @@ def bench_retrieval(args, rank, world):
                       "GBps": rk_bytes / 1e6 / kms["rank_rows"], "frac_hbm": rk_bytes / 1e6 / kms["rank_rows"] / HBM_PEAK_GBS},
     }
     dominant = max(("pairwise_dist", "rank_rows"), key=lambda k: kms[k])
+    tr = pmc_traffic_gb(dominant, q, n, d)
     roofline = {"kernel": dominant, "bound": "hbm", "achieved": kernels[dominant]["GBps"], "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": kernels[dominant]["frac_hbm"], "traffic": pmc_traffic_gb(dominant, q, n, d)}
+                "unit": "GB/s", "frac": kernels[dominant]["frac_hbm"],
+                "traffic": None if tr is None else tr["bytes"],          # HBM bytes per launch (PMC), vs algorithmic_GB below
+                "algorithmic_bytes": kernels[dominant]["algorithmic_GB"] * 1e9, "traffic_detail": tr}
     out = {
         "metric": "retrieval_Mpairs_per_sec", "value": value, "unit": "Mpairs/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -185,8 +188,8 @@ def pmc_traffic_gb(kernel, q, n, d):
         if [rec["q"], rec["n"], rec["d"]] != [q, n, d]:
             return None
         ff = rec.get("fetch_factor", 2)   # gfx950: FETCH_SIZE halves wide coalesced reads (x2); other widths count in full
-        return {"unit": "GB", "read": rec["fetch_kb"] * ff * 1024 / 1e9, "write": rec["write_kb"] * 1024 / 1e9,
-                "total": (rec["fetch_kb"] * ff + rec["write_kb"]) * 1024 / 1e9, "source": rec["source"]}
+        return {"bytes": (rec["fetch_kb"] * ff + rec["write_kb"]) * 1024.0, "read_GB": rec["fetch_kb"] * ff * 1024 / 1e9,
+                "write_GB": rec["write_kb"] * 1024 / 1e9, "source": rec["source"]}
     except Exception:
         return None
 
