@@ -1,7 +1,7 @@
 #!/bin/bash
 # PMC counter passes (each in its own rocprofv3 run, no tracing flags) for the pdist and rank kernels
 set -u
-OUT=gpurun_out/s3; mkdir -p $OUT; export TMPDIR=/tmp
+OUT=gpurun_out/pmc; mkdir -p $OUT; export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 rocprofv3 -L 2>/dev/null | grep -oE "\b(SQ_[A-Z_0-9]+|TCC_[A-Z_0-9]+|GRBM_[A-Z_]+|FETCH_SIZE|WRITE_SIZE|MfmaUtil|VALUBusy|LDSBankConflict)\b" | sort -u | tr '\n' ' ' > $OUT/counters.txt
 run_pmc () { # name counters cmd...
