@@ -280,7 +280,7 @@ class ClassHierarchy(object):
         ``se_hierarchical_precision`` instead of the reference's Python loop (class_hierarchy.py:257-314, ~0.6 h at
         N = 50k) -- and the 330 s ``.tolist()`` hand-off of evaluate_retrieval.py:69-73 disappears.
 
-        ``features``: float32 ``[N, D]`` array (normalised in place on the device copy when ``normalize``);
+        ``features``: float32 ``[N, D]`` array or (device) tensor (a device copy is normalised when ``normalize``);
         ``labels``: class label of image ``ids[i]`` (``ids`` defaults to ``range(N)``), as a sequence or a mapping.
         Returns ``(means, per_query)`` exactly like ``hierarchical_precision``."""
         import torch
@@ -307,7 +307,10 @@ class ClassHierarchy(object):
                 best[c] = np.cumsum(np.repeat(vals[order], counts[order]))
 
         dev = torch.device('cuda', torch.cuda.current_device())
-        feats = torch.from_numpy(np.ascontiguousarray(features, dtype=np.float32)).to(dev)
+        if torch.is_tensor(features):    # features straight from the network (learn_image_embeddings feature extraction): stay on the device
+            feats = features.detach().to(device=dev, dtype=torch.float32).contiguous().clone()
+        else:
+            feats = torch.from_numpy(np.ascontiguousarray(features, dtype=np.float32)).to(dev)
         cls_d = torch.from_numpy(cls_h).to(dev)
         qidx_d = torch.arange(n, dtype=torch.int32, device=dev)
         args_d = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (wup_t, lcs_t, best_w, best_l)]
