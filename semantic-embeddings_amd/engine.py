@@ -8,14 +8,19 @@ predict_generator`` + ``multi_gpu_model`` play in the reference (learn_image_emb
   Keras-style update (L2 regulariser folded into the gradient BEFORE clipping, global-norm
   clipping, ``lr / (1 + decay * t)``, momentum / Nesterov) is a handful of whole-buffer launches
   regardless of the number of layers;
-* the loss head is the fused HIP kernel (``utils.CosineEmbeddingLoss``); backbone math runs under
-  bf16 autocast (MIOpen / hipBLASLt), master weights and the loss stay fp32;
+* the loss head is the fused HIP kernel (``utils.CosineEmbeddingLoss``); the backbone (MIOpen / hipBLASLt) runs in the
+  mode ``backbone_mode`` picks per architecture -- fp32 NCHW for the CIFAR-sized ResNets (their 16-64 channel
+  convolutions are launch-bound: bf16 autocast only adds ~880 cast/accumulate launches per step), bf16 autocast
+  channels_last for the ImageNet-sized ones; master weights and the loss are always fp32;
+* launch-bound steps are replayed as HIP graphs (``Trainer.enable_graphs``), validated against the eager gradient
+  at capture time;
 * metrics are accumulated on the device and read back once per epoch (no per-step host sync).
 
 Semantics mirrored from Keras 2.2 [third party, not in the reference tree]: SGD velocity
 ``v = m v - lr g; w += v`` (Nesterov: ``w += m v - lr g``), ``clipnorm`` = global-norm clip,
 per-replica BatchNorm statistics (``multi_gpu_model`` towers == no SyncBN).
 """
+import os
 import time
 
 import numpy as np
@@ -27,6 +32,20 @@ def dist_info():
     if dist.is_available() and dist.is_initialized():
         return dist.get_rank(), dist.get_world_size()
     return 0, 1
+
+
+def backbone_mode(architecture):
+    """``(autocast_dtype, memory_format)`` for ``Trainer``: how the PyTorch-ROCm backbone of ``architecture`` runs.
+    Measured on MI355X, resnet-110-fc, batch 128 (tools/train_variants.py, tools/graph_variants.py): bf16 autocast
+    channels_last 31.5 ms/step, fp32 channels_last 23.7, fp32 NCHW 21.6 (eager; all host-launch-bound), fp32 NCHW
+    HIP-graph replay 15.3.  ``SE_TRAIN_DTYPE`` = fp32|bf16 and ``SE_TRAIN_LAYOUT`` = nchw|nhwc override."""
+    small = str(architecture).startswith(('resnet-32', 'resnet-110', 'simple', 'wrn-'))      # CIFAR-sized inputs
+    dtype = os.environ.get('SE_TRAIN_DTYPE', 'fp32' if small else 'bf16').lower()
+    layout = os.environ.get('SE_TRAIN_LAYOUT', 'nchw' if small else 'nhwc').lower()
+    if dtype not in ('fp32', 'bf16') or layout not in ('nchw', 'nhwc'):
+        raise ValueError('SE_TRAIN_DTYPE must be fp32|bf16 and SE_TRAIN_LAYOUT nchw|nhwc')
+    return (None if dtype == 'fp32' else torch.bfloat16,
+            torch.contiguous_format if layout == 'nchw' else torch.channels_last)
 
 
 class FlatState(object):
@@ -129,8 +148,11 @@ class Trainer(object):
     A batch from the sequences is ``(X, y)`` or ``(X, [y_1, y_2, ...])``."""
 
     def __init__(self, model, losses, metrics=None, lr=0.1, momentum=0.9, nesterov=False, clipnorm=None, decay=0.0,
-                 l2_of=None, autocast_dtype=torch.bfloat16, bucket_bytes=25 << 20, trainable=None):
+                 l2_of=None, autocast_dtype=torch.bfloat16, bucket_bytes=25 << 20, trainable=None, memory_format=None):
         self.model = model
+        self.memory_format = memory_format       # None: leave model and batches as they come (channels_last by construction)
+        if memory_format is not None:
+            model.to(memory_format=memory_format)
         self.losses = losses
         self.metrics = metrics or {}
         self.lr, self.momentum, self.nesterov, self.clipnorm, self.decay = lr, momentum, nesterov, clipnorm, decay
@@ -145,10 +167,13 @@ class Trainer(object):
         self.reducer = BucketedAllReduce(self.flat, bucket_bytes)
         self.stop_training = False
         self._graph = None
+        self._graph_tried = False
 
     # ---------------------------------------------------------------- one step
 
     def _forward(self, X):
+        if self.memory_format is not None and X.dim() == 4:
+            X = X.contiguous(memory_format=self.memory_format)     # no-op when the loader already produces this layout
         if self.autocast_dtype is not None and X.is_cuda:
             with torch.autocast('cuda', dtype=self.autocast_dtype):
                 out = self.model(X)
@@ -190,49 +215,76 @@ class Trainer(object):
 
     # ---------------------------------------------------------------- HIP-graph replay of the step
 
-    def enable_graphs(self, X, y, warmup=3):
+    def enable_graphs(self, X, y, warmup=3, validate=4, tol=2e-3):
         """Capture the training step into two HIP graphs (``torch.cuda.CUDAGraph``): A = zero grads + forward + fused
         loss/metric + backward, B = the whole-buffer SGD update; the RCCL all-reduce of the flat gradient buffer stays
         an eager call between them (one message per step), so 1-GPU and N-GPU runs replay identical graphs.
-        A ResNet-110 step is ~1500 small launches and launch-bound in eager mode.  Batches must keep the shape of
-        ``(X, y)``.  Returns False (and stays eager) if the capture fails.
+        A ResNet-110 step is ~1500 small launches and host-launch-bound in eager mode (21.6 -> 15.3 ms on MI355X, fp32).
+        Batches of another shape than ``(X, y)`` (a short last batch) run eagerly.
 
-        EXPERIMENTAL: on torch 2.10 + ROCm 7.0 the replayed backward of the ResNet backbones goes non-finite after a
-        few replays (reproduced with a pure-PyTorch loss and no HIP kernels of this package: tools/debug_graph.py), so
-        nothing enables this by default."""
+        The model's state is untouched: parameters, velocity and BatchNorm buffers are snapshotted before the warm-up
+        steps the capture needs (MIOpen / hipBLASLt algorithm searches) and restored afterwards.  Graph A is then
+        **validated**: ``validate`` replays must reproduce the eager gradient of the same batch (relative L2 error
+        below ``tol``, all finite).  On torch 2.10 + ROCm 7.0 the replayed bf16-autocast backward of these backbones
+        turns non-finite within a few replays (tools/graph_variants.py; fp32 replays are clean), which this check
+        catches: the trainer then stays eager, says so, and returns False."""
         if not X.is_cuda:
             return False
         ys = y if isinstance(y, (tuple, list)) else (y,)
+        hooks_were = self.reducer.enabled
+        snap_p, snap_v, snap_it = self.flat.flat_p.clone(), self.flat.flat_v.clone(), self.iterations
+        snap_buf = [b.clone() for b in self.model.buffers()]
+
+        def restore():
+            self.flat.flat_p.copy_(snap_p)
+            self.flat.flat_v.copy_(snap_v)
+            for b, sb in zip(self.model.buffers(), snap_buf):
+                b.copy_(sb)
+            self.iterations = snap_it
+
         try:
             self._sX = X.clone()
             self._sy = [t.clone() for t in ys]
+            sy = self._sy if len(self._sy) > 1 else self._sy[0]
             self._lr_t = torch.full((), float(self.lr), dtype=torch.float32, device=X.device)
-            hooks_were = self.reducer.enabled
             self.reducer.enabled = False          # no collectives inside the capture: all-reduce runs between the graphs
-            self._hooks_off = True
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 for _ in range(warmup):           # MIOpen / hipBLASLt algorithm searches must happen before the capture
-                    self._eager_core(self._sX, self._sy if len(self._sy) > 1 else self._sy[0], {})
-                    self._allreduce_flat(hooks_were)
-                    self.apply_update(1.0 / self.world if hooks_were else 1.0, lr_tensor=self._lr_t)
+                    self._eager_core(self._sX, sy, {})
+                    self.apply_update(1.0, lr_tensor=self._lr_t, count=False)
             torch.cuda.current_stream().wait_stream(side)
+            restore()
             self._g_logs = {}
             ga = torch.cuda.CUDAGraph()
             with torch.cuda.graph(ga):
-                self._g_loss = self._eager_core(self._sX, self._sy if len(self._sy) > 1 else self._sy[0], self._g_logs)
+                self._g_loss = self._eager_core(self._sX, sy, self._g_logs)
             gb = torch.cuda.CUDAGraph()
             with torch.cuda.graph(gb):
                 self.apply_update(1.0 / self.world if hooks_were else 1.0, lr_tensor=self._lr_t, count=False)
+            if validate:
+                self._eager_core(self._sX, sy, {})
+                ref = self.flat.flat_g.clone()
+                ref_norm = float(torch.linalg.vector_norm(ref))
+                for r in range(validate):
+                    ga.replay()
+                    g = self.flat.flat_g
+                    err = float(torch.linalg.vector_norm(g - ref)) / max(ref_norm, 1e-30)
+                    if not (err < tol) or not bool(torch.isfinite(self._g_loss)):      # NaN compares False
+                        raise RuntimeError('replay %d of the captured step does not reproduce the eager gradient '
+                                           '(relative L2 error %g, loss %g)' % (r, err, float(self._g_loss)))
+            restore()
             self._graph = (ga, gb)
             self._graph_allreduce = hooks_were
+            self._graph_steps = 0
             return True
         except Exception as e:                    # stay eager, loudly
-            print('[engine] HIP-graph capture failed, staying eager: %s: %s' % (type(e).__name__, e), flush=True)
+            print('[engine] HIP-graph replay disabled, staying eager: %s: %s' % (type(e).__name__, e), flush=True)
             self._graph = None
-            self.reducer.enabled = self.world > 1
-            self._hooks_off = False
+            self.reducer.enabled = hooks_were
+            torch.cuda.synchronize()
+            restore()
             return False
 
     def _eager_core(self, X, y, logs):
@@ -248,6 +300,12 @@ class Trainer(object):
 
     def _graph_step(self, X, y, logs):
         ys = y if isinstance(y, (tuple, list)) else (y,)
+        if X.shape != self._sX.shape or any(a.shape != b.shape for a, b in zip(self._sy, ys)):
+            # e.g. the short last batch of an epoch: same arithmetic, launched eagerly (hooks are off in graph mode)
+            loss = self._eager_core(X, y, logs)
+            self._allreduce_flat(self._graph_allreduce)
+            self.apply_update(1.0 / self.world if self._graph_allreduce else 1.0)
+            return loss
         self._sX.copy_(X, non_blocking=True)
         for dst, src in zip(self._sy, ys):
             dst.copy_(src, non_blocking=True)
@@ -258,8 +316,12 @@ class Trainer(object):
         self._allreduce_flat(self._graph_allreduce)
         gb.replay()
         self.iterations += 1
+        self._graph_steps += 1
         for k, v in self._g_logs.items():      # static device scalars written by graph A
             logs[k] = logs.get(k, 0) + v.clone()
+        if self._graph_steps % 256 == 0 and not bool(torch.isfinite(self._g_loss)):     # one host sync per 256 steps
+            raise FloatingPointError('non-finite loss in HIP-graph replay %d (diverged training, or a replay fault: '
+                                     'rerun with SE_TRAIN_GRAPHS=0 to tell)' % self._graph_steps)
         return self._g_loss
 
     def apply_update(self, grad_scale=1.0, lr_tensor=None, count=True):
@@ -334,6 +396,16 @@ class Trainer(object):
 
     def fit(self, train_seq, validation_data=None, epochs=1, initial_epoch=0, callbacks=(), verbose=True, log_every=50):
         self.model.train()
+        # fp32 steps are replayed as HIP graphs unless SE_TRAIN_GRAPHS=0 (bf16 autocast replays fail the capture-time
+        # validation on this stack, so they are not even tried)
+        if (not self._graph_tried and self.autocast_dtype is None and len(train_seq) > 0
+                and os.environ.get('SE_TRAIN_GRAPHS', '1') != '0'):
+            self._graph_tried = True
+            X0, y0 = train_seq[0]
+            if X0.is_cuda:
+                ok = self.enable_graphs(X0, y0)
+                if verbose and self.is_main_process:
+                    print('[engine] training step: %s' % ('HIP-graph replay' if ok else 'eager launches'), flush=True)
         for cb in callbacks:
             cb.on_train_begin(self)
         history = []

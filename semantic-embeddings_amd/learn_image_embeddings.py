@@ -26,7 +26,7 @@ import torch.nn as nn
 
 import utils
 from datasets import get_data_generator
-from engine import Trainer
+from engine import Trainer, backbone_mode
 from models.cifar_resnet import keras_bn, keras_dense
 
 
@@ -199,11 +199,12 @@ def main(argv=None):
     train_seq = lambda: data_generator.train_sequence(args.batch_size, batch_transform=transform_inputs, batch_transform_kwargs=kw, **dp)
     val_seq = lambda: data_generator.test_sequence(args.val_batch_size, batch_transform=transform_inputs, batch_transform_kwargs=kw, **dp)
 
+    mode = backbone_mode(args.architecture)       # (autocast dtype, memory format) of the PyTorch-ROCm backbone
     # ---- optional warm-up of the new layers only (learn_image_embeddings.py:183-207)
     if args.finetune and args.finetune_init > 0:
         print('Pre-training new layers')
         pre = Trainer(model, losses, all_metrics, lr=args.sgd_lr, momentum=0.9, nesterov=args.nesterov, clipnorm=args.clipgrad,
-                      l2_of=l2_of, trainable=lambda n: ('embedding' in n) or ('prob' in n))
+                      autocast_dtype=mode[0], memory_format=mode[1], l2_of=l2_of, trainable=lambda n: ('embedding' in n) or ('prob' in n))
         pre.fit(train_seq(), val_seq(), epochs=args.finetune_init, verbose=not args.no_progress)
         for p in model.parameters():
             p.requires_grad_(True)
@@ -220,7 +221,7 @@ def main(argv=None):
         callbacks.append(utils.ModelCheckpoint(args.snapshot, **ck) if world <= 1 else utils.TemplateModelCheckpoint(model, args.snapshot, **ck))
     decay = (1.0 / args.max_decay - 1) / ((data_generator.num_train // args.batch_size) * epochs) if args.max_decay > 0 else 0.0
     trainer = Trainer(model, losses, all_metrics, lr=args.sgd_lr, momentum=0.9, nesterov=args.nesterov, clipnorm=args.clipgrad,
-                      decay=decay, l2_of=l2_of)
+                      decay=decay, l2_of=l2_of, autocast_dtype=mode[0], memory_format=mode[1])
     trainer.fit(train_seq(), val_seq(), epochs=epochs, initial_epoch=args.initial_epoch, callbacks=callbacks, verbose=not args.no_progress)
 
     # ---- final evaluation (learn_image_embeddings.py:246-255)

@@ -115,6 +115,46 @@ def test_training_step_resnet110_fc_uses_hip_loss_and_learns():
     assert feats.shape == (64, 100)
 
 
+@pytest.mark.gpu
+def test_training_graph_replay_matches_eager_steps_and_keeps_state():
+    """Trainer.enable_graphs (fp32 NCHW backbone_mode of the CIFAR ResNets): capture must leave parameters, velocity and
+    BatchNorm buffers untouched, replayed steps must follow the eager trajectory, a short batch runs eagerly."""
+    import utils
+    from datasets import SyntheticGenerator
+    from engine import Trainer, backbone_mode
+    E = np.load(os.path.join(GOLDEN, "embeddings.npz"))["cifar100_unitsphere"]
+    Ed = torch.from_numpy(E.astype(np.float32)).cuda()
+    adt, fmt = backbone_mode("resnet-32")
+    assert adt is None and fmt == torch.contiguous_format
+    gen = SyntheticGenerator(100, 32, 3, 256, 32)
+    seq = gen.train_sequence(32, shuffle=False)
+    batches = [seq[i] for i in range(4)]
+
+    def make():
+        torch.manual_seed(0)
+        model = utils.build_network(100, "resnet-32", classification=True, no_softmax=True, input_channels=3).cuda()
+        l2 = {id(p): model.regularizer for p in model.regularized_parameters()}
+        return Trainer(model, {"l2norm": (utils.CosineEmbeddingLoss(Ed), 1.0)}, {"l2norm": [utils.nn_accuracy(Ed, dot_prod_sim=True)]},
+                       lr=0.05, clipnorm=10.0, l2_of=l2, autocast_dtype=adt, memory_format=fmt)
+
+    eager, graph = make(), make()
+    p0 = graph.flat.flat_p.clone()
+    b0 = [b.clone() for b in graph.model.buffers()]
+    assert graph.enable_graphs(*batches[0]) is True
+    assert torch.equal(graph.flat.flat_p, p0) and float(graph.flat.flat_v.abs().max()) == 0.0 and graph.iterations == 0
+    assert all(torch.equal(a, b) for a, b in zip(graph.model.buffers(), b0))
+    le, lg = {}, {}
+    for i in range(6):
+        a = float(eager.train_step(*batches[i % 4], le))
+        b = float(graph.train_step(*batches[i % 4], lg))
+        assert np.isfinite(b) and abs(a - b) < 2e-3 * max(1.0, abs(a)), (i, a, b)
+    rel = float(torch.linalg.vector_norm(eager.flat.flat_p - graph.flat.flat_p) / torch.linalg.vector_norm(eager.flat.flat_p))
+    assert rel < 1e-3, rel
+    assert abs(float(le["max_sim_acc"]) - float(lg["max_sim_acc"])) < 1e-6 + 0.2
+    Xs, ys = batches[0][0][:8], batches[0][1][:8]          # short batch: eager launches inside a graph-mode trainer
+    assert np.isfinite(float(graph.train_step(Xs, ys, lg))) and graph.iterations == 7
+
+
 def test_hierarchical_precision_device_matches_reference_values():
     """se_hierarchical_precision + device rankings vs the values the REFERENCE's class_hierarchy produced on its own
     rankings (tests/golden/hierarchy_cifar.npz), both branches, whole-list and clipped AHP, AP; per-query values also

@@ -1,5 +1,5 @@
 """Training-step benchmark used by bench.py: ResNet-110-fc (or resnet-50) cosine-embedding
-training on synthetic batches -- forward (bf16 autocast), fused HIP loss fwd/bwd + MFMA accuracy
+training on synthetic batches -- forward (fp32 for the CIFAR nets, bf16 autocast for resnet-50), fused HIP loss fwd/bwd + MFMA accuracy
 metric, backward, RCCL gradient all-reduce, Keras-style SGD update.  Nothing is skipped inside the
 timed region (BASELINE.json configs[1] / configs[3])."""
 import os
@@ -28,7 +28,7 @@ def load_embedding(num_classes):
 def bench_train(args, rank, world):
     import utils
     from datasets import SyntheticGenerator
-    from engine import Trainer
+    from engine import Trainer, backbone_mode
 
     dev = torch.device("cuda", torch.cuda.current_device())
     arch = args.arch
@@ -43,17 +43,20 @@ def bench_train(args, rank, world):
     loss = utils.CosineEmbeddingLoss(emb_dev)
     metric = utils.nn_accuracy(emb_dev, dot_prod_sim=True)
     l2_of = {id(p): model.regularizer for p in model.regularized_parameters()} if getattr(model, "regularizer", 0) else {}
-    trainer = Trainer(model, {"l2norm": (loss, 1.0)}, {"l2norm": [metric]}, lr=0.1, momentum=0.9, clipnorm=10.0, l2_of=l2_of)
+    adt, fmt = backbone_mode(arch)                   # fp32 NCHW for the CIFAR ResNets, bf16 channels_last for resnet-50
+    trainer = Trainer(model, {"l2norm": (loss, 1.0)}, {"l2norm": [metric]}, lr=0.1, momentum=0.9, clipnorm=10.0, l2_of=l2_of,
+                      autocast_dtype=adt, memory_format=fmt)
     B = args.batch                                   # per-GPU batch: weak scaling
     gen = SyntheticGenerator(classes, size, 3, B * 64 * world, B * world)
     seq = gen.train_sequence(B * world, shuffle=False, rank=rank, world_size=world)
     batches = [seq[i] for i in range(8)]             # pre-generated, resident in HBM
+    batches = [(x.contiguous(memory_format=fmt), y) for x, y in batches]
+    # The product default (Trainer.fit): fp32 steps are replayed as two HIP graphs (fwd+loss+bwd | update) after the
+    # capture-time validation against the eager gradient; SE_TRAIN_GRAPHS=0 times eager launches.  bf16-autocast replays
+    # fail that validation on torch 2.10 / ROCm 7.0 and stay eager.
     graphs = False
-    # HIP-graph replay of the step (Trainer.enable_graphs) is OPT-IN: it is 1.46x faster on MI355X (19.8 vs 28.9 ms) but
-    # with torch 2.10 / ROCm 7.0 the replayed backward of this network turns non-finite after 1-5 replays even with
-    # pure-PyTorch loss and metric (tools/debug_graph.py), so the benchmark times the eager step.
-    if os.environ.get("SE_TRAIN_GRAPHS", "0") == "1":
-        graphs = trainer.enable_graphs(*batches[0])      # falls back to eager (and says so) if the capture fails
+    if adt is None and os.environ.get("SE_TRAIN_GRAPHS", "1") != "0":
+        graphs = trainer.enable_graphs(*batches[0])
     logs = {}
     steps, warm = max(args.steps, 20) if args.workload != "train" else args.steps, max(args.warmup, 5)
     for i in range(warm):
@@ -73,10 +76,13 @@ def bench_train(args, rank, world):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     loss_val = float(torch.as_tensor(logs["loss"]).item()) / (steps + warm)
+    if not np.isfinite(loss_val):
+        raise FloatingPointError("non-finite mean training loss %r (graphs=%s)" % (loss_val, graphs))
     return {"metric": "train_images_per_sec", "value": B * world * steps / dt, "unit": "images/s", "n_gpus": world,
             "steps": steps, "warmup": warm, "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32" if adt is None else "bf16", "data": "synthetic",
             "config": {"workload": "%s cosine-embedding training step, %dx%dx3, %d classes, per-GPU batch %d" % (arch, size, size, classes, B),
                        "global_batch": B * world, "parallelism": "dp%d" % world,
+                       "backbone": "%s, %s" % ("fp32" if adt is None else "bf16 autocast", "NCHW" if fmt == torch.contiguous_format else "channels_last"),
                        "step": "2 HIP graphs (fwd+loss+bwd | update) + eager RCCL all-reduce" if graphs else "eager launches"},
             "mean_loss": loss_val}
