@@ -275,17 +275,25 @@ class Trainer(object):
                         raise RuntimeError('replay %d of the captured step does not reproduce the eager gradient '
                                            '(relative L2 error %g, loss %g)' % (r, err, float(self._g_loss)))
             restore()
-            self._graph = (ga, gb)
-            self._graph_allreduce = hooks_were
-            self._graph_steps = 0
-            return True
-        except Exception as e:                    # stay eager, loudly
-            print('[engine] HIP-graph replay disabled, staying eager: %s: %s' % (type(e).__name__, e), flush=True)
-            self._graph = None
-            self.reducer.enabled = hooks_were
+            graphs, why = (ga, gb), None
+        except Exception as e:
+            graphs, why = None, '%s: %s' % (type(e).__name__, e)
             torch.cuda.synchronize()
             restore()
+        if self.world > 1:                        # every rank must take the same path (graph mode changes the collective pattern)
+            agree = torch.tensor([1 if graphs is not None else 0], dtype=torch.int32, device=X.device)
+            dist.all_reduce(agree, op=dist.ReduceOp.MIN)
+            if int(agree.item()) == 0 and graphs is not None:
+                graphs, why = None, 'another rank failed the capture or its validation'
+        if graphs is None:                        # stay eager, loudly
+            print('[engine] HIP-graph replay disabled, staying eager: %s' % why, flush=True)
+            self._graph = None
+            self.reducer.enabled = hooks_were
             return False
+        self._graph = graphs
+        self._graph_allreduce = hooks_were
+        self._graph_steps = 0
+        return True
 
     def _eager_core(self, X, y, logs):
         self.flat.flat_g.zero_()
