@@ -80,6 +80,17 @@ class FlatState(object):
             off += n
         self.total = total
         self.has_l2 = bool((self.flat_l2 != 0).any().item())
+        self.all_contiguous = all(p.is_contiguous() for p in params)
+
+    def bind_grads(self):
+        """(Re-)point every ``p.grad`` at its slice of the flat gradient buffer (accumulating mode)."""
+        for p, (off, n) in zip(self.params, self.offsets):
+            p.grad = self.flat_g[off:off + n].as_strided(p.shape, p.stride())
+
+    def gather_grads(self):
+        """Stolen-gradient mode: autograd left every gradient in a tensor of its own (``p.grad`` was None, so nothing
+        was accumulated); pack them into the flat buffer with one batched ``cat`` (4 launches for 442 tensors)."""
+        torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self.params], out=self.flat_g)
 
 
 class BucketedAllReduce(object):
@@ -168,6 +179,7 @@ class Trainer(object):
         self.stop_training = False
         self._graph = None
         self._graph_tried = False
+        self._grads_bound = True           # p.grad are views of flat_g (FlatState); False while gradients are stolen
 
     # ---------------------------------------------------------------- one step
 
@@ -204,11 +216,7 @@ class Trainer(object):
     def train_step(self, X, y, logs):
         if self._graph is not None:
             return self._graph_step(X, y, logs)
-        flat = self.flat
-        flat.flat_g.zero_()
-        outs = self._forward(X)
-        loss = self._loss_and_metrics(outs, y, logs)
-        loss.backward()
+        loss = self._eager_core(X, y, logs)
         scale = self.reducer.finish()
         self.apply_update(scale)
         return loss
@@ -296,10 +304,27 @@ class Trainer(object):
         return True
 
     def _eager_core(self, X, y, logs):
-        self.flat.flat_g.zero_()
+        """Zero / forward / loss + metrics / backward; leaves the (rank-local) gradient in ``flat.flat_g``.
+        Without bucket hooks to feed (single process, or graph mode where the all-reduce is one call after backward) the
+        gradients are *stolen*: ``p.grad = None`` makes autograd hand over each gradient tensor as it is instead of
+        launching one ``flat_g[slice] += grad`` per parameter (442 launches, 1.5 ms of GPU time on resnet-110-fc), and one
+        batched ``cat`` packs them into the flat buffer."""
+        flat = self.flat
+        steal = flat.all_contiguous and not self.reducer.enabled
+        if steal:
+            for p in flat.params:
+                p.grad = None
+            self._grads_bound = False
+        else:
+            if not self._grads_bound:
+                flat.bind_grads()
+                self._grads_bound = True
+            flat.flat_g.zero_()
         outs = self._forward(X)
         loss = self._loss_and_metrics(outs, y, logs)
         loss.backward()
+        if steal:
+            flat.gather_grads()
         return loss.detach()
 
     def _allreduce_flat(self, on):

@@ -44,7 +44,11 @@ def keras_conv(cin, cout, k, stride=1):
 
 
 def keras_bn(c):
-    return nn.BatchNorm2d(c, eps=KERAS_BN_EPS, momentum=KERAS_BN_MOMENTUM)
+    bn = nn.BatchNorm2d(c, eps=KERAS_BN_EPS, momentum=KERAS_BN_MOMENTUM)
+    # Keras' BatchNormalization has no batch counter and a fixed momentum never reads torch's: dropping the buffer saves one
+    # `num_batches_tracked += 1` launch per layer and step (109 launches = 0.5 ms of a 15 ms resnet-110 step)
+    bn.register_buffer('num_batches_tracked', None)
+    return bn
 
 
 def keras_dense(cin, cout):

@@ -170,6 +170,44 @@ def test_keras_sgd_update_on_flat_buffers():
         assert torch.allclose(lin.bias, ref.bias, atol=1e-6), step
 
 
+def test_stolen_gradient_mode_equals_accumulating_mode_and_backbone_modes(monkeypatch):
+    """engine.Trainer packs stolen gradients (p.grad = None + one cat) when every parameter is contiguous and no bucket hooks
+    run, and accumulates into flat views otherwise; both give the same training trajectory."""
+    import engine
+    import utils
+    assert engine.backbone_mode("resnet-110-fc") == (None, torch.contiguous_format)
+    assert engine.backbone_mode("resnet-50") == (torch.bfloat16, torch.channels_last)
+    monkeypatch.setenv("SE_TRAIN_DTYPE", "bf16"); monkeypatch.setenv("SE_TRAIN_LAYOUT", "nhwc")
+    assert engine.backbone_mode("resnet-32") == (torch.bfloat16, torch.channels_last)
+    monkeypatch.setenv("SE_TRAIN_LAYOUT", "sideways")
+    with pytest.raises(ValueError):
+        engine.backbone_mode("resnet-32")
+
+    def make(fmt):
+        torch.manual_seed(3)
+        m = utils.build_network(10, "resnet-32", classification=True, no_softmax=True, input_channels=3)
+        l2 = {id(p): m.regularizer for p in m.regularized_parameters()}
+        return engine.Trainer(m, {"o": (lambda y, x: torch.nn.functional.cross_entropy(x, y, reduction="none"), 1.0)}, {}, lr=0.05,
+                              momentum=0.9, clipnorm=5.0, l2_of=l2, autocast_dtype=None, memory_format=fmt)
+    a, b = make(torch.contiguous_format), make(torch.contiguous_format)
+    assert a.flat.all_contiguous and not make(torch.channels_last).flat.all_contiguous
+    b.flat.all_contiguous = False            # same layout, accumulating mode
+    g = torch.Generator().manual_seed(0)
+    for _ in range(3):
+        X, y = torch.randn(8, 3, 32, 32, generator=g), torch.randint(0, 10, (8,), generator=g)
+        la, lb = float(a.train_step(X, y, {})), float(b.train_step(X, y, {}))
+        assert abs(la - lb) < 1e-5
+    assert not a._grads_bound and b._grads_bound
+    pa = torch.cat([p.detach().reshape(-1) for p in a.model.parameters()])
+    pb = torch.cat([p.detach().reshape(-1) for p in b.model.parameters()])
+    assert torch.allclose(pa, pb, rtol=1e-4, atol=1e-6)
+    # switching a trainer back to accumulating mode re-binds p.grad to the flat buffer
+    a.reducer.enabled = True
+    a.reducer.finish = lambda: 1.0
+    a._eager_core(X, y, {})
+    assert a._grads_bound and all(p.grad.data_ptr() >= a.flat.flat_g.data_ptr() for p in a.flat.params)
+
+
 def test_synthetic_generator_interface():
     from datasets import get_data_generator
     g = get_data_generator("synthetic:10x8x64x32", ".")
