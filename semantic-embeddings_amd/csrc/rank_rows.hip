@@ -364,64 +364,73 @@ constexpr int RR_HW_BITS = 11;   // digit width of the hardware-ordered variant:
 // add of the group size issued by lane 0; only the other lanes issue their own returning add.  The top digit of
 // real distance rows is heavily skewed -- all-positive Euclidean distances put every key of a wave step on one
 // counter, i.e. a 64-way same-address conflict per instruction (16.9 ms instead of 11 ms on the CLI-default branch).
-template <int ITEMS, bool PEEL, int V, int S0, int I = 0>
-struct RRRankHWFinish {
-    static __device__ __forceinline__ void run(uint32_t (&ir)[ITEMS], uint32_t (&key)[ITEMS], uint32_t (&r)[V], uint32_t (&sh)[V],
-                                               uint32_t (&grp)[V])
-    {
-        lds_wait_le<V - 1 - I>(r[I]);
-        uint32_t rank = (r[I] >> sh[I]) & 0xFFFFu;
-        if constexpr (PEEL) {
-            const uint32_t lead = (uint32_t)__builtin_amdgcn_readfirstlane((int)r[I]);   // lane 0's counter word before its add
-            const uint32_t own = (grp[I] != 0xFFFFFFFFu) ? lead : r[I];                     // group members use lane 0's word (same digit => same half)
-            rank = ((own >> sh[I]) & 0xFFFFu) + (grp[I] != 0xFFFFFFFFu ? grp[I] : 0u);
-        }
-        ir[S0 + I] = (ir[S0 + I] & 0xFFFF0000u) | rank;
-        opaque(ir[S0 + I]);
-        opaque(key[S0 + I]);
-        if constexpr (I + 1 < V) RRRankHWFinish<ITEMS, PEEL, V, S0, I + 1>::run(ir, key, r, sh, grp);
-    }
-};
-template <int ITEMS, bool PEEL, int S0 = 0>
+// Digit d of a pass = key bits [shift, shift + wlo + whi): its low wlo = 10 bits select the counter WORD, bit 10 (whi = 1;
+// the 10-bit last pass has whi = 0) the 16-bit HALF -- both straight v_bfe_u32 of the key, and the S phase can scan the
+// packed words without unpacking them (digits 0..1023 are the low halves, 1024..2047 the high halves).
+// The adds are software-pipelined one by one -- "retire step S - RR_GH, issue step S" -- so every lane keeps RR_GH - 1 or
+// RR_GH returning adds in flight from the first step to the last (tools/probes/lds_throughput.hip: the LDS sustains one
+// random-word returning add per 6.4 cycles and CU; batches of 8 that drain before the next batch is issued reached 21).
+template <int ITEMS, bool PEEL, int S = 0>
 struct RRRankHW {
     // `peel` is wave-uniform (one code instance for all passes: two instances of this unrolled body make hipcc spill)
-    static __device__ __forceinline__ void run(uint32_t (&ir)[ITEMS], uint32_t (&key)[ITEMS], int shift, uint32_t dmask, uint32_t cb, int lane,
-                                               bool peel)
+    static __device__ __forceinline__ void run(uint32_t (&ir)[ITEMS], uint32_t (&key)[ITEMS], uint32_t (&r)[RR_GH], uint32_t (&sh)[RR_GH],
+                                               uint32_t (&grp)[RR_GH], uint32_t shift, uint32_t hshift, uint32_t wlo, uint32_t whi, uint32_t cb,
+                                               int lane, bool peel)
     {
-        constexpr int V = (ITEMS - S0 < RR_GH) ? (ITEMS - S0) : RR_GH;
-        uint32_t r[V], sh[V], grp[V];
-#pragma unroll
-        for (int g = 0; g < V; g++) {
-            const uint32_t d = (key[S0 + g] >> shift) & dmask;
-            sh[g] = (d & 1u) << 4;
-            const uint32_t ca = cb + ((d << 1) & ~3u);
-            uint32_t inc = 1u << sh[g];
-            grp[g] = 0xFFFFFFFFu;
+        constexpr int SLOT = S % RR_GH;
+        uint32_t ca = 0, inc = 0, shv = 0, g = 0xFFFFFFFFu;
+        uint64_t part = ~0ull;
+        if constexpr (S < ITEMS) {
+            const uint32_t w = __builtin_amdgcn_ubfe(key[S], shift, wlo);
+            const uint32_t h = __builtin_amdgcn_ubfe(key[S], hshift, whi);   // width 0 -> 0
+            ca = cb + (w << 2);
+            shv = h << 4;
+            inc = 1u << shv;
             if constexpr (PEEL) {
-                uint64_t m = 0;                      // lanes sharing lane 0's digit (most significant pass only)
                 if (peel) {                          // wave-uniform branch: the other passes skip the group bookkeeping
+                    // lanes sharing lane 0's digit (most significant pass only) are ranked by one ballot and ONE add of the group size
+                    const uint32_t d = w | (h << 10);
                     const bool in = (d == (uint32_t)__builtin_amdgcn_readfirstlane((int)d));
-                    m = __ballot(in);
-                    if (in) grp[g] = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                    if (lane == 0) inc = (uint32_t)__popcll(m) << sh[g];
+                    const uint64_t m = __ballot(in);
+                    if (in) g = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    if (lane == 0) inc = (uint32_t)__popcll(m) << shv;
+                    part = ~m | 1ull;                // only lane 0 and the lanes outside its group issue the add
                 }
-                // Only lane 0 and the lanes outside its group issue the add.  The exec mask is narrowed INSIDE the asm
-                // statement: a C++ `if` around an asynchronous DS return lets hipcc copy the (not yet landed) result
-                // register at the join.  Lane 0 always takes part: exactly one DS operation per step for the wait counts.
-                const uint64_t part = ~m | 1ull;
+            }
+        }
+        if constexpr (S >= RR_GH) {                  // retire step J: wait until only the adds issued after it are outstanding
+            constexpr int J = S - RR_GH;
+            constexpr int younger = ((S < ITEMS ? S : ITEMS) - 1) - J;
+            lds_wait_le<younger>(r[SLOT]);
+            uint32_t rank = __builtin_amdgcn_ubfe(r[SLOT], sh[SLOT], 16u);
+            if constexpr (PEEL) {
+                const uint32_t lead = (uint32_t)__builtin_amdgcn_readfirstlane((int)r[SLOT]);   // lane 0's counter word before its add
+                const uint32_t own = (grp[SLOT] != 0xFFFFFFFFu) ? lead : r[SLOT];                 // group members use lane 0's word (same digit => same half)
+                rank = __builtin_amdgcn_ubfe(own, sh[SLOT], 16u) + (grp[SLOT] != 0xFFFFFFFFu ? grp[SLOT] : 0u);
+            }
+            ir[J] = (ir[J] & 0xFFFF0000u) | rank;
+            opaque(ir[J]);    // materialise now: nothing but key/ir stays live per key
+            opaque(key[J]);   // (and no cached counter address either)
+        }
+        if constexpr (S < ITEMS) {
+            sh[SLOT] = shv;
+            grp[SLOT] = g;
+            if constexpr (PEEL) {
+                // The exec mask is narrowed INSIDE the asm statement: a C++ `if` around an asynchronous DS return lets hipcc copy the
+                // (not yet landed) result register at the join.  Lane 0 always takes part: exactly one DS operation per step.
                 uint64_t saved;
-                r[g] = 0;
+                r[SLOT] = 0;
                 asm volatile("s_and_saveexec_b64 %0, %4\n\tds_add_rtn_u32 %1, %2, %3\n\ts_mov_b64 exec, %0"
-                             : "=&s"(saved), "+v"(r[g])
+                             : "=&s"(saved), "+v"(r[SLOT])
                              : "v"(ca), "v"(inc), "s"(part)
                              : "memory");
             } else {
-                asm volatile("ds_add_rtn_u32 %0, %1, %2" : "=v"(r[g]) : "v"(ca), "v"(inc) : "memory");
+                asm volatile("ds_add_rtn_u32 %0, %1, %2" : "=v"(r[SLOT]) : "v"(ca), "v"(inc) : "memory");
             }
         }
-        RRRankHWFinish<ITEMS, PEEL, V, S0>::run(ir, key, r, sh, grp);
+        // the scheduling fence keeps hipcc from hoisting the address arithmetic of all ITEMS steps (live registers -> spills)
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (S0 + V < ITEMS) RRRankHW<ITEMS, PEEL, S0 + V>::run(ir, key, shift, dmask, cb, lane, peel);
+        if constexpr (S + 1 < ITEMS + RR_GH) RRRankHW<ITEMS, PEEL, S + 1>::run(ir, key, r, sh, grp, shift, hshift, wlo, whi, cb, lane, peel);
     }
 };
 
@@ -451,34 +460,56 @@ __global__ __launch_bounds__(RR_THREADS, 2) void rank_rows_reg_kernel(const floa
     uint64_t t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last = PROF ? __builtin_amdgcn_s_memtime() : 0;
 #define RR_T(i) if constexpr (PROF) { const uint64_t now = __builtin_amdgcn_s_memtime(); t_acc[i] += now - t_last; t_last = now; } else { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
 
+    // The row loop is software-pipelined over HBM: the NEXT row's distances are loaded into the key registers as soon as the
+    // last pass no longer needs them (after its D phase) and land behind the final index exchange; they are canonicalised --
+    // the only wait on vector memory in the loop -- BEFORE this row's ranks are stored, so the stores drain during the next
+    // row's LDS phases instead of in front of its first use of a loaded key (vmcnt counts loads and stores together:
+    // waiting for loads issued after the stores cost ~25 % of the kernel, the time HBM needs to absorb 200-400 KB per CU).
+    uint32_t key[ITEMS], ir[ITEMS];   // ir = (index << 16) | (within-wave rank, then destination)
+    uint32_t ring[RR_RING];
+#define RR_LOAD_ONE(DROW, WPOS, S)                                                                                   \
+    {                                                                                                                 \
+        /* unconditional load (clamped index; the padding is applied in RR_CANON): a branch around a load makes      \
+           hipcc wait for each load before issuing the next */                                                        \
+        const int pos = (WPOS) + (S) * WAVE;                                                                          \
+        int gi = pos < N ? pos : N - 1;                                                                               \
+        opaque(gi);                                                                                                   \
+        key[S] = __float_as_uint((DROW)[gi]);                                                                         \
+    }
+#define RR_CANON()                                                                                                    \
+    {                                                                                                                 \
+        int wpos_ = wpos0;                                                                                            \
+        opaque(wpos_);                                                                                                \
+        _Pragma("unroll") for (int s = 0; s < ITEMS; s++) {                                                           \
+            const int pos = wpos_ + s * WAVE;                                                                         \
+            key[s] = canon_key(__uint_as_float(key[s])) | (uint32_t)((N - 1 - pos) >> 31); /* pos >= N: all ones */   \
+        }                                                                                                             \
+    }
+    if ((int64_t)blockIdx.x < Q) {
+        const float *drow = pdist + (int64_t)blockIdx.x * ldp;
+        int wpos = wpos0;
+        opaque(wpos);
+#pragma unroll
+        for (int s = 0; s < ITEMS; s++) RR_LOAD_ONE(drow, wpos, s)
+        RR_CANON()
+    }
     uint32_t pf_sink = 0;
     for (int64_t row = blockIdx.x; row < Q; row += gridDim.x) {
-        const float *drow = pdist + row * ldp;
-        uint32_t key[ITEMS], ir[ITEMS];   // ir = (index << 16) | (within-wave rank, then destination)
-        uint32_t ring[RR_RING];
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf_sink) : : "memory");   // the L2 prefetch of this row has landed (sink register free again)
-        int wpos = wpos0;
-        opaque(wpos);   // per-row opaque: otherwise hipcc hoists ITEMS row-invariant clamps/masks out of the row loop and keeps them live
+        const bool more = row + gridDim.x < Q;
+        {
+            int wpos = wpos0;
+            opaque(wpos);
 #pragma unroll
-        for (int s = 0; s < ITEMS; s++) {
-            // unconditional loads (clamped index, padding applied arithmetically): a branch around a load
-            // makes hipcc wait for each load before issuing the next
-            const int pos = wpos + s * WAVE;
-            int gi = pos < N ? pos : N - 1;
-            opaque(gi);
-            key[s] = canon_key(drow[gi]) | (uint32_t)((N - 1 - pos) >> 31);   // pos >= N: all ones
-            ir[s] = (uint32_t)pos << 16;
+            for (int s = 0; s < ITEMS; s++) ir[s] = (uint32_t)(wpos + s * WAVE) << 16;
         }
-        RR_T(0)
 #pragma unroll 1
         for (int p = 0; p < NPASS; p++) {
             const int shift = p * BITS;
             const int end = (shift + BITS < 32) ? shift + BITS : 32;        // bits [0, end) are sorted after this pass
-            const uint32_t dmask = (1u << (end - shift)) - 1u;
-            if (p == NPASS - 1 && row + gridDim.x < Q) {
-                // L2 prefetch of this workgroup's NEXT row (one workgroup per CU: nothing else hides its 200 KB of
-                // HBM latency): one dword per 128-byte line, all into one sink register that stays reserved until
-                // the s_waitcnt at the top of the row loop.
+            [[maybe_unused]] const uint32_t dmask = (1u << (end - shift)) - 1u;
+            if (p == NPASS - 1 && more) {
+                // L2 prefetch of this workgroup's NEXT row (one workgroup per CU: nothing else hides its 200 KB of HBM latency): one dword
+                // per 128-byte line, all into one sink register that stays reserved until the loads after the pass loop have been waited for
                 const char *nrow = (const char *)(pdist + (row + gridDim.x) * ldp);
                 const uint32_t row_bytes = (uint32_t)N * 4u;
                 for (uint32_t off = (uint32_t)tid * 128u; off < row_bytes; off += RR_THREADS * 128u)
@@ -487,7 +518,11 @@ __global__ __launch_bounds__(RR_THREADS, 2) void rank_rows_reg_kernel(const floa
             // ---- R: stable rank inside the wave ----
 #pragma unroll
             for (int j = 0; j < CNT_WORDS / WAVE; j++) mycnt[j * WAVE + lane] = 0;
-            if constexpr (HWORD) RRRankHW<ITEMS, PEEL>::run(ir, key, shift, dmask, cb, lane, p == NPASS - 1);
+            [[maybe_unused]] const uint32_t wlo = 10u, whi = (uint32_t)(end - shift) - 10u, hshift = (uint32_t)(shift + 10) & 31u;   // HWORD digit split
+            if constexpr (HWORD) {
+                uint32_t hr[RR_GH], hs[RR_GH], hg[RR_GH];
+                RRRankHW<ITEMS, PEEL>::run(ir, key, hr, hs, hg, (uint32_t)shift, hshift, wlo, whi, cb, lane, p == NPASS - 1);
+            }
             else RRRank<ITEMS>::run(ir, key, shift, lane, cb);
             lds_wait();
             RR_T(1)
@@ -514,26 +549,35 @@ __global__ __launch_bounds__(RR_THREADS, 2) void rank_rows_reg_kernel(const floa
                 }
             }
             } else {
-                // 2048 digits x 8 waves of 16-bit counts: thread t owns digits 4t .. 4t+3 = one 8-byte LDS access per wave
-                uint32_t t0 = 0, t1 = 0, t2 = 0, t3 = 0;   // per-digit totals over the waves
+                // 2048 digits x 8 waves of 16-bit counts, two per word (low half: digit w, high half: digit 1024 + w).  Thread t owns the
+                // words 2t and 2t+1 of every wave (one 8-byte LDS access each) and all arithmetic stays PACKED: a half never exceeds the
+                // 53,248 keys of a row, so the low halves cannot carry into the high ones.
+                uint32_t T0 = 0, T1 = 0;   // per-word totals over the waves
 #pragma unroll
                 for (int w = 0; w < RR_WAVES; w++) {
                     const uint2 v = *reinterpret_cast<const uint2 *>(wcnt + w * CNT_WORDS + 2 * tid);
-                    t0 += v.x & 0xFFFFu; t1 += v.x >> 16; t2 += v.y & 0xFFFFu; t3 += v.y >> 16;
+                    T0 += v.x; T1 += v.y;
                 }
                 uint32_t wtot;
-                uint32_t ex = wave_excl_scan(t0 + t1 + t2 + t3, wtot);
+                uint32_t ex = wave_excl_scan(T0 + T1, wtot);   // both halves scanned at once
                 if (lane == 63) wave_tot[wave] = wtot;
                 __syncthreads();
-                for (int w = 0; w < wave; w++) ex += wave_tot[w];
+                uint32_t all = 0;
+#pragma unroll
+                for (int w = 0; w < RR_WAVES; w++) {
+                    const uint32_t wt = wave_tot[w];
+                    all += wt;
+                    ex += (w < wave) ? wt : 0u;
+                }
+                ex += all << 16;           // the high-half digits follow ALL low-half digits
                 // digit-major / wave-minor: counts -> first destination of (wave, digit), written back in place
-                uint32_t s0 = ex, s1 = s0 + t0, s2 = s1 + t1, s3 = s2 + t2;
+                uint32_t s0 = ex, s1 = ex + T0;
 #pragma unroll
                 for (int w = 0; w < RR_WAVES; w++) {
                     uint2 *wp = reinterpret_cast<uint2 *>(wcnt + w * CNT_WORDS + 2 * tid);
                     const uint2 v = *wp;
-                    *wp = make_uint2(s0 | (s1 << 16), s2 | (s3 << 16));
-                    s0 += v.x & 0xFFFFu; s1 += v.x >> 16; s2 += v.y & 0xFFFFu; s3 += v.y >> 16;
+                    *wp = make_uint2(s0, s1);
+                    s0 += v.x; s1 += v.y;
                 }
             }
             __syncthreads();
@@ -545,7 +589,7 @@ __global__ __launch_bounds__(RR_THREADS, 2) void rank_rows_reg_kernel(const floa
 #pragma unroll
                 for (int g = 0; g < 8; g++)
                     if (s0 + g < ITEMS) {
-                        if constexpr (HWORD) first[g] = reinterpret_cast<const uint16_t *>(mycnt)[(key[s0 + g] >> shift) & dmask];
+                        if constexpr (HWORD) first[g] = reinterpret_cast<const uint16_t *>(mycnt)[(__builtin_amdgcn_ubfe(key[s0 + g], (uint32_t)shift, wlo) << 1) | __builtin_amdgcn_ubfe(key[s0 + g], hshift, whi)];
                         else first[g] = mycnt[(key[s0 + g] >> shift) & 0xFFu];
                     }
 #pragma unroll
@@ -586,11 +630,27 @@ __global__ __launch_bounds__(RR_THREADS, 2) void rank_rows_reg_kernel(const floa
             // (the next pass's barriers order these reads before its first exchange write)
         }
 #undef RR_DST
-        // ---- the exchange buffer now holds the ranking: stream it out ----
+        // ---- the exchange buffer now holds the ranking: canonicalise the next row's keys (waits for its loads), then stream the ranks out ----
+        // (the loads sit after the pass loop, not inside its last iteration: a re-definition of the key registers on the `break` path makes
+        // hipcc copy all ITEMS index registers there; the row was prefetched into L2 during the last pass)
+        {
+            const float *drow = pdist + (more ? row + gridDim.x : row) * ldp;
+            int wpos = wpos0;
+            opaque(wpos);   // per-row opaque: otherwise hipcc hoists ITEMS row-invariant clamps out of the row loop and keeps them live
+#pragma unroll
+            for (int s = 0; s < ITEMS; s++) RR_LOAD_ONE(drow, wpos, s)
+        }
+        RR_CANON()
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf_sink) : : "memory");   // prefetch dwords landed too: the sink register is free again, nothing is outstanding
+        RR_T(0)
         if (idx64) {
             int64_t *o = (int64_t *)rank + row * ldr;
-            for (int j = tid * 4; j < N; j += RR_THREADS * 4) {
-                const uint2 v = *reinterpret_cast<const uint2 *>(xbuf + j);
+            // (the next row's keys are live: no unrolling, the LDS read of the next step is issued before this step's stores instead)
+            uint2 nv = *reinterpret_cast<const uint2 *>(xbuf + (tid * 4 < N ? tid * 4 : 0));
+            _Pragma("unroll 1") for (int j = tid * 4; j < N; j += RR_THREADS * 4) {
+                const uint2 v = nv;
+                const int jn = j + RR_THREADS * 4;
+                nv = *reinterpret_cast<const uint2 *>(xbuf + (jn < N ? jn : 0));
                 const int64_t e0 = v.x & 0xFFFFu, e1 = v.x >> 16, e2 = v.y & 0xFFFFu, e3 = v.y >> 16;
                 if (vec_ok && j + 3 < N) {
                     *reinterpret_cast<longlong2 *>(o + j) = make_longlong2(e0, e1);
@@ -604,8 +664,11 @@ __global__ __launch_bounds__(RR_THREADS, 2) void rank_rows_reg_kernel(const floa
             }
         } else {
             int32_t *o = (int32_t *)rank + row * ldr;
-            for (int j = tid * 4; j < N; j += RR_THREADS * 4) {
-                const uint2 v = *reinterpret_cast<const uint2 *>(xbuf + j);
+            uint2 nv = *reinterpret_cast<const uint2 *>(xbuf + (tid * 4 < N ? tid * 4 : 0));
+            _Pragma("unroll 1") for (int j = tid * 4; j < N; j += RR_THREADS * 4) {
+                const uint2 v = nv;
+                const int jn = j + RR_THREADS * 4;
+                nv = *reinterpret_cast<const uint2 *>(xbuf + (jn < N ? jn : 0));
                 const int e0 = v.x & 0xFFFFu, e1 = v.x >> 16, e2 = v.y & 0xFFFFu, e3 = v.y >> 16;
                 if (vec_ok && j + 3 < N) {
                     *reinterpret_cast<int4 *>(o + j) = make_int4(e0, e1, e2, e3);
