@@ -355,8 +355,12 @@ struct RRRank {
 // workgroup hammering the LDS), but the ISA does not promise it, so this variant is only selected after the
 // same property has been re-verified on the device at first use (se_rank_rows: probe kernel) and can be
 // switched off with SE_RANK_SAFE=1.  ~5 VALU per key and pass instead of ~41.
-constexpr int RR_GH = 8;    // returning adds in flight per lane
-constexpr int RR_HW_BITS = 11;   // digit width of the hardware-ordered variant: 3 passes (11 + 11 + 10 bits) instead of 4
+#ifndef SE_RR_GH
+#define SE_RR_GH 8
+#endif
+constexpr int RR_GH = SE_RR_GH;    // returning adds in flight per lane
+constexpr int RR_HW_BITS = 11;   // digit width of the hardware-ordered variant: 3 passes (11 + 11 + 10 bits; rows of >= 32,768 columns: 10 + 10 + 12) instead of 4
+constexpr int RR_WIDE_WORDS = 2048;   // counter words per wave of the 12-bit pass (4096 packed 16-bit counters)
 // Counters are 16 bits wide, two per LDS word (8 waves x 2048 digits x 2 B = 32 KB next to the 100 KB exchange
 // buffer): a wave holds at most 64 x 104 keys and a destination is < 53,248, so neither half can carry into the
 // other.  The returning add is done on the word with the increment shifted into the digit's half.
@@ -389,7 +393,7 @@ struct RRRankHW {
             if constexpr (PEEL) {
                 if (peel) {                          // wave-uniform branch: the other passes skip the group bookkeeping
                     // lanes sharing lane 0's digit (most significant pass only) are ranked by one ballot and ONE add of the group size
-                    const uint32_t d = w | (h << 10);
+                    const uint32_t d = w | (h << 11);   // (w < 2048)
                     const bool in = (d == (uint32_t)__builtin_amdgcn_readfirstlane((int)d));
                     const uint64_t m = __ballot(in);
                     if (in) g = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -442,29 +446,32 @@ __global__ __launch_bounds__(RR_THREADS, 2) void rank_rows_reg_kernel(const floa
     // two launches per call when the detector is used: the variant that does not match the flag leaves at once
     if (skew_flag && ((*skew_flag != 0) != PEEL)) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char rr_raw[];
-    constexpr int BITS = HWORD ? RR_HW_BITS : 8;                        // digit width
+    constexpr int BITS = HWORD ? RR_HW_BITS : 8;                        // digit width (narrow passes)
     constexpr int NB = 1 << BITS;
-    constexpr int NPASS = (32 + BITS - 1) / BITS;                       // 3 (11 + 11 + 10) or 4
+    constexpr int NPASS = (32 + BITS - 1) / BITS;                       // 3 or 4
     constexpr int CNT_WORDS = HWORD ? NB / 2 : NB;                      // LDS words per wave: packed 16-bit or 32-bit counters
+    // WIDE: digits of 10 + 10 + 12 bits instead of 11 + 11 + 10.  The most significant digit of real distance rows is skewed (sign,
+    // exponent, 1-2 mantissa bits: ~20 values, 8 lanes of a wave step on the same counter = 29 instead of 8 cycles per returning add);
+    // two more mantissa bits quarter the multiplicity.  Its 8 x 4096 16-bit counters (64 KB) do not fit next to the exchange buffer, so
+    // they ALIAS it: the buffer is idle from the last exchange read of the previous pass to the first scatter of this one (two extra
+    // barriers per row keep the other waves' reads / counter look-ups on the right side of that reuse).
+    constexpr bool WIDE = HWORD && ((size_t)RR_THREADS * ITEMS * sizeof(uint16_t) >= (size_t)RR_WAVES * RR_WIDE_WORDS * sizeof(uint32_t));
     uint32_t *wcnt = reinterpret_cast<uint32_t *>(rr_raw);              // [RR_WAVES][CNT_WORDS]
     uint32_t *wave_tot = wcnt + RR_WAVES * CNT_WORDS;                   // [8] (+pad)
     uint16_t *xbuf = reinterpret_cast<uint16_t *>(wave_tot + 16);       // [RR_THREADS * ITEMS]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wpos0 = wave * (ITEMS * WAVE) + lane;                     // position of (step s) = wpos0 + 64 s
-    uint32_t *mycnt = wcnt + wave * CNT_WORDS;
-    const uint32_t cb = lds_off(mycnt);                                 // this wave's digit counters, byte address
     const uint32_t xb = lds_off(xbuf);                                  // exchange buffer, byte address
     const uint32_t rb = xb + 2u * (uint32_t)wpos0;                      // this lane's read slot of step 0
 #define RR_DST(IR) (xb + (((IR) & 0xFFFFu) << 1))
     // tuning aid (SE_RR_PROFILE=1): shader-clock cycles per phase, summed over every workgroup's wave 0
-    uint64_t t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last = PROF ? __builtin_amdgcn_s_memtime() : 0;
-#define RR_T(i) if constexpr (PROF) { const uint64_t now = __builtin_amdgcn_s_memtime(); t_acc[i] += now - t_last; t_last = now; } else { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
+    uint64_t t_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_pp[24] = {}, t_last = PROF ? __builtin_amdgcn_s_memtime() : 0;
+#define RR_T(i) if constexpr (PROF) { lds_wait(); __syncthreads(); /* phase times are workgroup-wide: include the skew between the waves */ const uint64_t now = __builtin_amdgcn_s_memtime(); t_acc[i] += now - t_last; if (rr_pass >= 0) t_pp[(i) * 3 + rr_pass] += now - t_last; t_last = now; } else { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
 
-    // The row loop is software-pipelined over HBM: the NEXT row's distances are loaded into the key registers as soon as the
-    // last pass no longer needs them (after its D phase) and land behind the final index exchange; they are canonicalised --
-    // the only wait on vector memory in the loop -- BEFORE this row's ranks are stored, so the stores drain during the next
-    // row's LDS phases instead of in front of its first use of a loaded key (vmcnt counts loads and stores together:
-    // waiting for loads issued after the stores cost ~25 % of the kernel, the time HBM needs to absorb 200-400 KB per CU).
+    // The row loop is software-pipelined over HBM: the NEXT row is prefetched into L2 during the last pass (one dword per 128-byte
+    // line), loaded into the key registers right after it -- BEFORE this row's rank stores are issued, so the memory pipeline serves
+    // the loads first -- and canonicalised after the write-out, which covers most of their latency.  (With the loads issued after
+    // the stores, as in the first version, every row first waited for HBM to absorb its 200-400 KB: 29 % of the kernel.)
     uint32_t key[ITEMS], ir[ITEMS];   // ir = (index << 16) | (within-wave rank, then destination)
     uint32_t ring[RR_RING];
 #define RR_LOAD_ONE(DROW, WPOS, S)                                                                                   \
@@ -494,6 +501,7 @@ __global__ __launch_bounds__(RR_THREADS, 2) void rank_rows_reg_kernel(const floa
         RR_CANON()
     }
     uint32_t pf_sink = 0;
+    [[maybe_unused]] int rr_pass = -1;   // profile build: pass index for the per-pass phase times
     for (int64_t row = blockIdx.x; row < Q; row += gridDim.x) {
         const bool more = row + gridDim.x < Q;
         {
@@ -504,21 +512,29 @@ __global__ __launch_bounds__(RR_THREADS, 2) void rank_rows_reg_kernel(const floa
         }
 #pragma unroll 1
         for (int p = 0; p < NPASS; p++) {
-            const int shift = p * BITS;
-            const int end = (shift + BITS < 32) ? shift + BITS : 32;        // bits [0, end) are sorted after this pass
-            [[maybe_unused]] const uint32_t dmask = (1u << (end - shift)) - 1u;
-            if (p == NPASS - 1 && more) {
-                // L2 prefetch of this workgroup's NEXT row (one workgroup per CU: nothing else hides its 200 KB of HBM latency): one dword
-                // per 128-byte line, all into one sink register that stays reserved until the loads after the pass loop have been waited for
-                const char *nrow = (const char *)(pdist + (row + gridDim.x) * ldp);
-                const uint32_t row_bytes = (uint32_t)N * 4u;
-                for (uint32_t off = (uint32_t)tid * 128u; off < row_bytes; off += RR_THREADS * 128u)
-                    asm volatile("global_load_dword %0, %1, off" : "=v"(pf_sink) : "v"(nrow + off) : "memory");
-            }
+            const int shift = WIDE ? p * 10 : p * BITS;
+            rr_pass = p;
+            const int end = WIDE ? (p == 2 ? 32 : shift + 10) : ((shift + BITS < 32) ? shift + BITS : 32);   // bits [0, end) are sorted after this pass
+            const bool wide = WIDE && p == 2;                               // 12-bit digit, counters aliased onto the exchange buffer
             // ---- R: stable rank inside the wave ----
+            // counters of this pass: the wave's slice of the dedicated region, or (wide pass) of the idle exchange buffer
+            uint32_t *pcnt = wcnt;              // [RR_WAVES][pcw]
+            int pcw = CNT_WORDS;
+            if (wide) {
+                __syncthreads();                // every wave has finished reading the exchange buffer (previous pass's key exchange)
+                pcnt = reinterpret_cast<uint32_t *>(xbuf);
+                pcw = RR_WIDE_WORDS;
+            }
+            uint32_t *mycnt = pcnt + wave * pcw;
+            const uint32_t cb = lds_off(mycnt);                             // this wave's digit counters, byte address
 #pragma unroll
             for (int j = 0; j < CNT_WORDS / WAVE; j++) mycnt[j * WAVE + lane] = 0;
-            [[maybe_unused]] const uint32_t wlo = 10u, whi = (uint32_t)(end - shift) - 10u, hshift = (uint32_t)(shift + 10) & 31u;   // HWORD digit split
+            if (wide) {
+#pragma unroll
+                for (int j = CNT_WORDS / WAVE; j < RR_WIDE_WORDS / WAVE; j++) mycnt[j * WAVE + lane] = 0;
+            }
+            // HWORD digit split: low wlo bits = counter word, the rest (0 or 1 bit) = half
+            [[maybe_unused]] const uint32_t wlo = wide ? 11u : 10u, whi = (uint32_t)(end - shift) - wlo, hshift = (uint32_t)(shift + (int)wlo) & 31u;
             if constexpr (HWORD) {
                 uint32_t hr[RR_GH], hs[RR_GH], hg[RR_GH];
                 RRRankHW<ITEMS, PEEL>::run(ir, key, hr, hs, hg, (uint32_t)shift, hshift, wlo, whi, cb, lane, p == NPASS - 1);
@@ -549,39 +565,71 @@ __global__ __launch_bounds__(RR_THREADS, 2) void rank_rows_reg_kernel(const floa
                 }
             }
             } else {
-                // 2048 digits x 8 waves of 16-bit counts, two per word (low half: digit w, high half: digit 1024 + w).  Thread t owns the
-                // words 2t and 2t+1 of every wave (one 8-byte LDS access each) and all arithmetic stays PACKED: a half never exceeds the
-                // 53,248 keys of a row, so the low halves cannot carry into the high ones.
-                uint32_t T0 = 0, T1 = 0;   // per-word totals over the waves
+                // 8 waves x pcw words of 16-bit counts, two per word (low half: digit w, high half: digit pcw + w).  Thread t owns the
+                // words 2t and 2t+1 of every wave (one 8-byte LDS access each; the 12-bit pass: also 1024 + 2t and 1025 + 2t) and all
+                // arithmetic stays PACKED: a half never exceeds the 53,248 keys of a row, so the low halves cannot carry into the high ones.
+                uint32_t T0 = 0, T1 = 0, U0 = 0, U1 = 0;   // per-word totals over the waves (U: second word group of the wide pass)
 #pragma unroll
                 for (int w = 0; w < RR_WAVES; w++) {
-                    const uint2 v = *reinterpret_cast<const uint2 *>(wcnt + w * CNT_WORDS + 2 * tid);
+                    const uint2 v = *reinterpret_cast<const uint2 *>(pcnt + w * pcw + 2 * tid);
                     T0 += v.x; T1 += v.y;
                 }
-                uint32_t wtot;
+                if (wide) {
+                    __builtin_amdgcn_sched_barrier(0);   // one word group at a time: 2 x ITEMS registers are live across the scan
+#pragma unroll
+                    for (int w = 0; w < RR_WAVES; w++) {
+                        const uint2 v = *reinterpret_cast<const uint2 *>(pcnt + w * pcw + CNT_WORDS + 2 * tid);
+                        U0 += v.x; U1 += v.y;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                uint32_t wtot, wtot2 = 0, ex2 = 0;
                 uint32_t ex = wave_excl_scan(T0 + T1, wtot);   // both halves scanned at once
-                if (lane == 63) wave_tot[wave] = wtot;
+                if (wide) ex2 = wave_excl_scan(U0 + U1, wtot2);
+                if (lane == 63) { wave_tot[wave] = wtot; wave_tot[RR_WAVES + wave] = wtot2; }
                 __syncthreads();
-                uint32_t all = 0;
+                uint32_t all = 0, all2 = 0;
 #pragma unroll
                 for (int w = 0; w < RR_WAVES; w++) {
-                    const uint32_t wt = wave_tot[w];
-                    all += wt;
+                    const uint32_t wt = wave_tot[w], wt2 = wave_tot[RR_WAVES + w];
+                    all += wt; all2 += wt2;
                     ex += (w < wave) ? wt : 0u;
+                    ex2 += (w < wave) ? wt2 : 0u;
                 }
-                ex += all << 16;           // the high-half digits follow ALL low-half digits
+                ex2 += all;                        // the second word group follows the whole first group
+                const uint32_t hi = (all + all2) << 16;   // the high-half digits follow ALL low-half digits
+                ex += hi; ex2 += hi;
                 // digit-major / wave-minor: counts -> first destination of (wave, digit), written back in place
                 uint32_t s0 = ex, s1 = ex + T0;
 #pragma unroll
                 for (int w = 0; w < RR_WAVES; w++) {
-                    uint2 *wp = reinterpret_cast<uint2 *>(wcnt + w * CNT_WORDS + 2 * tid);
+                    uint2 *wp = reinterpret_cast<uint2 *>(pcnt + w * pcw + 2 * tid);
                     const uint2 v = *wp;
                     *wp = make_uint2(s0, s1);
                     s0 += v.x; s1 += v.y;
                 }
+                if (wide) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    s0 = ex2; s1 = ex2 + U0;
+#pragma unroll
+                    for (int w = 0; w < RR_WAVES; w++) {
+                        uint2 *wp = reinterpret_cast<uint2 *>(pcnt + w * pcw + CNT_WORDS + 2 * tid);
+                        const uint2 v = *wp;
+                        *wp = make_uint2(s0, s1);
+                        s0 += v.x; s1 += v.y;
+                    }
+                }
             }
             __syncthreads();
             RR_T(2)
+            if (p == NPASS - 1 && more) {
+                // L2 prefetch of this workgroup's NEXT row (one workgroup per CU: nothing else hides its 200 KB of HBM latency): one dword
+                // per 128-byte line, all into one sink register that stays reserved until the loads after the pass loop have been waited for
+                const char *nrow = (const char *)(pdist + (row + gridDim.x) * ldp);
+                const uint32_t row_bytes = (uint32_t)N * 4u;
+                for (uint32_t off = (uint32_t)tid * 128u; off < row_bytes; off += RR_THREADS * 128u)
+                    asm volatile("global_load_dword %0, %1, off" : "=v"(pf_sink) : "v"(nrow + off) : "memory");
+            }
             // ---- X: destinations, then the 2-byte exchanges ----
 #pragma unroll
             for (int s0 = 0; s0 < ITEMS; s0 += 8) {
@@ -600,6 +648,7 @@ __global__ __launch_bounds__(RR_THREADS, 2) void rank_rows_reg_kernel(const floa
                     }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if (wide) __syncthreads();   // the scatter below overwrites the (aliased) counters other waves may still be looking up
             RR_T(3)
 #pragma unroll
             for (int s = 0; s < ITEMS; s++) { opaque(ir[s]); lds_st16_hi(RR_DST(ir[s]), ir[s]); }           // index
@@ -630,9 +679,12 @@ __global__ __launch_bounds__(RR_THREADS, 2) void rank_rows_reg_kernel(const floa
             // (the next pass's barriers order these reads before its first exchange write)
         }
 #undef RR_DST
+        rr_pass = -1;
         // ---- the exchange buffer now holds the ranking: canonicalise the next row's keys (waits for its loads), then stream the ranks out ----
         // (the loads sit after the pass loop, not inside its last iteration: a re-definition of the key registers on the `break` path makes
-        // hipcc copy all ITEMS index registers there; the row was prefetched into L2 during the last pass)
+        // hipcc copy all ITEMS index registers there, and a separate straight-line instance of the last pass -- measured, DESIGN.md 5.2 --
+        // pushes the 98-key build into scratch; the row was prefetched into L2 during the last pass.  They are issued BEFORE the rank
+        // stores and waited for after them: the memory pipeline serves them first and the write-out covers most of their latency.)
         {
             const float *drow = pdist + (more ? row + gridDim.x : row) * ldp;
             int wpos = wpos0;
@@ -640,9 +692,6 @@ __global__ __launch_bounds__(RR_THREADS, 2) void rank_rows_reg_kernel(const floa
 #pragma unroll
             for (int s = 0; s < ITEMS; s++) RR_LOAD_ONE(drow, wpos, s)
         }
-        RR_CANON()
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf_sink) : : "memory");   // prefetch dwords landed too: the sink register is free again, nothing is outstanding
-        RR_T(0)
         if (idx64) {
             int64_t *o = (int64_t *)rank + row * ldr;
             // (the next row's keys are live: no unrolling, the LDS read of the next step is issued before this step's stores instead)
@@ -681,10 +730,16 @@ __global__ __launch_bounds__(RR_THREADS, 2) void rank_rows_reg_kernel(const floa
             }
         }
         RR_T(7)
+        RR_CANON()
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf_sink) : : "memory");   // prefetch dwords landed too: the sink register is free again, nothing is outstanding
+        RR_T(0)
         // (the next row's pass-0 barriers order these reads before its first exchange write)
     }
     if (PROF && tid == 0)
-        for (int i = 0; i < 8; i++) atomicAdd(&prof[i], (unsigned long long)t_acc[i]);
+    {
+        for (int i = 0; i < 12; i++) atomicAdd(&prof[i], (unsigned long long)t_acc[i]);
+        for (int i = 0; i < 24; i++) atomicAdd(&prof[12 + i], (unsigned long long)t_pp[i]);
+    }
 #undef RR_T
 }
 
@@ -712,15 +767,14 @@ static bool rank_use_tiled(int64_t n)
 // digit over 3 rows x 1024 evenly spaced columns; flag = 1 when one value holds >= 30 % of them.  The two kernel variants launched
 // behind it read the flag and the one it does not select returns immediately -- no host round trip.
 __global__ __launch_bounds__(256) void rank_skew_detect_kernel(const float *__restrict__ pdist, int64_t ldp, int64_t Q, int N,
-                                                               uint32_t *__restrict__ flag)
+                                                               int shift, uint32_t *__restrict__ flag)
 {
-    constexpr int NBIN = 1 << (32 - 2 * RR_HW_BITS);   // values of the most significant digit (1024)
+    constexpr int NBIN = 4096;   // values of the most significant digit: 1024 (10 bits, shift 22) or 4096 (12 bits, shift 20)
     __shared__ uint32_t hist[NBIN];
     __shared__ uint32_t best;
     for (int i = threadIdx.x; i < NBIN; i += 256) hist[i] = 0;
     if (threadIdx.x == 0) best = 0;
     __syncthreads();
-    const int shift = 2 * RR_HW_BITS;                  // first bit of the most significant digit (22)
     const int cols = N < 1024 ? N : 1024;
     for (int r = 0; r < 3; r++) {
         const int64_t row = (r == 0) ? 0 : (r == 1 ? Q / 2 : Q - 1);
@@ -761,13 +815,13 @@ static int launch_rank_reg_variant(const float *pdist, int64_t ldp, int64_t q, i
     const int vec_ok = ((((uintptr_t)rank) & 15) == 0) && ((ldr * esz) % 16 == 0);
     unsigned long long *prof = nullptr;
     if (profile && ITEMS == 98) {
-        SE_HIP_CHECK(hipMalloc((void **)&prof, 8 * sizeof(unsigned long long)));
-        SE_HIP_CHECK(hipMemsetAsync(prof, 0, 8 * sizeof(unsigned long long), s));
+        SE_HIP_CHECK(hipMalloc((void **)&prof, 36 * sizeof(unsigned long long)));
+        SE_HIP_CHECK(hipMemsetAsync(prof, 0, 36 * sizeof(unsigned long long), s));
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(RR_THREADS), lds, s, pdist, ldp, q, n, rank, ldr, idx64, vec_ok, prof, skew_flag);
     SE_LAUNCH_CHECK();
     if (prof) {
-        unsigned long long h[8];
+        unsigned long long h[36];
         SE_HIP_CHECK(hipStreamSynchronize(s));
         SE_HIP_CHECK(hipMemcpy(h, prof, sizeof(h), hipMemcpyDeviceToHost));
         SE_HIP_CHECK(hipFree(prof));
@@ -777,7 +831,9 @@ static int launch_rank_reg_variant(const float *pdist, int64_t ldp, int64_t q, i
         if (tot > 0) {
             fprintf(stderr, "[se_rank_rows profile] ITEMS=%d hw=%d peel=%d grid=%lld:", ITEMS, (int)HW, (int)PEEL, (long long)grid);
             for (int i = 0; i < 8; i++) fprintf(stderr, " %s %.1f%%", names[i], 100.0 * (double)h[i] / tot);
-            fprintf(stderr, "  (%.0f cycles per row)\n", tot / (double)q);
+            fprintf(stderr, "  (%.0f cycles per row)\n[se_rank_rows profile] cycles per row by phase and pass:", tot / (double)q);
+            for (int i = 1; i < 7; i++) fprintf(stderr, " %s %.0f/%.0f/%.0f", names[i], (double)h[12 + 3 * i] / (double)q, (double)h[13 + 3 * i] / (double)q, (double)h[14 + 3 * i] / (double)q);
+            fprintf(stderr, "\n");
         }
     }
     return SE_OK;
@@ -796,7 +852,9 @@ static int launch_rank_reg(const float *pdist, int64_t ldp, int64_t q, int n, vo
         return launch_rank_reg_variant<ITEMS, true, false>(pdist, ldp, q, n, rank, idx64, ldr, nullptr, s);
     }
     uint32_t *flag = (uint32_t *)scratch + 16;   // (words 0-1 belong to the capability probe)
-    hipLaunchKernelGGL(rank_skew_detect_kernel, dim3(1), dim3(256), 0, s, pdist, ldp, q, n, flag);
+    // first bit of the most significant digit: 20 for the instantiations whose last pass is 12 bits wide (see WIDE in the kernel), else 22
+    const int top_shift = ((size_t)RR_THREADS * ITEMS * sizeof(uint16_t) >= (size_t)RR_WAVES * RR_WIDE_WORDS * sizeof(uint32_t)) ? 20 : 2 * RR_HW_BITS;
+    hipLaunchKernelGGL(rank_skew_detect_kernel, dim3(1), dim3(256), 0, s, pdist, ldp, q, n, top_shift, flag);
     SE_LAUNCH_CHECK();
     int rc = launch_rank_reg_variant<ITEMS, true, false>(pdist, ldp, q, n, rank, idx64, ldr, flag, s);
     if (rc != SE_OK) return rc;

@@ -51,6 +51,12 @@ def main():
         rk = torch.empty((q, n), dtype=torch.int32, device="cuda")
         med, mn = timeit(lambda: sehip.rank_rows(pd, out=rk), args.reps)
         print("rank q=%d n=%d: median %.3f ms (min %.3f)  %.1f GB/s algorithmic, %.1f Mkeys/s" % (q, n, med, mn, 8.0 * q * n / med / 1e6, q * n / med / 1e3))
+        # the CLI-default Euclidean branch: all-positive distances (skewed top digit -> the group-peeling build)
+        xe = torch.from_numpy(np.random.default_rng(0).standard_normal((n, d)).astype(np.float32)).cuda()
+        sq = sehip.row_sqnorm(xe)
+        pd = sehip.pairwise_dist(xe[:q], xe, metric=sehip.METRIC_EUCLID, sqa=sq[:q], sqb=sq, out=pd)
+        med, mn = timeit(lambda: sehip.rank_rows(pd, out=rk), args.reps)
+        print("rank (Euclidean rows) q=%d n=%d: median %.3f ms (min %.3f)  %.1f GB/s algorithmic" % (q, n, med, mn, 8.0 * q * n / med / 1e6))
     elif args.what == "hprec":
         C = 100
         rng = np.random.default_rng(1)
