@@ -266,10 +266,12 @@ class Trainer(object):
             restore()
             self._g_logs = {}
             ga = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(ga):
+            # multi-process: the RCCL watchdog thread polls events while we capture; only this thread's calls may invalidate the capture
+            mode = dict(capture_error_mode='thread_local') if self.world > 1 else {}
+            with torch.cuda.graph(ga, **mode):
                 self._g_loss = self._eager_core(self._sX, sy, self._g_logs)
             gb = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gb):
+            with torch.cuda.graph(gb, **mode):
                 self.apply_update(1.0 / self.world if hooks_were else 1.0, lr_tensor=self._lr_t, count=False)
             if validate:
                 self._eager_core(self._sX, sy, {})
