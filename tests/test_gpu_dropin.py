@@ -3,6 +3,7 @@ evaluate_retrieval.pairwise_retrieval, utils losses/metrics, one training step o
 import glob
 import os
 import pickle
+import sys
 
 import numpy as np
 import pytest
@@ -13,6 +14,7 @@ from oracle import retrieval_oracle as ro
 
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(GOLDEN, "retrieval_*.npz"))))
@@ -244,3 +246,50 @@ def test_evaluate_retrieval_cli_end_to_end(tmp_path, capsys):
                                        compute_ap=True, all_ids=list(range(len(labels))))
     for m, v in want.items():
         assert perf["run"][m] == pytest.approx(v, rel=1e-10, abs=1e-10), m
+
+
+# ---------------------------------------------------------------- world_size 2 on ONE GPU (gloo): the N > 1 graph-mode step
+
+def _graph_dp_worker(rank, world, port, out):
+    import torch.distributed as dist
+    for p in (os.path.join(ROOT, "semantic-embeddings_amd"), ROOT):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)     # RCCL refuses two ranks on one device; gloo all-reduces CUDA tensors
+    torch.cuda.set_device(0)
+    import utils
+    from datasets import SyntheticGenerator
+    from engine import Trainer, backbone_mode
+    E = np.load(os.path.join(GOLDEN, "embeddings.npz"))["cifar100_unitsphere"]
+    Ed = torch.from_numpy(E.astype(np.float32)).cuda()
+    adt, fmt = backbone_mode("resnet-32")
+    torch.manual_seed(0)
+    model = utils.build_network(100, "resnet-32", classification=True, no_softmax=True, input_channels=3).cuda()
+    tr = Trainer(model, {"l2norm": (utils.CosineEmbeddingLoss(Ed), 1.0)}, {"l2norm": [utils.nn_accuracy(Ed, dot_prod_sim=True)]},
+                 lr=0.05, clipnorm=10.0, autocast_dtype=adt, memory_format=fmt)
+    assert tr.world == 2 and tr.reducer.enabled
+    gen = SyntheticGenerator(100, 32, 3, 256, 32)
+    seq = gen.train_sequence(32, shuffle=False, rank=rank, world_size=world)
+    ok = tr.enable_graphs(*seq[0])
+    logs = {}
+    losses = [float(tr.train_step(*seq[i % len(seq)], logs)) for i in range(4)]
+    torch.cuda.synchronize()
+    flat = tr.flat.flat_p.detach().cpu()
+    both = [None, None]
+    dist.all_gather_object(both, flat.numpy().tobytes())
+    if rank == 0:
+        torch.save({"ok": ok, "same": both[0] == both[1], "finite": bool(np.isfinite(losses).all()), "mode": tr._graph is not None}, out)
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_training_graph_mode_world2_keeps_ranks_in_sync(tmp_path):
+    """Two processes (gloo) on the one GPU: capture + agreement all-reduce + graph A | eager all-reduce | graph B must leave
+    both ranks with bit-identical parameters, like the eager bucketed path does."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "g.pt")
+    mp.spawn(_graph_dp_worker, args=(2, 29637, out), nprocs=2, join=True)
+    got = torch.load(out)
+    assert got["ok"] and got["mode"] and got["same"] and got["finite"], got
