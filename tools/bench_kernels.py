@@ -27,7 +27,7 @@ def timeit(fn, reps):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["pdist", "rank", "loss", "topk", "hprec"])
+    ap.add_argument("what", choices=["pdist", "rank", "loss", "topk", "hprec", "shard"])
     ap.add_argument("--n", type=int, default=50000)
     ap.add_argument("--q", type=int, default=None)
     ap.add_argument("--d", type=int, default=100)
@@ -75,6 +75,20 @@ def main():
                                                                   ahp_len=ahp, want_ap=(ahp == 0)), args.reps)
             print("hprec %-22s q=%d n=%d: median %.3f ms (min %.3f)  %.1f GB/s of ranks, %.1f Mranks/s" %
                   (name, qq, n, med, mn, 4.0 * qq * n / med / 1e6, qq * n / med / 1e3))
+    elif args.what == "shard":
+        # BASELINE.json configs[4], one rank's share: 50,000 queries x (1,281,167 / 8) gallery rows, D = 1000, top-251, then the
+        # merge of the 8 all-gathered lists (synthetic: 8 copies with shifted indices)
+        D, Q, NS, K = 1000, args.q or 50000, 160146, args.k
+        g = torch.from_numpy(np.random.default_rng(1).standard_normal((NS, D)).astype(np.float32)).cuda()
+        qq = torch.from_numpy(np.random.default_rng(2).standard_normal((Q, D)).astype(np.float32)).cuda()
+        sehip.normalize_rows_(g); sehip.normalize_rows_(qq)
+        med, mn = timeit(lambda: sehip.retrieve_topk(qq, g, K, metric=sehip.METRIC_COSINE, col_offset=NS), max(2, args.reps // 2))
+        print("shard retrieve_topk q=%d n=%d d=%d k=%d: median %.1f ms (min %.1f)  %.1f Mpairs/s, %.1f TFLOP/s (fp32 MFMA)" %
+              (Q, NS, D, K, med, mn, Q * NS / med / 1e3, 2.0 * Q * NS * D / med / 1e9))
+        od, oi = sehip.retrieve_topk(qq, g, K, metric=sehip.METRIC_COSINE)
+        dd = torch.stack([od + 1e-3 * r for r in range(8)]); ii = torch.stack([oi + NS * r for r in range(8)])
+        med, mn = timeit(lambda: sehip.topk_merge(dd, ii), args.reps)
+        print("topk_merge parts=8 q=%d k=%d: median %.3f ms  (all-gather payload %.1f MB per rank)" % (Q, K, med, Q * K * 8 / 1e6))
     elif args.what == "topk":
         pd = sehip.pairwise_dist(x[:q], x, metric=sehip.METRIC_COSINE)
         med, mn = timeit(lambda: sehip.topk_rows(pd, args.k), args.reps)
