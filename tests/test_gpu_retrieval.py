@@ -224,6 +224,33 @@ def test_rank_rows_ballot_kernel_in_subprocess():
     assert "hardware-ordered" not in out.stdout
 
 
+@pytest.mark.parametrize("peel", ["0", "1"])
+def test_rank_rows_pinned_peel_variants_in_subprocess(peel):
+    """Both builds of the hardware-ordered kernel (plain / group-peeling last pass) on every row shape, whatever the skew
+    detector would choose: SE_RANK_PEEL pins the build (read once per process, hence the subprocess).  Long rows use
+    the 12-bit last digit whose counters alias the exchange buffer; all-positive rows make lane 0's digit group large."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np, torch\n"
+        "sys.path[:0] = %r\n"
+        "import sehip\n"
+        "from oracle import retrieval_oracle as ro\n"
+        "rng = np.random.default_rng(5)\n"
+        "for n in (700, 5000, 20481, 32768, 40961, 50000, 53248):\n"
+        "    pd = rng.standard_normal((4, n)).astype(np.float32)\n"
+        "    pd[1] = 150.0 + 30.0 * np.abs(pd[1])\n"                     # Euclidean-like: one exponent, all positive
+        "    pd[2] = rng.integers(0, 3, size=n).astype(np.float32)\n"    # three values: huge tie groups
+        "    pd[3, ::7] = np.nan\n"
+        "    got = sehip.rank_rows(torch.from_numpy(pd).cuda()).cpu().numpy()\n"
+        "    assert np.array_equal(got, ro.canon_rank_rows(pd)), n\n"
+        "print('peel-ok')\n"
+    ) % ([PKG_DIR, ROOT_DIR],)
+    env = dict(os.environ, SE_RANK_PEEL=peel)
+    out = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert out.returncode == 0 and "peel-ok" in out.stdout, out.stdout
+
+
 def test_rank_rows_many_rows_persistent_grid(sehip):
     """More rows than resident workgroups: the persistent row loop re-uses LDS across rows."""
     pd = gauss(1500, 2500, seed=11)
