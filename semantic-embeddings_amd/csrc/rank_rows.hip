@@ -227,12 +227,11 @@ __global__ __launch_bounds__(RK_THREADS) void rank_rows_kernel(const float *__re
 //   * position p of the current arrangement lives in wave p / (64 ITEMS), step (p / 64) % ITEMS,
 //     lane p % 64; positions >= N hold padding keys 0xFFFFFFFF whose initial position is behind
 //     every real key, so stability keeps them last and they are never written out;
-//   * per pass: (R) stable within-wave rank of every key by wave multisplit (8 ballots) + one
-//     returning LDS add per digit group on the wave's private counters; (S) digit-major /
-//     wave-minor scan of the 8 x 256 counters; (X) in-place exchange through a 2-byte-per-key LDS
-//     buffer (160 KB of LDS cannot hold 4 B x 50k keys): the 16-bit index, then the key halves
-//     that later passes still need (pass 0: both, passes 1-2: the high half, pass 3: none) --
-//     8 two-byte exchanges per key instead of 12;
+//   * per pass: (R) stable within-wave rank of every key on the wave's private LDS counters -- ONE returning add per key
+//     (hardware-ordered build: 3 passes of 11 + 11 + 10 or 10 + 10 + 12 bits) or an 8-ballot wave multisplit + one add per
+//     digit group (guaranteed-order build: 4 passes of 8 bits); (S) digit-major / wave-minor scan of the counters;
+//     (X) in-place exchange through a 2-byte-per-key LDS buffer (160 KB of LDS cannot hold 4 B x 50k keys): the 16-bit
+//     index, then the key halves that later passes still need -- 6 (8) two-byte exchanges per key instead of 9 (12);
 //   * indices travel as 16 bits (N <= 65536 by construction) packed with the 16-bit destination;
 //   * after the last pass the exchange buffer IS the ranking: it is streamed to HBM with 16-byte
 //     stores.
