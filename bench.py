@@ -214,6 +214,9 @@ def main():
     if args.workload == "train":
         from train_bench import bench_train
         out = bench_train(args, rank, world)
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
+            from train_bench import cpu_baseline_train
+            out["cpu_baseline"] = cpu_baseline_train(args)
     else:
         out, feats_h = bench_retrieval(args, rank, world)
         if args.with_train:
@@ -222,8 +225,14 @@ def main():
                 out["train"] = bench_train(args, rank, world)
             except Exception as e:   # the retrieval line must survive a training-side failure
                 out["train"] = {"error": "%s: %s" % (type(e).__name__, e)}
-        if rank == 0 and not args.no_cpu_baseline:
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:      # reported baselines: rank 0 at N = 1 only, bounded samples
             out["cpu_baseline"] = cpu_baseline_retrieval(args, feats_h)
+            if args.with_train and "error" not in out["train"]:
+                try:
+                    from train_bench import cpu_baseline_train
+                    out["train"]["cpu_baseline"] = cpu_baseline_train(args)
+                except Exception as e:
+                    out["train"]["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -86,3 +86,32 @@ def bench_train(args, rank, world):
                        "backbone": "%s, %s" % ("fp32" if adt is None else "bf16 autocast", "NCHW" if fmt == torch.contiguous_format else "channels_last"),
                        "step": "2 HIP graphs (fwd+loss+bwd | update) + eager RCCL all-reduce" if graphs else "eager launches"},
             "mean_loss": loss_val}
+
+
+def cpu_baseline_train(args, steps=3):
+    """CPU restatement of the reference training step on the host cores (Keras/TF are absent, so this is the
+    same PyTorch backbone + the plain-PyTorch cosine loss, fp32, all host threads; "port", not "reference")."""
+    import torch.nn.functional as F
+    import utils
+    from engine import Trainer
+    arch = args.arch
+    classes, size = (200, 224) if arch == "resnet-50" else (100, 32)
+    emb = torch.from_numpy(load_embedding(classes).astype(np.float32))
+    torch.manual_seed(0)
+    model = utils.build_network(classes, arch, input_channels=3)
+
+    def loss(y, x):                                   # utils.py:125-127 + :44-46 in plain PyTorch
+        return 1.0 - (F.normalize(x.float(), dim=-1, eps=1e-6) * emb[y]).sum(-1)
+    l2_of = {id(p): model.regularizer for p in model.regularized_parameters()} if getattr(model, "regularizer", 0) else {}
+    tr = Trainer(model, {"l2norm": (loss, 1.0)}, {}, lr=0.1, momentum=0.9, clipnorm=10.0, l2_of=l2_of, autocast_dtype=None)
+    B = args.batch
+    g = torch.Generator().manual_seed(0)
+    X = torch.randn(B, 3, size, size, generator=g).contiguous(memory_format=torch.channels_last)
+    y = torch.randint(0, classes, (B,), generator=g)
+    tr.train_step(X, y, {})                           # warm-up (allocations, oneDNN primitive caches)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tr.train_step(X, y, {})
+    dt = time.perf_counter() - t0
+    return {"value": B * steps / dt, "unit": "images/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": "%d steps of the same %s step (batch %d, fp32, PyTorch CPU, %d threads), %.1f s" % (steps, arch, B, torch.get_num_threads(), dt)}
