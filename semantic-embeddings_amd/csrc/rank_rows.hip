@@ -354,6 +354,9 @@ struct RRRank {
 // workgroup hammering the LDS), but the ISA does not promise it, so this variant is only selected after the
 // same property has been re-verified on the device at first use (se_rank_rows: probe kernel) and can be
 // switched off with SE_RANK_SAFE=1.  ~5 VALU per key and pass instead of ~41.
+#ifndef SE_RR_PF
+#define SE_RR_PF 1
+#endif
 #ifndef SE_RR_GH
 #define SE_RR_GH 8
 #endif
@@ -491,6 +494,13 @@ __global__ __launch_bounds__(RR_THREADS, 2) void rank_rows_reg_kernel(const floa
             key[s] = canon_key(__uint_as_float(key[s])) | (uint32_t)((N - 1 - pos) >> 31); /* pos >= N: all ones */   \
         }                                                                                                             \
     }
+#define RR_PREFETCH_NEXT_ROW() \
+    if (p == NPASS - 1 && more) { \
+                const char *nrow = (const char *)(pdist + (row + gridDim.x) * ldp); \
+                const uint32_t row_bytes = (uint32_t)N * 4u; \
+                for (uint32_t off = (uint32_t)tid * 128u; off < row_bytes; off += RR_THREADS * 128u) \
+                    asm volatile("global_load_dword %0, %1, off" : "=v"(pf_sink) : "v"(nrow + off) : "memory"); \
+            }
     if ((int64_t)blockIdx.x < Q) {
         const float *drow = pdist + (int64_t)blockIdx.x * ldp;
         int wpos = wpos0;
@@ -542,6 +552,7 @@ __global__ __launch_bounds__(RR_THREADS, 2) void rank_rows_reg_kernel(const floa
             lds_wait();
             RR_T(1)
             __syncthreads();
+            if (SE_RR_PF == 3) { RR_PREFETCH_NEXT_ROW() }
             // ---- S: counters -> first destination of every (wave, digit) ----
             if constexpr (!HWORD) {
             uint32_t ex = 0;
@@ -621,14 +632,10 @@ __global__ __launch_bounds__(RR_THREADS, 2) void rank_rows_reg_kernel(const floa
             }
             __syncthreads();
             RR_T(2)
-            if (p == NPASS - 1 && more) {
-                // L2 prefetch of this workgroup's NEXT row (one workgroup per CU: nothing else hides its 200 KB of HBM latency): one dword
-                // per 128-byte line, all into one sink register that stays reserved until the loads after the pass loop have been waited for
-                const char *nrow = (const char *)(pdist + (row + gridDim.x) * ldp);
-                const uint32_t row_bytes = (uint32_t)N * 4u;
-                for (uint32_t off = (uint32_t)tid * 128u; off < row_bytes; off += RR_THREADS * 128u)
-                    asm volatile("global_load_dword %0, %1, off" : "=v"(pf_sink) : "v"(nrow + off) : "memory");
-            }
+            // L2 prefetch of this workgroup's NEXT row (one workgroup per CU: nothing else hides its 200 KB of HBM latency): one dword
+            // per 128-byte line, all into one sink register that stays reserved until the loads after the pass loop have been waited for.
+            // SE_RR_PF (build-time tuning aid): 0 = no prefetch, 1 = before the destination phase of the last pass (default), 2 = after it, 3 = before its scan
+            if (SE_RR_PF == 1) { RR_PREFETCH_NEXT_ROW() }
             // ---- X: destinations, then the 2-byte exchanges ----
 #pragma unroll
             for (int s0 = 0; s0 < ITEMS; s0 += 8) {
@@ -647,6 +654,7 @@ __global__ __launch_bounds__(RR_THREADS, 2) void rank_rows_reg_kernel(const floa
                     }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if (SE_RR_PF == 2) { RR_PREFETCH_NEXT_ROW() }
             if (wide) __syncthreads();   // the scatter below overwrites the (aliased) counters other waves may still be looking up
             RR_T(3)
 #pragma unroll
