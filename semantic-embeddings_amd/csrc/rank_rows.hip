@@ -354,6 +354,11 @@ struct RRRank {
 // workgroup hammering the LDS), but the ISA does not promise it, so this variant is only selected after the
 // same property has been re-verified on the device at first use (se_rank_rows: probe kernel) and can be
 // switched off with SE_RANK_SAFE=1.  ~5 VALU per key and pass instead of ~41.
+#ifndef SE_RR_NT
+#define SE_RR_NT 0   // 1: nontemporal rank stores (build-time tuning aid)
+#endif
+typedef int rr_i32x4 __attribute__((ext_vector_type(4)));
+typedef long long rr_i64x2 __attribute__((ext_vector_type(2)));
 #ifndef SE_RR_PF
 #define SE_RR_PF 1
 #endif
@@ -709,8 +714,13 @@ __global__ __launch_bounds__(RR_THREADS, 2) void rank_rows_reg_kernel(const floa
                 nv = *reinterpret_cast<const uint2 *>(xbuf + (jn < N ? jn : 0));
                 const int64_t e0 = v.x & 0xFFFFu, e1 = v.x >> 16, e2 = v.y & 0xFFFFu, e3 = v.y >> 16;
                 if (vec_ok && j + 3 < N) {
-                    *reinterpret_cast<longlong2 *>(o + j) = make_longlong2(e0, e1);
-                    *reinterpret_cast<longlong2 *>(o + j + 2) = make_longlong2(e2, e3);
+                    if (SE_RR_NT) {
+                        __builtin_nontemporal_store((rr_i64x2){e0, e1}, reinterpret_cast<rr_i64x2 *>(o + j));
+                        __builtin_nontemporal_store((rr_i64x2){e2, e3}, reinterpret_cast<rr_i64x2 *>(o + j + 2));
+                    } else {
+                        *reinterpret_cast<longlong2 *>(o + j) = make_longlong2(e0, e1);
+                        *reinterpret_cast<longlong2 *>(o + j + 2) = make_longlong2(e2, e3);
+                    }
                 } else {
                     o[j] = e0;
                     if (j + 1 < N) o[j + 1] = e1;
@@ -727,7 +737,8 @@ __global__ __launch_bounds__(RR_THREADS, 2) void rank_rows_reg_kernel(const floa
                 nv = *reinterpret_cast<const uint2 *>(xbuf + (jn < N ? jn : 0));
                 const int e0 = v.x & 0xFFFFu, e1 = v.x >> 16, e2 = v.y & 0xFFFFu, e3 = v.y >> 16;
                 if (vec_ok && j + 3 < N) {
-                    *reinterpret_cast<int4 *>(o + j) = make_int4(e0, e1, e2, e3);
+                    if (SE_RR_NT) __builtin_nontemporal_store((rr_i32x4){e0, e1, e2, e3}, reinterpret_cast<rr_i32x4 *>(o + j));
+                    else *reinterpret_cast<int4 *>(o + j) = make_int4(e0, e1, e2, e3);
                 } else {
                     o[j] = e0;
                     if (j + 1 < N) o[j + 1] = e1;
