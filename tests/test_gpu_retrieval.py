@@ -251,6 +251,20 @@ def test_rank_rows_pinned_peel_variants_in_subprocess(peel):
     assert out.returncode == 0 and "peel-ok" in out.stdout, out.stdout
 
 
+@pytest.mark.parametrize("n", [300, 5000, 50000])
+def test_rank_rows_special_values(sehip, n):
+    """-0.0 ties with +0.0, denormals keep their order, infinities sit at the ends, every NaN (either sign, any payload) is last --
+    all tie groups in index order.  (The register-resident kernel builds its keys with its own 6-instruction mapping.)"""
+    rng = np.random.default_rng(n)
+    specials = np.array([0.0, -0.0, 1e-45, -1e-45, 1.17549435e-38, -1.17549435e-38, np.inf, -np.inf, 3.4028235e38, -3.4028235e38], dtype=np.float32)
+    pd = rng.choice(specials, size=(3, n)).astype(np.float32)
+    pd[1] = np.where(rng.random(n) < 0.5, rng.standard_normal(n).astype(np.float32), pd[1])
+    nanbits = np.array([0x7FC00000, 0xFFC00000, 0x7F800001, 0xFFFFFFFF], dtype=np.uint32).view(np.float32)
+    pd[2, ::5] = rng.choice(nanbits, size=len(pd[2, ::5]))
+    got = sehip.rank_rows(dev(pd)).cpu().numpy()
+    assert np.array_equal(got, ro.canon_rank_rows(pd))
+
+
 def test_rank_rows_many_rows_persistent_grid(sehip):
     """More rows than resident workgroups: the persistent row loop re-uses LDS across rows."""
     pd = gauss(1500, 2500, seed=11)
