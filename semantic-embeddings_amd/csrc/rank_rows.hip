@@ -499,7 +499,7 @@ __global__ __launch_bounds__(RR_THREADS, 2) void rank_rows_reg_kernel(const floa
         /* unconditional load (clamped index; the padding is applied in RR_CANON): a branch around a load makes      \
            hipcc wait for each load before issuing the next */                                                        \
         const int pos = (WPOS) + (S) * WAVE;                                                                          \
-        int gi = pos < N ? pos : N - 1;                                                                               \
+        uint32_t gi = (uint32_t)(pos < N ? pos : N - 1);   /* unsigned: scalar base + 32-bit lane offset addressing */ \
         opaque(gi);                                                                                                   \
         key[S] = __float_as_uint((DROW)[gi]);                                                                         \
     }
