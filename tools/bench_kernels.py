@@ -46,6 +46,11 @@ def main():
             gb = (4.0 * q * n + 4.0 * (q + n) * d) / 1e9
             print("pdist %-16s q=%d n=%d d=%d: median %.3f ms (min %.3f)  %.1f GB/s algorithmic, %.1f TFLOP/s useful" %
                   (name, q, n, d, med, mn, gb / med * 1e3, 2.0 * q * n * d / med / 1e9))
+        xe = torch.from_numpy(np.random.default_rng(0).standard_normal((n, d)).astype(np.float32)).cuda()
+        sq = sehip.row_sqnorm(xe)
+        for name, b in (("Euclid symmetric", xe), ("Euclid general", xe.clone())):
+            med, mn = timeit(lambda: sehip.pairwise_dist(xe[:q], b, metric=sehip.METRIC_EUCLID, sqa=sq[:q], sqb=sq, out=out), args.reps)
+            print("pdist %-16s q=%d n=%d d=%d: median %.3f ms (min %.3f)  %.1f GB/s algorithmic" % (name, q, n, d, med, mn, gb / med * 1e3))
     elif args.what == "rank":
         pd = sehip.pairwise_dist(x[:q], x, metric=sehip.METRIC_COSINE)
         rk = torch.empty((q, n), dtype=torch.int32, device="cuda")
