@@ -408,8 +408,15 @@ struct RRRankHW {
             const uint32_t w = __builtin_amdgcn_ubfe(key[S], shift, wlo);
             const uint32_t h = __builtin_amdgcn_ubfe(key[S], hshift, whi);   // width 0 -> 0
             ca = cb + (w << 2);
-            shv = h << 4;
-            inc = 1u << shv;
+            if constexpr (PEEL) {
+                shv = h << 4;
+                inc = 1u << shv;
+            } else {
+                // no shift amounts: the increment is 1 + 0xFFFF h, and `shv` holds the v_perm_b32 selector that drops the returned
+                // half straight into the low half of ir (bytes [ir3, ir2, r(1 + 2h), r(2h)]): 6 VALU per key instead of 7
+                inc = __umul24(h, 0xFFFFu) + 1u;
+                shv = __umul24(h, 0x0202u) + 0x07060100u;
+            }
             if constexpr (PEEL) {
                 if (peel) {                          // wave-uniform branch: the other passes skip the group bookkeeping
                     // lanes sharing lane 0's digit (most significant pass only) are ranked by one ballot and ONE add of the group size
@@ -426,13 +433,14 @@ struct RRRankHW {
             constexpr int J = S - RR_GH;
             constexpr int younger = ((S < ITEMS ? S : ITEMS) - 1) - J;
             lds_wait_le<younger>(r[SLOT]);
-            uint32_t rank = __builtin_amdgcn_ubfe(r[SLOT], sh[SLOT], 16u);
             if constexpr (PEEL) {
                 const uint32_t lead = (uint32_t)__builtin_amdgcn_readfirstlane((int)r[SLOT]);   // lane 0's counter word before its add
                 const uint32_t own = (grp[SLOT] != 0xFFFFFFFFu) ? lead : r[SLOT];                 // group members use lane 0's word (same digit => same half)
-                rank = __builtin_amdgcn_ubfe(own, sh[SLOT], 16u) + (grp[SLOT] != 0xFFFFFFFFu ? grp[SLOT] : 0u);
+                const uint32_t rank = __builtin_amdgcn_ubfe(own, sh[SLOT], 16u) + (grp[SLOT] != 0xFFFFFFFFu ? grp[SLOT] : 0u);
+                ir[J] = (ir[J] & 0xFFFF0000u) | rank;
+            } else {
+                ir[J] = __builtin_amdgcn_perm(ir[J], r[SLOT], sh[SLOT]);
             }
-            ir[J] = (ir[J] & 0xFFFF0000u) | rank;
             opaque(ir[J]);    // materialise now: nothing but key/ir stays live per key
             opaque(key[J]);   // (and no cached counter address either)
         }
@@ -717,11 +725,13 @@ __global__ __launch_bounds__(RR_THREADS, 2) void rank_rows_reg_kernel(const floa
 #pragma unroll
             for (int s = 0; s < ITEMS; s++) RR_LOAD_ONE(drow, wpos, s)
         }
+        int wt = tid;
+        opaque(wt);   // per-row opaque: the write-out offsets are recomputed here instead of living (spilled) across the whole row loop
         if (idx64) {
             int64_t *o = (int64_t *)rank + row * ldr;
             // (the next row's keys are live: no unrolling, the LDS read of the next step is issued before this step's stores instead)
-            uint2 nv = *reinterpret_cast<const uint2 *>(xbuf + (tid * 4 < N ? tid * 4 : 0));
-            _Pragma("unroll 1") for (int j = tid * 4; j < N; j += RR_THREADS * 4) {
+            uint2 nv = *reinterpret_cast<const uint2 *>(xbuf + (wt * 4 < N ? wt * 4 : 0));
+            _Pragma("unroll 1") for (int j = wt * 4; j < N; j += RR_THREADS * 4) {
                 const uint2 v = nv;
                 const int jn = j + RR_THREADS * 4;
                 nv = *reinterpret_cast<const uint2 *>(xbuf + (jn < N ? jn : 0));
@@ -743,8 +753,8 @@ __global__ __launch_bounds__(RR_THREADS, 2) void rank_rows_reg_kernel(const floa
             }
         } else {
             int32_t *o = (int32_t *)rank + row * ldr;
-            uint2 nv = *reinterpret_cast<const uint2 *>(xbuf + (tid * 4 < N ? tid * 4 : 0));
-            _Pragma("unroll 1") for (int j = tid * 4; j < N; j += RR_THREADS * 4) {
+            uint2 nv = *reinterpret_cast<const uint2 *>(xbuf + (wt * 4 < N ? wt * 4 : 0));
+            _Pragma("unroll 1") for (int j = wt * 4; j < N; j += RR_THREADS * 4) {
                 const uint2 v = nv;
                 const int jn = j + RR_THREADS * 4;
                 nv = *reinterpret_cast<const uint2 *>(xbuf + (jn < N ? jn : 0));
