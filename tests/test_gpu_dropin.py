@@ -248,6 +248,34 @@ def test_evaluate_retrieval_cli_end_to_end(tmp_path, capsys):
         assert perf["run"][m] == pytest.approx(v, rel=1e-10, abs=1e-10), m
 
 
+@pytest.mark.gpu
+def test_learn_image_embeddings_cli_end_to_end(tmp_path, capsys):
+    """The training CLI with the reference's flags on a synthetic dataset: two epochs of ResNet-110-fc against the CIFAR-100
+    unit-sphere class embeddings (HIP loss head, HIP-graph replay of the step, validation, log, dumps), then the dumped
+    features go through evaluate_retrieval.pairwise_retrieval."""
+    import json
+    import learn_image_embeddings as lie
+    import evaluate_retrieval as er
+    E = np.load(os.path.join(GOLDEN, "embeddings.npz"))["cifar100_unitsphere"]
+    emb = str(tmp_path / "emb.pickle")
+    with open(emb, "wb") as f:
+        pickle.dump({"embedding": E, "ind2label": list(range(100)), "label2ind": {i: i for i in range(100)}}, f)
+    feat, wts, logd = str(tmp_path / "feat.pickle"), str(tmp_path / "w.pt"), str(tmp_path / "log")
+    final = lie.main(["--dataset", "synthetic:100x32x192x64", "--data_root", "-", "--embedding", emb, "--architecture", "resnet-110-fc",
+                      "--loss", "inv_corr", "--lr_schedule", "SGD", "--sgd_lr", "0.05", "--epochs", "2", "--batch_size", "32",
+                      "--val_batch_size", "32", "--feature_dump", feat, "--weight_dump", wts, "--log_dir", logd, "--no_progress"])
+    assert np.isfinite(final["loss"]) and 0.0 <= final["max_sim_acc"] <= 1.0, final
+    log = [json.loads(l) for l in open(os.path.join(logd, "training_log.jsonl"))]
+    assert [e["epoch"] for e in log] == [1, 2] and all(np.isfinite(e["loss"]) and np.isfinite(e["val_loss"]) for e in log)
+    assert os.path.getsize(wts) > 1_000_000
+    with open(feat, "rb") as f:
+        dump = pickle.load(f)
+    feats = np.stack([dump["feat"][i] for i in range(64)])
+    assert feats.shape == (64, 100) and np.allclose(np.linalg.norm(feats, axis=-1), 1.0, atol=1e-4)      # the model ends in the l2norm layer
+    ranked = dict(er.pairwise_retrieval(feat, normalize=True, return_generator=False))
+    assert sorted(ranked) == list(range(64)) and all(ranked[i][0] == i and len(ranked[i]) == 64 for i in ranked)
+
+
 # ---------------------------------------------------------------- world_size 2 on ONE GPU (gloo): the N > 1 graph-mode step
 
 def _graph_dp_worker(rank, world, port, out):
