@@ -222,3 +222,23 @@ def test_synthetic_generator_interface():
     assert half[0].shape[0] == 8 and torch.equal(half[1], y[1::2])
     with pytest.raises(NotImplementedError):
         get_data_generator("ilsvrc", ".")
+
+
+def test_cli_parsers_accept_every_reference_flag():
+    """Drop-in CLIs: the option sets of the reference's learn_image_embeddings.py:57-94 (+ utils.py:402-418) and
+    evaluate_retrieval.py:157-174, listed here verbatim (the reference tree is not read at test time)."""
+    import learn_image_embeddings as lie
+    import evaluate_retrieval as er
+    train_flags = ("--dataset --data_root --embedding --architecture --loss --cls_weight --cls_base --lr_schedule --clipgrad --max_decay "
+                   "--nesterov --epochs --batch_size --val_batch_size --snapshot --snapshot_best --initial_epoch --finetune --finetune_init "
+                   "--gpus --read_workers --queue_size --gpu_merge --model_dump --weight_dump --feature_dump --log_dir --no_progress --top_k_acc "
+                   "--sgd_patience --sgd_lr --sgd_min_lr --sgd_schedule --sgdr_base_len --sgdr_mul --sgdr_max_lr --clr_step_len --clr_min_lr "
+                   "--clr_max_lr").split()
+    eval_flags = "--dataset --data_root --hierarchy --is_a --str_ids --classes_from --feat --label --norm --plot_max --prec_type --clip_ahp --csv".split()
+    for parser, flags in ((lie.build_parser(), train_flags), (er.build_parser(), eval_flags)):
+        have = {o for a in parser._actions for o in a.option_strings}
+        assert not [f for f in flags if f not in have], [f for f in flags if f not in have]
+    a = lie.build_parser().parse_args("--dataset CIFAR-100 --data_root /d --embedding e.pickle --architecture resnet-110-fc --loss inv_corr "
+                                      "--lr_schedule SGDR --sgdr_max_lr 0.1 --max_decay 0 --epochs 372 --batch_size 100 --gpus 4 --read_workers 8 "
+                                      "--queue_size 100 --gpu_merge --snapshot s.h5 --model_dump m.h5 --feature_dump f.pickle --top_k_acc 5".split())
+    assert a.architecture == "resnet-110-fc" and a.sgdr_max_lr == 0.1 and a.gpus == 4 and a.top_k_acc == [5]       # the README's CIFAR-100 command line
