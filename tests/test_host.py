@@ -242,3 +242,13 @@ def test_cli_parsers_accept_every_reference_flag():
                                       "--lr_schedule SGDR --sgdr_max_lr 0.1 --max_decay 0 --epochs 372 --batch_size 100 --gpus 4 --read_workers 8 "
                                       "--queue_size 100 --gpu_merge --snapshot s.h5 --model_dump m.h5 --feature_dump f.pickle --top_k_acc 5".split())
     assert a.architecture == "resnet-110-fc" and a.sgdr_max_lr == 0.1 and a.gpus == 4 and a.top_k_acc == [5]       # the README's CIFAR-100 command line
+
+
+def test_bench_traffic_record_matches_the_committed_pmc_profile():
+    """bench.py's roofline.traffic comes from profiles/pmc_traffic.json (rocprofv3 PMC passes it cannot run itself): right shape only,
+    FETCH_SIZE correction applied, close to the algorithmic bytes of the ranking kernel (one read + one write per element)."""
+    import bench
+    tr = bench.pmc_traffic_gb("rank_rows", 50000, 50000, 100)
+    assert tr is not None and os.path.exists(os.path.join(os.path.dirname(bench.__file__), tr["source"].split(" ")[0]))
+    assert 0.95 < tr["bytes"] / 20e9 < 1.15 and abs(tr["read_GB"] + tr["write_GB"] - tr["bytes"] / 1e9) < 1e-6
+    assert bench.pmc_traffic_gb("rank_rows", 1000, 50000, 100) is None and bench.pmc_traffic_gb("nope", 50000, 50000, 100) is None
