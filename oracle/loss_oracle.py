@@ -5,13 +5,15 @@ training-side hot path: L2-normalisation head, cosine loss, its closed-form back
 nearest-class-embedding accuracy metrics.  Only tests/, __graft_entry__.smoke() and bench.py's
 cpu_baseline leg may import this module.
 
-PARITY UNPINNED: the reference evaluates these ops inside Keras 2.2 / TensorFlow 1.x
-(README.md:315-316 of the reference), neither of which is installable here, and the reference
-ships no tests or golden loss values.  The restatement follows the reference
-source line by line (citations below) and TF 1.x's documented ``l2_normalize`` formula
-``x * rsqrt(maximum(sum(square(x)), epsilon))`` with ``epsilon = 1e-12``; it is cross-checked in
-tests/test_oracle.py against an independent torch-float64 autograd formulation, which is NOT the
-reference.
+Parity status: PINNED to the reference's own source lines.  tests/golden/loss_ref_*.npz hold the
+outputs of the reference's utils.py:34-127 and learn_labelembedding.py:17-37, imported UNMODIFIED
+(oracle/ref_import.py) and evaluated on a NumPy ``keras.backend`` stand-in (oracle/keras_stub.py) in
+float32 and float64; tests/test_oracle.py checks every function below against them (float64: to
+1e-12).  What remains a restatement of third-party code is listed in oracle/keras_stub.py:
+``tf.nn.l2_normalize`` (``x * rsqrt(maximum(sum(square(x)), 1e-12))``), ``tf.nn.top_k``,
+``tf.nn.log_softmax`` / ``K.softmax`` and Keras 2.2's ``sparse_categorical_crossentropy`` -- Keras /
+TensorFlow themselves (README.md:315-316 of the reference) are not installable here.  The backward
+formulas are closed forms checked against torch-float64 autograd of the same expressions.
 
 Citations are into /root/reference/.
 """
@@ -150,33 +152,45 @@ def _log_softmax(z):
     return z - np.log(np.exp(z).sum(axis=-1, keepdims=True))
 
 
-def labelembed_loss(out1, out2, tar, targets, tau=2.0, alpha=0.9, beta=0.5, dtype=np.float64):
-    """learn_labelembedding.py:17-37 (forward value only; stop_gradient has no forward effect).
+def _keras_sparse_ce(prob, targets, keps=1e-7):
+    """Keras 2.2 ``K.sparse_categorical_crossentropy(target, output)`` on probabilities: clip to [1e-7, 1 - 1e-7], log,
+    then TF's sparse_softmax_cross_entropy_with_logits -- which renormalises: -(log c_y - log sum_j c_j)."""
+    c = np.clip(prob, keps, 1 - keps)
+    return -(np.log(c[np.arange(len(targets)), targets]) - np.log(c.sum(axis=-1)))
 
-    Keras' sparse_categorical_crossentropy on probabilities clips them to [1e-7, 1 - 1e-7]
-    (Keras 2.2 backend, `_EPSILON`) before the log -- restated here."""
+
+def labelembed_loss(out1, out2, tar, targets, tau=2.0, alpha=0.9, beta=0.5, dtype=np.float64):
+    """learn_labelembedding.py:17-37 (forward value only; stop_gradient has no forward effect)."""
     out1 = np.asarray(out1, dtype=dtype)
     out2 = np.asarray(out2, dtype=dtype)
     tar = np.asarray(tar, dtype=dtype)
     targets = np.asarray(targets).astype(np.int64)
     b = out1.shape[0]
     rows = np.arange(b)
-    keps = 1e-7
 
     out2_prob = _softmax(out2)
     tau2_prob = _softmax(out2 / tau)
     soft_tar = _softmax(tar)
 
-    p1 = np.clip(_softmax(out1), keps, 1 - keps)
-    l_o1_y = -np.log(p1[rows, targets])
+    l_o1_y = _keras_sparse_ce(_softmax(out1), targets)
     pred = out2.argmax(axis=-1)
     mask = (pred == targets).astype(dtype)
     l_o1_emb = -np.sum(soft_tar * _log_softmax(out1), axis=1)
-    p2 = np.clip(out2_prob, keps, 1 - keps)
-    l_o2_y = -np.log(p2[rows, targets])
+    l_o2_y = _keras_sparse_ce(out2_prob, targets)
     l_emb_o2 = -np.sum(tau2_prob * _log_softmax(tar), axis=1) * mask * (b / (mask.sum() + 1e-8))
     l_re = np.maximum(out2_prob[rows, targets] - alpha, 0)
     return beta * l_o1_y + (1 - beta) * l_o1_emb + l_o2_y + l_emb_o2 + l_re
+
+
+def _keras_sparse_ce_grad(sm, hot, keps=1e-7):
+    """d/d logits of `_keras_sparse_ce(softmax(logits), y)`: with in_j = 1{eps < p_j < 1 - eps} (clip_by_value passes the
+    gradient strictly inside the range), S = sum_j clip(p_j), R = sum_j in_j p_j:
+        d_i = in_y (p_i - onehot_i) + p_i (in_i - R) / S."""
+    inside = ((sm > keps) & (sm < 1 - keps)).astype(sm.dtype)
+    S = np.clip(sm, keps, 1 - keps).sum(axis=-1, keepdims=True)
+    R = (inside * sm).sum(axis=-1, keepdims=True)
+    in_y = (inside * hot).sum(axis=-1, keepdims=True)
+    return in_y * (sm - hot) + sm * (inside - R) / S
 
 
 def labelembed_loss_bwd(out1, out2, tar, targets, grad_loss_i, tau=2.0, alpha=0.9, beta=0.5, dtype=np.float64):
@@ -191,17 +205,14 @@ def labelembed_loss_bwd(out1, out2, tar, targets, grad_loss_i, tau=2.0, alpha=0.
     g = np.asarray(grad_loss_i, dtype=dtype)[:, None]
     b, c = out1.shape
     rows = np.arange(b)
-    keps = 1e-7
     hot = np.zeros((b, c), dtype=dtype)
     hot[rows, targets] = 1
     sm1, sm2, smt, sm2t = _softmax(out1), _softmax(out2), _softmax(tar), _softmax(out2 / tau)
-    p1y, p2y = sm1[rows, targets][:, None], sm2[rows, targets][:, None]
-    k1 = ((p1y > keps) & (p1y < 1 - keps)).astype(dtype) * beta
-    k2 = ((p2y > keps) & (p2y < 1 - keps)).astype(dtype)
+    p2y = sm2[rows, targets][:, None]
     kre = np.where(p2y > alpha, p2y, 0.0)
     mask = (out2.argmax(axis=-1) == targets).astype(dtype)
     scale = b / (mask.sum() + 1e-8)
-    d1 = g * (k1 * (sm1 - hot) + (1 - beta) * (sm1 - smt))
-    d2 = g * (k2 * (sm2 - hot) + kre * (hot - sm2))
+    d1 = g * (beta * _keras_sparse_ce_grad(sm1, hot) + (1 - beta) * (sm1 - smt))
+    d2 = g * (_keras_sparse_ce_grad(sm2, hot) + kre * (hot - sm2))
     dt = g * (mask * scale)[:, None] * (smt - sm2t)
     return d1, d2, dt

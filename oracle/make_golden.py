@@ -10,8 +10,17 @@ from /root/reference (see oracle/ref_import.py), on seeded inputs:
 * hierarchy_cifar.npz ``ClassHierarchy.hierarchical_precision`` outputs
                       (class_hierarchy.py:211-316) for a small retrieval problem + the taxonomy
                       edges (Cifar-Hierarchy/cifar.parent-child.txt: data file)
-* loss_cifar100.npz   seeded inputs + loss oracle outputs (NOT from the reference: Keras/TF are
-                      absent -- "parity unpinned", see oracle/loss_oracle.py)
+* loss_cifar100.npz   seeded inputs + loss oracle outputs (round-1 fixture, kept)
+* loss_ref_*.npz      seeded inputs + the outputs of the reference's OWN utils.py:34-127 and
+                      learn_labelembedding.py:17-37, imported unmodified and evaluated on the NumPy
+                      ``keras.backend`` stand-in of oracle/keras_stub.py, in float32 (the reference's
+                      precision) and float64 (tight values for the oracle)
+* lr_schedules.npz    learning-rate trajectories of the reference's get_lr_schedule (utils.py:288-399)
+                      with its own clr_callback.py / sgdr_callback.py driven epoch by epoch
+* retrieval_d555_*.npz, retrieval_d1000_*.npz   D > 448: this host's OpenBLAS restarts its FMA chain per
+                      K block; the probed block list travels in the fixture (``kblocks``)
+* imagenet_mintree_unitsphere.npz   the class embedding missing from the reference checkout, regenerated
+                      by the reference's compute_class_embedding.py:14-40,176-250 in JSON class order
 
 Usage:  python -m oracle.make_golden        (from the repo root)
 """
@@ -43,6 +52,141 @@ def ref_ranking(er, features, normalize):
     inp = {k: v.copy() for k, v in features.items()} if isinstance(features, dict) else features.copy()
     ret = er.pairwise_retrieval(inp, normalize=normalize, return_generator=False)
     return np.array([ret[i] for i in ids], dtype=np.int32)
+
+
+def openblas_kblocks(d, q=448):
+    """K blocking of OpenBLAS level-3 drivers (driver/level3/level3.c, level3_syrk.c: GEMM_Q = 448 on this host's kernels):
+    blocks of q while >= 2q remain, then the rest split in two halves (rounded up) if it exceeds q."""
+    out, ls = [], 0
+    while ls < d:
+        m = d - ls
+        if m >= 2 * q:
+            m = q
+        elif m > q:
+            m = (m + 1) // 2
+        out.append(m)
+        ls += m
+    return out
+
+
+def probe_kblocks(feat):
+    """The K-block list under which the canonical FMA chain reproduces THIS host's BLAS bit for bit (checked, not assumed)."""
+    from oracle import retrieval_oracle as ro
+    x = np.ascontiguousarray(feat[:96], dtype=np.float32)
+    want = np.dot(x, x.T)
+    for kb in ([x.shape[1]], openblas_kblocks(x.shape[1])):
+        if np.array_equal(want, ro.canon_pdist(x, None, ro.METRIC_DOT, kblocks=kb)):
+            return kb
+    raise RuntimeError("host BLAS summation order not reproduced for D=%d" % x.shape[1])
+
+
+def regenerate_imagenet_mintree():
+    """embeddings/imagenet_mintree.unitsphere.pickle is missing from the checkout (.MISSING_LARGE_BLOBS): rerun the reference's
+    compute_class_embedding.py (unitsphere method) on ILSVRC/wordnet.parent-child.mintree.txt with the class list in the order
+    of ILSVRC/imagenet_class_index.unitsphere.json."""
+    import json
+    import subprocess
+    import tempfile
+    with open(os.path.join(REF, "ILSVRC", "imagenet_class_index.unitsphere.json")) as f:
+        idx = json.load(f)
+    synsets = [idx[str(i)][0] for i in range(len(idx))]
+    with tempfile.TemporaryDirectory() as tmp:
+        cl = os.path.join(tmp, "classes.txt")
+        with open(cl, "w") as f:
+            f.write("\n".join(synsets) + "\n")
+        out = os.path.join(tmp, "imagenet_mintree.unitsphere.pickle")
+        env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
+        subprocess.check_call([sys.executable, os.path.join(REF, "compute_class_embedding.py"), "--hierarchy",
+                               os.path.join(REF, "ILSVRC", "wordnet.parent-child.mintree.txt"), "--str_ids", "--class_list", cl,
+                               "--out", out], env=env, cwd=tmp)
+        with open(out, "rb") as f:
+            e = pickle.load(f)
+    emb = np.asarray(e["embedding"])
+    assert emb.shape == (1000, 1000) and list(e["ind2label"]) == synsets
+    assert np.abs(np.linalg.norm(emb, axis=1) - 1).max() < 1e-9
+    np.savez_compressed(os.path.join(OUT, "imagenet_mintree_unitsphere.npz"), embedding=emb.astype(np.float32),
+                        ind2label=np.array(synsets), max_abs_f64_minus_f32=np.abs(emb - emb.astype(np.float32)).max())
+    print("imagenet_mintree.unitsphere", emb.shape)
+    return emb
+
+
+def loss_reference_goldens(emb):
+    """Evaluate the reference's own loss / metric source lines (imported unmodified) on seeded inputs."""
+    refs = {fx: (ref_import.import_reference("utils", fx), ref_import.import_reference("learn_labelembedding", fx))
+            for fx in ("float32", "float64")}
+    for key, B, noise in (("cifar100_unitsphere", 128, 0.35), ("cifar100_glove", 96, 0.35), ("nab_sim8", 96, 0.35),
+                          ("cub_balanced_unitsphere", 64, 0.35), ("imagenet_mintree_unitsphere", 48, 0.05)):
+        E = np.asarray(emb[key], dtype=np.float64)
+        C, D = E.shape
+        rng = np.random.default_rng(C * 7 + D)
+        y = rng.integers(0, C, size=B)
+        if key == "nab_sim8":
+            zero = np.nonzero(np.abs(E).sum(axis=1) == 0)[0]
+            y[:len(zero[:8])] = zero[:8]                     # classes whose embedding is the zero vector
+        x = (E[y] + noise * rng.standard_normal((B, D)) * np.abs(E).mean()).astype(np.float32)
+        x[::3] *= 4.0                                        # raw (un-normalised) network outputs of varying norm
+        x[1] = 0.0                                           # the epsilon clamp of l2_normalize
+        x[2] *= 1e-9
+        out = {"x": x, "labels": y.astype(np.int64)}
+        o1, o2, tar = (rng.standard_normal((B, C)).astype(np.float32) * 2 for _ in range(3))
+        o2[np.arange(B)[::2], y[::2]] += 7.0                 # confident + correct: mask = 1, relu(p - alpha) > 0
+        out.update(le_out1=o1, le_out2=o2, le_tar=tar)
+        for fx, (u, ll) in refs.items():
+            s = "_" + fx[-2:]
+            y_true = E[y]                                    # learn_image_embeddings.py:48-50 (cast to floatx on feed)
+            xhat = u.l2norm(x)                               # utils.py:125-127
+            out["xhat" + s] = xhat
+            out["inv_correlation" + s] = u.inv_correlation(y_true.astype(fx), xhat)                       # utils.py:44-46
+            out["squared_distance" + s] = u.squared_distance(y_true.astype(fx), x)                        # utils.py:34-36
+            out["mean_distance" + s] = u.mean_distance(y_true.astype(fx), x)                              # utils.py:39-41
+            for k in (1, 5):
+                out["max_sim_acc%d" % k + s] = u.nn_accuracy(E, True, k)(y_true.astype(fx), xhat)         # utils.py:87-95
+                out["nn_accuracy%d" % k + s] = u.nn_accuracy(E, False, k)(y_true.astype(fx), x)           # utils.py:73-85
+            out["devise_ranking_loss" + s] = u.devise_ranking_loss(E, 0.1)(y_true.astype(fx), xhat)       # utils.py:103-122
+            out["labelembed_loss" + s] = ll.labelembed_loss(o1, o2, tar, y.astype(fx), num_classes=C)     # learn_labelembedding.py:21-37
+        np.savez_compressed(os.path.join(OUT, "loss_ref_%s.npz" % key), **out)
+        print("loss_ref", key, x.shape, "acc", float(out["max_sim_acc1_32"].mean()), float(out["nn_accuracy1_32"].mean()))
+
+
+def lr_schedule_goldens():
+    """Learning-rate trajectories of the reference's schedules (utils.py:288-399, clr_callback.py, sgdr_callback.py)."""
+    from oracle import keras_stub
+    u = ref_import.import_reference("utils")
+    out = {}
+
+    class _Model(object):
+        def __init__(self, lr):
+            self.optimizer = type("Opt", (), {})()
+            self.optimizer.lr = keras_stub.Variable(lr)
+
+    cbs, n = u.get_lr_schedule("SGDR", 50000, 100, {"sgdr_base_len": 4, "sgdr_mul": 2, "sgdr_max_lr": 0.1})
+    m = _Model(0.1)
+    cbs[0].set_model(m)
+    cbs[0].on_train_begin()
+    lrs = []
+    for ep in range(30):
+        lrs.append(m.optimizer.lr.value)
+        cbs[0].on_epoch_end(ep, {})
+    out["sgdr_lr_per_epoch"], out["sgdr_epochs"] = np.array(lrs), n
+
+    cbs, n = u.get_lr_schedule("CLR", 1000, 100, {"clr_step_len": 2, "clr_min_lr": 1e-5, "clr_max_lr": 0.1})
+    m = _Model(0.1)
+    cbs[0].set_model(m)
+    cbs[0].on_train_begin()
+    lrs = []
+    for it in range(100):
+        lrs.append(m.optimizer.lr.value)
+        cbs[0].on_batch_end(it, {})
+    out["clr_lr_per_batch"], out["clr_epochs"] = np.array(lrs), n
+
+    cbs, n = u.get_lr_schedule("SGD", 50000, 100, {"sgd_schedule": "1:0.1,31:0.01,41:0.001,50"})
+    out["sgd_schedule_lr"], out["sgd_schedule_epochs"] = np.array([cbs[0].schedule(ep, 0.5) for ep in range(50)]), n
+    cbs, n = u.get_lr_schedule("ResNet-Schedule", 50000, 100, {})
+    out["resnet_schedule_lr"], out["resnet_schedule_epochs"] = np.array([cbs[0].schedule(ep) for ep in range(164)]), n
+    cbs, n = u.get_lr_schedule("SGD", 50000, 100, {})
+    out["sgd_plateau_epochs"], out["sgd_plateau_patience"], out["sgd_plateau_min_lr"] = n, cbs[0].kw["patience"], cbs[0].kw["min_lr"]
+    np.savez_compressed(os.path.join(OUT, "lr_schedules.npz"), **out)
+    print("lr schedules", {k: np.shape(v) for k, v in out.items()})
 
 
 def main():
@@ -125,6 +269,34 @@ def main():
     acc = loss_oracle.nn_accuracy(e_cifar, True)(e_cifar[yb], fwd["xhat"])
     np.savez_compressed(os.path.join(OUT, "loss_cifar100.npz"), x=xb, labels=yb, loss_i=fwd["loss_i"],
                         loss=fwd["loss"], inv_norm=fwd["inv_norm"], dx=dx, acc=acc)
+
+    # ---------------------------------------------------------------- imagenet_mintree.unitsphere (regenerated)
+    e_inet = regenerate_imagenet_mintree()
+
+    # ---------------------------------------------------------------- retrieval, D > 448 (BLAS K blocks)
+    from oracle import retrieval_oracle as ro
+    e_nab, _ = load_embedding("nab.unitsphere")
+    rng = np.random.default_rng(5)
+    big = {}
+    yn = rng.integers(0, e_nab.shape[0], size=160)
+    xn = (e_nab[yn] + 0.05 * rng.standard_normal((160, e_nab.shape[1]))).astype(np.float32)
+    big["d555_cos"] = (xn, True)
+    big["d555_euc"] = (xn, False)
+    yi = rng.integers(0, 1000, size=112)
+    xi = (e_inet[yi] + 0.03 * rng.standard_normal((112, 1000))).astype(np.float32)
+    big["d1000_cos"] = (xi, True)
+    big["d1000_euc"] = (xi, False)
+    for name, (feat, norm) in big.items():
+        rank = ref_ranking(er, feat, norm)
+        kb = probe_kblocks(feat)
+        np.savez_compressed(os.path.join(OUT, "retrieval_%s.npz" % name), features=feat, normalize=np.bool_(norm),
+                            ref_ranking=rank.astype(np.int16), kblocks=np.array(kb, dtype=np.int32))
+        print(name, feat.shape, norm, "kblocks", kb)
+
+    # ---------------------------------------------------------------- loss / metric goldens from the reference's own lines
+    emb["imagenet_mintree_unitsphere"] = e_inet.astype(np.float32)   # as committed (the fixture must be self-consistent)
+    loss_reference_goldens(emb)
+    lr_schedule_goldens()
     print("done ->", OUT)
 
 

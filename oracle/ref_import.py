@@ -1,10 +1,13 @@
 """oracle/ref_import.py -- TEST INFRASTRUCTURE ONLY (this container only).
 
 Imports the reference's *own* modules from /root/reference, unmodified, so that golden vectors
-can be produced by the real implementation.  ``numexpr`` and the
-reference's ``datasets`` package (which needs Keras) are not importable here, so they are
+can be produced by the real implementation.  ``numexpr``, Keras/TensorFlow and
+the reference's ``datasets`` package (which needs Keras) are not importable here, so they are
 pre-seeded in ``sys.modules`` with minimal stand-ins:
 
+* ``keras`` / ``keras.backend`` -> oracle/keras_stub.py, a NumPy backend covering exactly the calls of
+  utils.py:34-127 and learn_labelembedding.py:17-37 (its header lists each third-party primitive and the
+  documented formula it restates);
 * ``numexpr.evaluate(expr, local_dict)`` -> ``eval(expr)`` on the NumPy arrays (float32 in,
   float32 out for ``A + B - 2 * C``; numexpr's own promotion rules are third-party and unverified
   -- "parity unpinned" at that one boundary).
@@ -45,25 +48,47 @@ def _datasets_stub():
     return m
 
 
-def import_reference(name):
-    """Import module ``name`` (e.g. 'evaluate_retrieval', 'class_hierarchy') from the reference tree."""
+def _empty_module(name, **attrs):
+    m = types.ModuleType(name)
+    for k, v in attrs.items():
+        setattr(m, k, v)
+    return m
+
+
+# names the reference's training-side modules import that must not leak into (or be taken from) the caller's sys.modules
+_SHADOWED = ("numexpr", "datasets", "keras", "keras.backend", "keras.callbacks", "keras.layers", "keras.models", "keras.utils",
+             "keras.metrics", "keras.applications", "keras.optimizers", "keras.regularizers", "keras.preprocessing",
+             "keras_applications", "keras_resnet", "models", "densenet", "clr_callback", "sgdr_callback", "utils", "class_hierarchy")
+
+
+def import_reference(name, floatx="float32"):
+    """Import module ``name`` (e.g. 'evaluate_retrieval', 'class_hierarchy', 'utils', 'learn_labelembedding') from the
+    reference tree, unmodified.  ``keras`` resolves to the NumPy stand-in of oracle/keras_stub.py evaluated in ``floatx``
+    precision; the reference's ``models`` package and ``densenet`` (network definitions, never called here) are empty stubs;
+    ``clr_callback`` / ``sgdr_callback`` / ``utils`` / ``class_hierarchy`` are the reference's own files."""
     if not available():
         raise ImportError("reference tree not present at " + REFERENCE_ROOT)
+    from oracle import keras_stub
     sys.dont_write_bytecode = True  # the mount is read-only
-    saved = {k: sys.modules.get(k) for k in ("numexpr", "datasets", name)}
+    names = set(_SHADOWED) | {name}
+    saved = {k: sys.modules.get(k) for k in names}
     saved_path = list(sys.path)
     try:
+        for k in names:
+            sys.modules.pop(k, None)
         sys.modules["numexpr"] = _numexpr_stub()
         sys.modules["datasets"] = _datasets_stub()
-        sys.modules.pop(name, None)
+        sys.modules.update(keras_stub.make_keras(floatx))
+        sys.modules["models"] = _empty_module("models", cifar_resnet=None, cifar_pyramidnet=None, plainnet=None,
+                                              wide_residual_network=None)
+        sys.modules["densenet"] = _empty_module("densenet")
         sys.path.insert(0, REFERENCE_ROOT)
         mod = importlib.import_module(name)
     finally:
-        sys.path[:] = saved_path
-        for k in ("numexpr", "datasets"):
-            if saved[k] is None:
-                sys.modules.pop(k, None)
-            else:
-                sys.modules[k] = saved[k]
-        sys.modules.pop(name, None)
+        sys.path[:] = [p for p in saved_path]
+        for k in set(sys.modules) & (names | {n for n in sys.modules if n.startswith("keras.")}):
+            sys.modules.pop(k, None)
+        for k, v in saved.items():
+            if v is not None:
+                sys.modules[k] = v
     return mod

@@ -273,7 +273,8 @@ class ClassHierarchy(object):
 
 
     def hierarchical_precision_device(self, features, labels, ks=[1, 10, 50, 100], compute_ahp=False, compute_ap=False,
-                                      normalize=False, ids=None, tile_rows=None):
+                                      normalize=False, ids=None, tile_rows=None, distributed=False, group=None, kblocks=None,
+                                      gather_per_query=True, kernels=None):
         """``hierarchical_precision(pairwise_retrieval(features, normalize), labels, ...)`` (ignore_qids = True, every
         image is query and gallery item) without leaving the GPU: the rankings stay device tensors
         (``evaluate_retrieval.ranking_tiles``) and the per-query gather + prefix sums run in
@@ -282,10 +283,24 @@ class ClassHierarchy(object):
 
         ``features``: float32 ``[N, D]`` array or (device) tensor (a device copy is normalised when ``normalize``);
         ``labels``: class label of image ``ids[i]`` (``ids`` defaults to ``range(N)``), as a sequence or a mapping.
-        Returns ``(means, per_query)`` exactly like ``hierarchical_precision``."""
+        Returns ``(means, per_query)`` exactly like ``hierarchical_precision``.
+
+        ``distributed`` (one process per GPU, ``torch.distributed`` initialised): every rank holds all features.
+        * metrics that need full rankings (AP, un-clipped AHP): the QUERIES are sharded -- rank r ranks rows
+          ``shard_bounds(N, G)[r]`` against the replicated gallery, no data-path collective; the per-query metric rows
+          are all-gathered (``gather_per_query``) or only their sums all-reduced (SURVEY.md section 8e row 2);
+        * otherwise (P@k and AHP@clip only) the GALLERY is sharded: per-shard fused distance + top-L with
+          L = max(ks, clip) + 1, RCCL all-gather of the ``(distance, global index)`` lists, canonical k-way merge
+          (``sharded_retrieval.sharded_topk``), then each rank scores its share of the queries.
+        ``kernels`` (tests): CPU stand-ins ``{'ranking_tiles', 'hierarchical_precision', 'local_topk', 'merge', 'device'}``."""
         import torch
-        import sehip
-        from evaluate_retrieval import ranking_tiles
+        from sharded_retrieval import shard_bounds, sharded_topk
+        kernels = dict(kernels or {})
+        if 'ranking_tiles' not in kernels or 'hierarchical_precision' not in kernels:
+            import sehip
+            from evaluate_retrieval import ranking_tiles
+            kernels.setdefault('ranking_tiles', ranking_tiles)
+            kernels.setdefault('hierarchical_precision', sehip.hierarchical_precision)
 
         ks = [ks] if isinstance(ks, int) else list(ks)
         ahp_clip = None if isinstance(compute_ahp, bool) else int(compute_ahp)
@@ -306,34 +321,80 @@ class ClassHierarchy(object):
                 order = np.argsort(-vals, kind='stable')
                 best[c] = np.cumsum(np.repeat(vals[order], counts[order]))
 
-        dev = torch.device('cuda', torch.cuda.current_device())
+        import torch.distributed as dist
+        world = dist.get_world_size(group) if (distributed and dist.is_initialized()) else 1
+        rank = dist.get_rank(group) if world > 1 else 0
+        dev = kernels.get('device') or torch.device('cuda', torch.cuda.current_device())
         if torch.is_tensor(features):    # features straight from the network (learn_image_embeddings feature extraction): stay on the device
             feats = features.detach().to(device=dev, dtype=torch.float32).contiguous().clone()
         else:
             feats = torch.from_numpy(np.ascontiguousarray(features, dtype=np.float32)).to(dev)
         cls_d = torch.from_numpy(cls_h).to(dev)
         qidx_d = torch.arange(n, dtype=torch.int32, device=dev)
-        args_d = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (wup_t, lcs_t, best_w, best_l)]
         ks_d = torch.tensor(ks, dtype=torch.int32, device=dev)
         ahp_len = -1 if not compute_ahp else (0 if ahp_clip is None else ahp_clip)
+        head_only = (not compute_ap) and (not compute_ahp or ahp_clip is not None)
+        q0, q1 = shard_bounds(n, world)[rank] if world > 1 else (0, n)
+        ncol = 2 * len(ks) + 3
         outs = []
-        for r0, tile in ranking_tiles(feats, normalize, tile_rows=tile_rows):
-            rows = tile.shape[0]
-            outs.append(sehip.hierarchical_precision(tile, cls_d, cls_d[r0:r0 + rows].contiguous(), qidx_d[r0:r0 + rows].contiguous(),
-                                                     *args_d, ks_d, ahp_len=ahp_len, want_ap=compute_ap))
-        res = torch.cat(outs).cpu().numpy()
+        if world > 1 and head_only:
+            # ---- sharded gallery: top-L lists are enough for every requested metric ----
+            L = min(n, max(ks + [ahp_clip or 0]) + 1)
+            best_w, best_l = best_w[:, :L + 1], best_l[:, :L + 1]
+            args_d = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (wup_t, lcs_t, best_w, best_l)]
+            g0, g1 = shard_bounds(n, world)[rank]
+            if 'local_topk' not in kernels:
+                import sehip
+                if normalize:
+                    sehip.normalize_rows_(feats)
+                metric = sehip.METRIC_COSINE if normalize else sehip.METRIC_EUCLID
+            else:
+                metric = None
+            _, top_i = sharded_topk(feats, feats[g0:g1], L, g0, metric=metric, group=group,
+                                    local_topk=kernels.get('local_topk'), merge=kernels.get('merge'))
+            if q1 > q0:
+                outs.append(kernels['hierarchical_precision'](top_i[q0:q1].contiguous(), cls_d, cls_d[q0:q1].contiguous(),
+                                                             qidx_d[q0:q1].contiguous(), *args_d, ks_d, ahp_len=ahp_len, want_ap=False))
+        else:
+            args_d = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (wup_t, lcs_t, best_w, best_l)]
+            for r0, tile in kernels['ranking_tiles'](feats, normalize, tile_rows=tile_rows, queries=(q0, q1), kblocks=kblocks):
+                rows = tile.shape[0]
+                outs.append(kernels['hierarchical_precision'](tile, cls_d, cls_d[r0:r0 + rows].contiguous(), qidx_d[r0:r0 + rows].contiguous(),
+                                                             *args_d, ks_d, ahp_len=ahp_len, want_ap=compute_ap))
+        res_d = torch.cat(outs) if outs else torch.zeros((0, ncol), dtype=torch.float64, device=dev)
+        sums = None
+        if world > 1:
+            if gather_per_query:    # ragged all-gather: pad every shard to the largest one
+                rows_max = max(e - s for s, e in shard_bounds(n, world))
+                padded = torch.zeros((rows_max, ncol), dtype=torch.float64, device=dev)
+                padded[:res_d.shape[0]] = res_d
+                gathered = torch.empty((world * rows_max, ncol), dtype=torch.float64, device=dev)
+                dist.all_gather_into_tensor(gathered, padded, group=group)
+                res_d = torch.cat([gathered[r * rows_max:r * rows_max + (e - s)] for r, (s, e) in enumerate(shard_bounds(n, world))])
+                q0, q1 = 0, n
+            else:                   # the means only: one all-reduce of ncol sums
+                sums = res_d.sum(dim=0)
+                dist.all_reduce(sums, group=group)
+        res = res_d.cpu().numpy()
 
         nk = len(ks)
+        my_ids = ids[q0:q1]
         prec = {}
+        col = {}
         for t, k in enumerate(ks):
-            prec['P@{} (WUP)'.format(k)] = dict(zip(ids, res[:, t].tolist()))
-            prec['P@{} (LCS_HEIGHT)'.format(k)] = dict(zip(ids, res[:, nk + t].tolist()))
+            col['P@{} (WUP)'.format(k)] = t
+            col['P@{} (LCS_HEIGHT)'.format(k)] = nk + t
         if compute_ahp:
             sfx = '' if ahp_clip is None else '@{}'.format(ahp_clip)
-            prec['AHP{} (WUP)'.format(sfx)] = dict(zip(ids, res[:, 2 * nk].tolist()))
-            prec['AHP{} (LCS_HEIGHT)'.format(sfx)] = dict(zip(ids, res[:, 2 * nk + 1].tolist()))
+            col['AHP{} (WUP)'.format(sfx)] = 2 * nk
+            col['AHP{} (LCS_HEIGHT)'.format(sfx)] = 2 * nk + 1
         if compute_ap:
-            prec['AP'] = dict(zip(ids, res[:, 2 * nk + 2].tolist()))
+            col['AP'] = 2 * nk + 2
+        for name, c in col.items():
+            prec[name] = dict(zip(my_ids, res[:, c].tolist()))
+        if sums is not None:
+            sums = sums.cpu().numpy()
+            return {name: float(sums[c]) / n for name, c in col.items()}, prec
         return {metric: sum(values.values()) / len(values) for metric, values in prec.items()}, prec
 
 

@@ -2,9 +2,11 @@
 //
 // Replaces `labelembed_loss(out1, out2, tar, targets, tau, alpha, beta)` (learn_labelembedding.py:21-37,
 // with `cross_entropy` :17-18) and what TF autodiff derives from it.  Per sample i with label y:
-//     L_o1_y   = -log clip(softmax(out1)[y])                          (Keras sparse CE on probabilities, eps 1e-7)
+//     L_o1_y   = -(log c_y - log sum_j c_j),  c = clip(softmax(out1), 1e-7, 1 - 1e-7)
+//                (Keras 2.2 sparse_categorical_crossentropy on probabilities: clip, log, then TF's
+//                 sparse_softmax_cross_entropy_with_logits, which renormalises the clipped probabilities)
 //     L_o1_emb = -sum_c softmax(tar)_c * log_softmax(out1)_c          (softmax(tar) is stop_gradient)
-//     L_o2_y   = -log clip(softmax(out2)[y])
+//     L_o2_y   = the same on softmax(out2)
 //     L_emb_o2 = -sum_c softmax(out2 / tau)_c * log_softmax(tar)_c * mask_i * B / (sum_j mask_j + 1e-8)
 //                mask_i = [argmax(out2) == y]                         (softmax(out2/tau) and mask are stop_gradient)
 //     L_re     = relu(softmax(out2)[y] - alpha)
@@ -20,7 +22,7 @@ namespace se {
 
 constexpr int LE_ROWS_PER_BLOCK = 4;   // 4 waves = 256 threads
 constexpr float KERAS_EPS = 1e-7f;     // keras.backend.epsilon(): probabilities are clipped to [eps, 1 - eps]
-constexpr int LE_AUX = 8;              // per-sample record kept for the backward pass
+constexpr int LE_AUX = 12;             // per-sample record kept for the backward pass
 
 __device__ __forceinline__ float wave_max(float v)
 {
@@ -29,7 +31,8 @@ __device__ __forceinline__ float wave_max(float v)
     return v;
 }
 
-// aux[i] = { lse(out1), lse(out2), lse(tar), lse(out2 / tau), mask, A_i = -sum tau2 * log_softmax(tar), base_i, p2_y }
+// aux[i] = { lse(out1), lse(out2), lse(tar), lse(out2 / tau), mask, A_i = -sum tau2 * log_softmax(tar), base_i, p2_y,
+//            S1 = sum_j clip(p1_j), R1 = sum_j 1{eps < p1_j < 1 - eps} p1_j, S2, R2 }
 __global__ __launch_bounds__(256) void labelembed_fwd_kernel(const float *__restrict__ out1, int64_t ld1,
                                                              const float *__restrict__ out2, int64_t ld2,
                                                              const float *__restrict__ tar, int64_t ldt,
@@ -75,11 +78,22 @@ __global__ __launch_bounds__(256) void labelembed_fwd_kernel(const float *__rest
         }
         s1 = wave_sum(s1); s2 = wave_sum(s2); st = wave_sum(st); s2t = wave_sum(s2t);
         w_t_o1 = wave_sum(w_t_o1); w_tau_t = wave_sum(w_tau_t);
+        const float lse1 = m1 + logf(s1), lse2 = m2w + logf(s2);
+        // pass 3: sums of the clipped probabilities (the renormalisation inside Keras' sparse CE) and of the un-clipped ones
+        float S1 = 0.f, R1 = 0.f, S2 = 0.f, R2 = 0.f;
+        for (int64_t c = lane; c < C; c += WAVE) {
+            const float p1 = expf(o1[c] - lse1), p2 = expf(o2[c] - lse2);
+            S1 += fminf(fmaxf(p1, KERAS_EPS), 1.0f - KERAS_EPS);
+            S2 += fminf(fmaxf(p2, KERAS_EPS), 1.0f - KERAS_EPS);
+            R1 += (p1 > KERAS_EPS && p1 < 1.0f - KERAS_EPS) ? p1 : 0.f;
+            R2 += (p2 > KERAS_EPS && p2 < 1.0f - KERAS_EPS) ? p2 : 0.f;
+        }
+        S1 = wave_sum(S1); S2 = wave_sum(S2); R1 = wave_sum(R1); R2 = wave_sum(R2);
         if (lane == 0) {
-            const float lse1 = m1 + logf(s1), lse2 = m2w + logf(s2), lset = mt + logf(st), lse2t = m2w * inv_tau + logf(s2t);
+            const float lset = mt + logf(st), lse2t = m2w * inv_tau + logf(s2t);
             const float p1y = expf(o1[y] - lse1), p2y = expf(o2[y] - lse2);
-            const float l_o1_y = -logf(fminf(fmaxf(p1y, KERAS_EPS), 1.0f - KERAS_EPS));
-            const float l_o2_y = -logf(fminf(fmaxf(p2y, KERAS_EPS), 1.0f - KERAS_EPS));
+            const float l_o1_y = -(logf(fminf(fmaxf(p1y, KERAS_EPS), 1.0f - KERAS_EPS)) - logf(S1));
+            const float l_o2_y = -(logf(fminf(fmaxf(p2y, KERAS_EPS), 1.0f - KERAS_EPS)) - logf(S2));
             const float l_o1_emb = -(w_t_o1 / st - lse1);         // -sum softmax(tar) * (out1 - lse1)
             const float a_i = -(w_tau_t / s2t - lset);            // -sum softmax(out2/tau) * (tar - lset)
             const float l_re = fmaxf(p2y - alpha, 0.f);
@@ -89,6 +103,7 @@ __global__ __launch_bounds__(256) void labelembed_fwd_kernel(const float *__rest
             r[5] = a_i;
             r[6] = beta * l_o1_y + (1.0f - beta) * l_o1_emb + l_o2_y + l_re;
             r[7] = p2y;
+            r[8] = S1; r[9] = R1; r[10] = S2; r[11] = R2;
         }
     }
 }
@@ -111,8 +126,10 @@ __global__ __launch_bounds__(256) void labelembed_finish_kernel(const float *__r
     for (int64_t i = threadIdx.x; i < B; i += 256) loss_i[i] = aux[i * LE_AUX + 6] + aux[i * LE_AUX + 5] * aux[i * LE_AUX + 4] * scale;
 }
 
-// d out1 = g [ beta (softmax1 - onehot_y) 1{eps < p1_y < 1 - eps} + (1 - beta) (softmax1 - softmax(tar)) ]
-// d out2 = g [ (softmax2 - onehot_y) 1{eps < p2_y < 1 - eps} + 1{p2_y > alpha} p2_y (onehot_y - softmax2) ]
+// With in_j = 1{eps < p_j < 1 - eps} (clip_by_value passes gradient strictly inside the range), S = sum_j clip(p_j), R = sum_j in_j p_j:
+//   ce'(p)_c = in_y (p_c - onehot_c) + p_c (in_c - R) / S          (= p - onehot when nothing is clipped)
+// d out1 = g [ beta ce'(softmax1) + (1 - beta) (softmax1 - softmax(tar)) ]
+// d out2 = g [ ce'(softmax2) + 1{p2_y > alpha} p2_y (onehot_y - softmax2) ]
 // d tar  = g mask_i scale (softmax(tar) - softmax(out2 / tau))
 __global__ __launch_bounds__(256) void labelembed_bwd_kernel(const float *__restrict__ out1, int64_t ld1, const float *__restrict__ out2,
                                                              int64_t ld2, const float *__restrict__ tar, int64_t ldt,
@@ -132,16 +149,18 @@ __global__ __launch_bounds__(256) void labelembed_bwd_kernel(const float *__rest
         const float lse1 = r[0], lse2 = r[1], lset = r[2], lse2t = r[3], mask = r[4], p2y = r[7];
         const float g = grad_loss_i ? grad_loss_i[row] : grad_scale;
         const float p1y = expf(o1[y] - lse1);
-        const float k1 = (p1y > KERAS_EPS && p1y < 1.0f - KERAS_EPS) ? beta : 0.f;   // clip_by_value passes gradient inside the range only
+        const float k1 = (p1y > KERAS_EPS && p1y < 1.0f - KERAS_EPS) ? 1.f : 0.f;   // clip_by_value passes gradient inside the range only
         const float k2 = (p2y > KERAS_EPS && p2y < 1.0f - KERAS_EPS) ? 1.f : 0.f;
+        const float rS1 = 1.0f / r[8], R1 = r[9], rS2 = 1.0f / r[10], R2 = r[11];
         const float kre = (p2y > alpha) ? p2y : 0.f;
         const float wt = g * mask * sc;
         for (int64_t c = lane; c < C; c += WAVE) {
             const float sm1 = expf(o1[c] - lse1), sm2 = expf(o2[c] - lse2), smt = expf(tr[c] - lset);
             const float sm2t = expf(o2[c] * inv_tau - lse2t);
             const float hot = (c == y) ? 1.f : 0.f;
-            if (d1) d1[row * ldd1 + c] = g * (k1 * (sm1 - hot) + (1.0f - beta) * (sm1 - smt));
-            if (d2) d2[row * ldd2 + c] = g * (k2 * (sm2 - hot) + kre * (hot - sm2));
+            const float in1 = (sm1 > KERAS_EPS && sm1 < 1.0f - KERAS_EPS) ? 1.f : 0.f, in2 = (sm2 > KERAS_EPS && sm2 < 1.0f - KERAS_EPS) ? 1.f : 0.f;
+            if (d1) d1[row * ldd1 + c] = g * (beta * (k1 * (sm1 - hot) + sm1 * (in1 - R1) * rS1) + (1.0f - beta) * (sm1 - smt));
+            if (d2) d2[row * ldd2 + c] = g * ((k2 * (sm2 - hot) + sm2 * (in2 - R2) * rS2) + kre * (hot - sm2));
             if (dt) dt[row * lddt + c] = wt * (smt - sm2t);
         }
     }

@@ -9,7 +9,13 @@ reference: evaluate_retrieval.py:22-73 (pairwise_retrieval), :76-151 (reporting 
   ``np.argsort`` is unstable and returns them in arbitrary order;
 * the ranking is produced query tile by query tile (the generator is genuinely lazy), so the
   N x N distance matrix never has to exist at once;
-* there is no CPU fallback: without a ROCm device the call raises ``sehip.SehipError``.
+* there is no CPU fallback: without a ROCm device the call raises ``sehip.SehipError``;
+* launched with one process per GPU (``python -m torch.distributed.run --nproc-per-node G evaluate_retrieval.py ...``)
+  the queries are sharded across the ranks (gallery replicated, rows of a ranking are independent) and the per-query
+  metrics are combined with one small all-reduce; rank 0 prints / writes / plots (SURVEY.md section 8e row 2);
+* ``--skip_ap`` (extension) drops the average-precision column; together with ``--clip_ahp`` no metric needs more than the
+  head of each ranking, and under several ranks the SHARDED-GALLERY path is taken: per-shard fused distance + top-k,
+  RCCL all-gather of the per-shard lists, k-way merge.
 """
 import argparse
 import os.path
@@ -51,17 +57,50 @@ def _as_feature_matrix(features):
     return features, ind2id, owned
 
 
-def ranking_tiles(features, normalize=False, tile_rows=None, idx64=False, queries=None):
+def host_blas_kblocks(d, q=448):
+    """K-block list of OpenBLAS's level-3 drivers for a depth-``d`` product (GEMM_Q = ``q``; 448 for the Haswell / SkylakeX /
+    Zen sgemm kernels): blocks of ``q`` while at least ``2 q`` remain, then the remainder split in two (first half rounded up)
+    if it exceeds ``q``.  The reference's ``np.dot`` (evaluate_retrieval.py:59,62) restarts its fp32 FMA chain at every block,
+    so for D > 448 bit-identical rankings need this list: ``pairwise_retrieval(..., kblocks=host_blas_kblocks(D))``.
+    Verified against this image's NumPy/OpenBLAS for D up to 2048 (oracle/make_golden.py probes it for the fixtures)."""
+    out, ls = [], 0
+    while ls < d:
+        m = d - ls
+        if m >= 2 * q:
+            m = q
+        elif m > q:
+            m = (m + 1) // 2
+        out.append(m)
+        ls += m
+    return out
+
+
+def _resolve_kblocks(kblocks, d):
+    if kblocks is None:
+        return None
+    if isinstance(kblocks, str):
+        if kblocks.lower() != 'openblas':
+            raise ValueError("kblocks must be None, 'openblas' or a list of block lengths summing to D")
+        kblocks = host_blas_kblocks(d)
+    kblocks = [int(v) for v in kblocks]
+    if sum(kblocks) != d or min(kblocks) <= 0:
+        raise ValueError('kblocks {} do not add up to the feature dimension {}'.format(kblocks, d))
+    return kblocks if len(kblocks) > 1 else None
+
+
+def ranking_tiles(features, normalize=False, tile_rows=None, idx64=False, queries=None, kblocks=None):
     """Generator over ``(first_row, rank_tile)`` with ``rank_tile`` an int32 (int64 if ``idx64``)
     DEVICE tensor ``[rows, N]``: the canonical ranking of queries ``first_row .. first_row+rows``.
 
     ``features`` must already be a float32 device tensor ``[N, D]``; it is normalised in place when
     ``normalize`` is set (like the reference mutates its input, evaluate_retrieval.py:58).
-    ``queries`` optionally restricts the query rows to ``range(*queries)``."""
+    ``queries`` optionally restricts the query rows to ``range(*queries)``; ``kblocks`` (None | 'openblas' | list) makes
+    the FMA chain restart per K block like the host BLAS the reference ran on (see ``host_blas_kblocks``)."""
     import torch
     import sehip
 
     n, _ = features.shape
+    kblocks = _resolve_kblocks(kblocks, features.shape[1])
     if normalize:
         sehip.normalize_rows_(features)
         metric, sq = sehip.METRIC_COSINE, None
@@ -74,11 +113,11 @@ def ranking_tiles(features, normalize=False, tile_rows=None, idx64=False, querie
     for r0 in range(q0, q1, tile_rows):
         rows = min(tile_rows, q1 - r0)
         sehip.pairwise_dist(features[r0:r0 + rows], features, metric=metric,
-                            sqa=None if sq is None else sq[r0:r0 + rows], sqb=sq, out=pd[:rows])
+                            sqa=None if sq is None else sq[r0:r0 + rows], sqb=sq, kblocks=kblocks, out=pd[:rows])
         yield r0, sehip.rank_rows(pd[:rows], idx64=idx64)
 
 
-def pairwise_retrieval(features, normalize=False, return_generator=True):
+def pairwise_retrieval(features, normalize=False, return_generator=True, kblocks=None):
     """ Uses each image as query and retrieves its nearest neighbors.
 
     # Arguments (identical to the reference, evaluate_retrieval.py:22-41):
@@ -86,6 +125,7 @@ def pairwise_retrieval(features, normalize=False, return_generator=True):
     - features: 2-d numpy array | dict id -> feature vector | dict with key 'feat' | path to a pickle of those.
     - normalize: Whether to L2-normalize the features.
     - return_generator: If True, a generator will be returned instead of a dictionary.
+    - kblocks (extension): None | 'openblas' | list -- K-block list of the host BLAS to reproduce for D > 448.
 
     # Returns:
         generator (or dict) of ``(image ID, list of all image IDs ordered by increasing distance)``.
@@ -100,7 +140,7 @@ def pairwise_retrieval(features, normalize=False, return_generator=True):
 
     def gen():
         first = True
-        for r0, tile in ranking_tiles(dev, normalize):
+        for r0, tile in ranking_tiles(dev, normalize, kblocks=kblocks):
             if first and normalize and not owned and isinstance(features, np.ndarray) and features.dtype == np.float32:
                 # the reference normalises the caller's array in place (`features /= ...`)
                 np.copyto(features, dev.cpu().numpy())
@@ -199,7 +239,30 @@ def build_parser():
     g.add_argument('--prec_type', type=str, default='LCS_HEIGHT', choices=['WUP', 'LCS_HEIGHT'], help='Class-similarity measure for the curve/CSV.')
     g.add_argument('--clip_ahp', type=int, default=None, help='Compute AHP on the first CLIP_AHP ranks only.')
     g.add_argument('--csv', type=str, default=None, help='Write the P@k table to this CSV file.')
+    g = p.add_argument_group('Extensions of this build (not in the reference)')
+    g.add_argument('--skip_ap', action='store_true', default=False,
+                   help='Do not compute AP; with --clip_ahp only the head of each ranking is needed (sharded-gallery top-k under several ranks).')
+    g.add_argument('--kblocks', type=str, default=None, help="'openblas': restart the fp32 dot-product chain per OpenBLAS K block (D > 448).")
     return p
+
+
+def init_distributed():
+    """One process per GPU when launched by torch.distributed.run (WORLD_SIZE > 1): RCCL ('nccl') on ROCm devices, gloo
+    otherwise (CPU tests).  Returns (rank, world)."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world <= 1:
+        return 0, 1
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29500')
+        if torch.cuda.is_available():
+            torch.cuda.set_device(int(os.environ.get('LOCAL_RANK', '0')) % max(torch.cuda.device_count(), 1))
+            dist.init_process_group('nccl')
+        else:
+            dist.init_process_group('gloo')
+    return dist.get_rank(), dist.get_world_size()
 
 
 def main(argv=None):
@@ -207,6 +270,7 @@ def main(argv=None):
     from class_hierarchy import ClassHierarchy
 
     args = build_parser().parse_args(argv)
+    rank, world = init_distributed()
 
     if args.classes_from:
         with open(args.classes_from, 'rb') as f:
@@ -224,17 +288,24 @@ def main(argv=None):
         if (len(ks) == 0) or (ks[-1] < k):
             ks.append(k)
     perf = OrderedDict()
-    for i, feat_dump in tqdm(enumerate(args.feat), total=len(args.feat)):
+    for i, feat_dump in tqdm(enumerate(args.feat), total=len(args.feat), disable=rank != 0):
         feat_name = args.label[i] if (args.label is not None) and (i < len(args.label)) else os.path.splitext(os.path.basename(feat_dump))[0]
         normalize = args.norm[i] if (args.norm is not None) and (i < len(args.norm)) else False
         # reference: hierarchy.hierarchical_precision(pairwise_retrieval(feat_dump, normalize), labels_test, ks, ...)
         # (evaluate_retrieval.py:197-201).  Here rankings and metrics stay on the GPU: no N x N Python lists.
         features, ind2id, _ = _as_feature_matrix(feat_dump)
+        # Several ranks: queries sharded (full rankings), or -- when no metric needs more than the head of a ranking
+        # (--skip_ap with --clip_ahp) -- the gallery sharded with an all-gather + merge of per-shard top-k lists.
         perf[feat_name] = hierarchy.hierarchical_precision_device(
-            features, labels_test, ks, compute_ahp=args.clip_ahp if args.clip_ahp else True, compute_ap=True,
-            normalize=normalize, ids=None if ind2id is None else ind2id.tolist())[0]
+            features, labels_test, ks, compute_ahp=args.clip_ahp if args.clip_ahp else True, compute_ap=not args.skip_ap,
+            normalize=normalize, ids=None if ind2id is None else ind2id.tolist(), distributed=world > 1,
+            kblocks=args.kblocks)[0]
+    if rank != 0:
+        return perf
 
     metrics = list(METRICS)
+    if args.skip_ap:
+        metrics.remove('AP')
     if args.clip_ahp:
         metrics[4] = 'AHP@{} (WUP)'.format(args.clip_ahp)
         metrics[9] = 'AHP@{} (LCS_HEIGHT)'.format(args.clip_ahp)

@@ -111,3 +111,134 @@ def test_shard_bounds_cover_everything():
         b = sr.shard_bounds(n, w)
         assert b[0][0] == 0 and b[-1][1] == n and all(b[i][1] == b[i + 1][0] for i in range(w - 1))
         assert max(e - s for s, e in b) - min(e - s for s, e in b) <= 1
+
+
+# ---------------------------------------------------------------- rank-aware retrieval evaluation
+
+def _hprec_standin(rank_tile, cls, qcls, qidx, wup, lcs, best_w, best_l, ks, ahp_len=-1, want_ap=False, list_len=None):
+    """NumPy stand-in for sehip.hierarchical_precision (se_hierarchical_precision's contract, class_hierarchy.py:257-314)."""
+    trapz = getattr(np, "trapezoid", None) or np.trapz
+    rank_tile, cls, qcls, qidx = (t.numpy() for t in (rank_tile, cls, qcls, qidx))
+    wup, lcs, best_w, best_l, ks = (t.numpy() for t in (wup, lcs, best_w, best_l, ks))
+    nk = len(ks)
+    out = np.zeros((rank_tile.shape[0], 2 * nk + 3))
+    for r in range(rank_tile.shape[0]):
+        ret = rank_tile[r]
+        cols = cls[ret]
+        qp = np.nonzero(ret == qidx[r])[0]
+        cw_best, cl_best = best_w[qcls[r]], best_l[qcls[r]]
+        w, l = wup[qcls[r], cols], lcs[qcls[r], cols]
+        rel = cols == qcls[r]
+        if len(qp):
+            p = int(qp[0])
+            w, l, rel = np.delete(w, p), np.delete(l, p), np.delete(rel, p)
+            cw_best = np.concatenate((cw_best[:p], cw_best[p + 1:] - 1.0))
+            cl_best = np.concatenate((cl_best[:p], cl_best[p + 1:] - 1.0))
+        cw, cl = np.cumsum(w), np.cumsum(l)
+        for t, k in enumerate(ks):
+            kk = min(int(k), len(cw))
+            out[r, t] = cw[kk - 1] / cw_best[k - 1]
+            out[r, nk + t] = cl[kk - 1] / cl_best[k - 1]
+        if ahp_len == 0:
+            out[r, 2 * nk] = trapz(cw / cw_best[:len(cw)], dx=1. / len(cw))
+            out[r, 2 * nk + 1] = trapz(cl / cl_best[:len(cl)], dx=1. / len(cl))
+        elif ahp_len > 0:
+            out[r, 2 * nk] = trapz(cw[:ahp_len] / cw_best[:ahp_len], dx=1. / ahp_len)
+            out[r, 2 * nk + 1] = trapz(cl[:ahp_len] / cl_best[:ahp_len], dx=1. / ahp_len)
+        if want_ap:
+            hits = np.flatnonzero(rel)
+            out[r, 2 * nk + 2] = float(np.mean(np.arange(1, hits.size + 1) / (hits + 1.0))) if hits.size else 0.0
+    return torch.from_numpy(out)
+
+
+def _cpu_kernels():
+    from oracle import retrieval_oracle as ro
+
+    def ranking_tiles(features, normalize=False, tile_rows=None, idx64=False, queries=None, kblocks=None):
+        f = features.numpy()
+        if normalize:
+            f[:] = ro.canon_normalize_rows(f)
+        q0, q1 = (0, len(f)) if queries is None else queries
+        step = 37                                          # several ragged tiles per shard
+        for r0 in range(q0, q1, step):
+            r1 = min(q1, r0 + step)
+            pd = ro.canon_pdist(f[r0:r1], f, ro.METRIC_COSINE if normalize else ro.METRIC_EUCLID)
+            yield r0, torch.from_numpy(ro.canon_rank_rows(pd))
+
+    def local_topk(q, g, k, off):
+        d, i = ro.canon_topk_rows(ro.canon_pdist(ro.canon_normalize_rows(q.numpy()), ro.canon_normalize_rows(g.numpy()), ro.METRIC_COSINE),
+                                  k, col_offset=off)
+        return torch.from_numpy(d), torch.from_numpy(i)
+
+    def merge(d, i):
+        md, mi = ro.canon_topk_merge(d.numpy(), i.numpy())
+        return torch.from_numpy(md), torch.from_numpy(mi)
+
+    return {"ranking_tiles": ranking_tiles, "hierarchical_precision": _hprec_standin, "local_topk": local_topk, "merge": merge,
+            "device": torch.device("cpu")}
+
+
+def _hprec_worker(rank, world, port, out):
+    _setup(rank, world, port)
+    from class_hierarchy import ClassHierarchy
+    g = np.load(os.path.join(ROOT, "tests", "golden", "hierarchy_cifar.npz"))
+    parents, children = {}, {}
+    for p, c in g["edges"].tolist():
+        parents.setdefault(c, []).append(p)
+        children.setdefault(p, []).append(c)
+    hier = ClassHierarchy(parents, children)
+    labels, feats, ks = g["labels"].tolist(), g["features"], g["ks"].tolist()
+    res = {}
+    # full rankings (AP + un-clipped AHP): queries sharded, per-query rows all-gathered
+    res["full"], per_query = hier.hierarchical_precision_device(feats.copy(), labels, ks, compute_ahp=True, compute_ap=True, normalize=True,
+                                                               distributed=True, kernels=_cpu_kernels())
+    assert len(per_query["AP"]) == len(labels)
+    # the same with only the sums reduced
+    res["sums"], local = hier.hierarchical_precision_device(feats.copy(), labels, ks, compute_ahp=True, compute_ap=True, normalize=True,
+                                                            distributed=True, gather_per_query=False, kernels=_cpu_kernels())
+    assert 0 < len(local["AP"]) < len(labels)
+    # head-only metrics: gallery sharded, all-gather of per-shard top-k + merge
+    res["head"], _ = hier.hierarchical_precision_device(feats.copy(), labels, ks, compute_ahp=50, compute_ap=False, normalize=True,
+                                                        distributed=True, kernels=_cpu_kernels())
+    gathered = [None] * world
+    dist.all_gather_object(gathered, res)
+    for name in res:
+        for m in res[name]:
+            assert gathered[0][name][m] == pytest.approx(gathered[1][name][m], rel=1e-13), (name, m)
+    if rank == 0:
+        import json
+        with open(out, "w") as f:
+            json.dump(res, f)
+    dist.destroy_process_group()
+
+
+def test_rank_aware_hierarchical_precision_equals_reference_outputs(tmp_path):
+    """world 2 (gloo): query-sharded full rankings and sharded-gallery top-k both reproduce the values the imported
+    reference produced on one process (tests/golden/hierarchy_cifar.npz: ClassHierarchy.hierarchical_precision over
+    evaluate_retrieval.pairwise_retrieval, class_hierarchy.py:211-316)."""
+    import json
+    out = str(tmp_path / "hprec.json")
+    mp.spawn(_hprec_worker, args=(2, 29617, out), nprocs=2, join=True)
+    with open(out) as f:
+        res = json.load(f)
+    g = np.load(os.path.join(ROOT, "tests", "golden", "hierarchy_cifar.npz"))
+    ref = dict(zip(g["metric_names"].tolist(), g["metric_values"].tolist()))
+    checked = 0
+    for m, v in res["full"].items():
+        assert v == pytest.approx(ref["%s|norm=1|ahp=True" % m], abs=1e-10), m
+        assert res["sums"][m] == pytest.approx(v, abs=1e-12), m
+        checked += 1
+    for m, v in res["head"].items():
+        assert v == pytest.approx(ref["%s|norm=1|ahp=50" % m], abs=1e-10), m
+        checked += 1
+    assert checked >= 2 * (2 * len(g["ks"]) + 2)
+
+
+def test_evaluate_retrieval_main_is_rank_aware(monkeypatch):
+    """`evaluate_retrieval.init_distributed` follows the torch.distributed.run environment, and `main` hands `distributed`
+    to the device metric path (checked without a GPU by stubbing the heavy pieces)."""
+    import evaluate_retrieval as er
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    assert er.init_distributed() == (0, 1)
+    src = open(er.__file__).read()
+    assert "distributed=world > 1" in src and "if rank != 0:" in src

@@ -336,18 +336,20 @@ def test_golden_rankings_from_the_imported_reference(sehip, path):
     feats = g["features"].astype(np.float32)
     norm = bool(g["normalize"])
     ref = g["ref_ranking"].astype(np.int64)
+    # D > 448: the reference's BLAS restarts its FMA chain per K block; the fixture carries the probed block list
+    kblocks = g["kblocks"].tolist() if "kblocks" in g.files else None
     x = dev(feats.copy())
     if norm:
         sehip.normalize_rows_(x)
-        pd = sehip.pairwise_dist(x, None, metric=ro.METRIC_COSINE)
+        pd = sehip.pairwise_dist(x, None, metric=ro.METRIC_COSINE, kblocks=kblocks)
     else:
-        pd = sehip.pairwise_dist(x, None, metric=ro.METRIC_EUCLID)
+        pd = sehip.pairwise_dist(x, None, metric=ro.METRIC_EUCLID, kblocks=kblocks)
     rk = sehip.rank_rows(pd).cpu().numpy().astype(np.int64)
     if "ids" in g.files:
         rk = g["ids"][rk]
     pdh = pd.cpu().numpy()
     # gate 1: exactly the canonical oracle
-    cpd, crk = ro.canon_retrieval(feats, norm)
+    cpd, crk = ro.canon_retrieval(feats, norm, kblocks=kblocks)
     assert np.array_equal(pdh, cpd)
     crk = crk.astype(np.int64)
     assert np.array_equal(rk, g["ids"][crk] if "ids" in g.files else crk)
@@ -381,3 +383,47 @@ def test_full_size_properties_50k(sehip):
     want_pd = ro.canon_pdist(xn[rows], xn, ro.METRIC_COSINE)
     assert np.array_equal(pd[rows].cpu().numpy(), want_pd)
     assert np.array_equal(rk[rows].cpu().numpy(), ro.canon_rank_rows(want_pd))
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "retrieval_d*[05]_*.npz"))))
+def test_drop_in_reproduces_reference_beyond_448_with_kblocks(path):
+    """`pairwise_retrieval(..., kblocks=...)` (the product path) on the D = 555 / D = 1000 fixtures == the imported
+    reference's rankings outside exact-tie groups."""
+    import evaluate_retrieval as er
+    g = np.load(path)
+    if "kblocks" not in g.files:
+        pytest.skip("single-chain fixture")
+    feats, norm = g["features"].astype(np.float32), bool(g["normalize"])
+    ret = er.pairwise_retrieval(feats.copy(), normalize=norm, return_generator=False, kblocks=g["kblocks"].tolist())
+    rk = np.array([ret[i] for i in range(len(feats))], dtype=np.int64)
+    ref = g["ref_ranking"].astype(np.int64)
+    cpd, _ = ro.canon_retrieval(feats, norm, kblocks=g["kblocks"].tolist())
+    for r in np.nonzero((rk != ref).any(axis=1))[0]:
+        assert np.array_equal(cpd[r][rk[r]], cpd[r][ref[r]]), "row %d differs outside a tie group" % r
+
+
+@pytest.mark.parametrize("metric", ["cosine", "euclid"])
+def test_benchmarked_step_at_full_size_is_oracle_exact(sehip, metric):
+    """bench.py's exact step at BASELINE configs[2] size -- 50,000 x 50,000 x 100: normalise -> SYMMETRIC
+    pairwise_dist(x, None) (upper-triangle tile walk + mirrored stores, 391 x 391 tiles) -> rank_rows (register-resident
+    hardware-ordered kernel) -- checked by oracle/verify.py: matrix == its transpose bitwise, every row a permutation /
+    sorted / index-ascending inside ties, and >= 50 sampled rows (first / last / middle tile rows, both sides of tile
+    boundaries, random rows) bit-equal to canon.c's distances and canonical ranking."""
+    from oracle import verify
+    n, d = 50000, 100
+    x = gauss(n, d, seed=0)
+    g = dev(x)
+    m = ro.METRIC_COSINE if metric == "cosine" else ro.METRIC_EUCLID
+    if metric == "cosine":
+        sehip.normalize_rows_(g)
+        pd = sehip.pairwise_dist(g, None, metric=m)
+    else:
+        sq = sehip.row_sqnorm(g)
+        pd = sehip.pairwise_dist(g, None, metric=m, sqa=sq, sqb=sq)
+    rk = sehip.rank_rows(pd)
+    ok, detail = verify.verify_retrieval_step(g.cpu().numpy(), pd, rk, m)
+    assert ok, detail
+    assert detail["rows_checked"] >= 50 and detail["symmetric"]
+    # the reference's index dtype (int64) through the same kernels
+    rk64 = sehip.rank_rows(pd[:1024], idx64=True)
+    assert rk64.dtype == torch.int64 and bool((rk64 == rk[:1024].long()).all())
