@@ -10,14 +10,24 @@ One JSON line on stdout (rank 0).  See DESIGN.md section 6 for what a "step" is:
   resident in HBM -- row normalisation, all-pairs cosine distance matrix, full canonical ranking.
   value = query x gallery pairs ranked per second (Mpairs/s), summed over ranks.  With N > 1 every
   rank evaluates its own 50k x 50k feature set (weak scaling, no data-path collective: retrieval jobs
-  and the rows of a ranking are independent -- SURVEY.md section 8e row 2).
-* train (BASELINE.json configs[1]): ResNet-110-fc cosine-embedding training step, images/s
-  (reported in the ``train`` object of the same line when --with-train is given, or as the primary
-  metric with --workload train).
+  and the rows of a ranking are independent -- SURVEY.md section 8e row 2).  AFTER the timed region the
+  last step's results are checked against the oracle at full size (``"verified"``, oracle/verify.py).
+* the same line carries, as objects next to the headline (all timed the same way, none part of ``value``):
+  ``train`` (BASELINE.json configs[1]: ResNet-110-fc step, images/s), ``train_r50`` (configs[3]: ResNet-50 224x224,
+  200 classes, per-GPU batch 64) and ``sharded_gallery`` (configs[4], the north_star retrieval split: 50,000 queries x
+  N x 160,146 gallery rows x D = 1000, per-shard fused distance + top-251 -> RCCL all-gather -> k-way merge, with the
+  three phases timed separately).
+* ``--workload train`` makes the training step the primary metric.
+
+``--gpus N`` with N > 1 and no torch.distributed environment makes this process re-launch itself as N ranks
+(``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...``); under an existing launcher the
+world size comes from the environment and must equal ``--gpus``.  ``n_gpus`` in the line is the size of the live process group.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -32,9 +42,15 @@ import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32 matrix peak
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 peak
+# LDS floor of the 3-pass register-resident ranking: LDS wave-instructions per key x measured cycles per
+# wave-instruction of each kind (tools/probes/lds_throughput.hip, profiles/r01_i_lds_throughput_probe.txt) at 2.4 GHz, 256 CUs
+RANK_LDS_FLOOR_CYCLES_PER_KEY = 73000.0 / 50000.0
+SHADER_CLOCK_GHZ = 2.4
+N_CUS = 256
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -47,28 +63,79 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-queries", type=int, default=3072)
     ap.add_argument("--with-train", dest="with_train", action="store_true", default=True,
-                    help="also time the ResNet-110-fc training step (adds a 'train' object; default on)")
+                    help="also time the ResNet-110-fc and ResNet-50 training steps (adds 'train' / 'train_r50' objects; default on)")
     ap.add_argument("--no-train", dest="with_train", action="store_false")
+    ap.add_argument("--no-sharded", dest="with_sharded", action="store_false", default=True,
+                    help="skip the sharded-gallery top-k leg (configs[4])")
+    ap.add_argument("--no-verify", dest="verify", action="store_false", default=True, help="skip the post-run oracle check")
     ap.add_argument("--batch", type=int, default=128, help="per-GPU batch (train)")
     ap.add_argument("--arch", default="resnet-110-fc")
-    return ap.parse_args()
+    ap.add_argument("--shard-rows", type=int, default=160146, help="gallery rows per rank of the sharded-gallery leg (1,281,167 / 8)")
+    ap.add_argument("--shard-queries", type=int, default=50000)
+    ap.add_argument("--shard-dim", type=int, default=1000)
+    ap.add_argument("--shard-k", type=int, default=251)
+    ap.add_argument("--dry", action="store_true",
+                    help="CPU plumbing test: gloo process group, tiny shapes, CPU stand-ins for the kernels (no measurement)")
+    return ap.parse_args(argv)
+
+
+# ---------------------------------------------------------------------------------------------
+# process group
+# ---------------------------------------------------------------------------------------------
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def maybe_spawn(args, argv):
+    """``--gpus N`` without a launcher: re-exec as N ranks.  Returns the exit code of the launcher, or None to continue."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return None
+    if not args.dry:
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            raise SystemExit("bench.py --gpus %d: only %d ROCm device(s) visible" % (args.gpus, have))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # dmabuf IPC only on this host driver (RCCL / tensor sharing)
+    return subprocess.call(cmd, env=env)
 
 
 def init_dist(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local)
+    if world != max(args.gpus, 1):
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
+    if not args.dry:
+        if torch.cuda.device_count() <= local:
+            raise SystemExit("bench.py: rank %d has no device %d (%d visible)" % (rank, local, torch.cuda.device_count()))
+        torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)   # "nccl" == RCCL on ROCm
+        dist.init_process_group("gloo" if args.dry else "nccl", rank=rank, world_size=world)   # "nccl" == RCCL on ROCm
+        world = dist.get_world_size()        # n_gpus = the live process group
     return rank, world, local
 
 
-def barrier_sync(world):
+def barrier_sync(world, dry=False):
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    if not dry:
+        torch.cuda.synchronize()
+
+
+def max_over_ranks(value, world, device):
+    if world == 1:
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
 
 
 class KernelTimer:
@@ -96,6 +163,20 @@ class KernelTimer:
 # retrieval workload
 # ---------------------------------------------------------------------------------------------
 
+def pdist_cost_model(q, n, d, symmetric, tile=128):
+    """Algorithmic bytes, executed flops and the binding floor of one se_pairwise_dist launch.  In symmetric
+    mode only the upper-triangle tiles are computed (each is stored twice), so the matrix pipe executes about half of 2 q n d."""
+    bytes_ = 4.0 * q * n + 4.0 * (q + n) * d
+    full = 2.0 * q * n * d
+    if symmetric:
+        t = (n + tile - 1) // tile
+        executed = (t * (t + 1) // 2) * (tile * tile) * 2.0 * d
+    else:
+        executed = full
+    floor_ms = max(executed / (MFMA_F32_PEAK_TFLOPS * 1e12), bytes_ / (HBM_PEAK_GBS * 1e9)) * 1e3
+    return bytes_, full, executed, floor_ms
+
+
 def bench_retrieval(args, rank, world):
     import sehip
     n, d = args.n, args.d
@@ -115,6 +196,7 @@ def bench_retrieval(args, rank, world):
     pd = torch.empty((q, n), dtype=torch.float32, device="cuda")
     rk = torch.empty((q, n), dtype=torch.int32, device="cuda")
     timer = None
+    last = {}
 
     def step():
         g = gallery0.clone()
@@ -130,6 +212,7 @@ def bench_retrieval(args, rank, world):
             sqq = sq if qs is g else sehip.row_sqnorm(qs)
             t("pairwise_dist", lambda: sehip.pairwise_dist(qs, g, metric=metric, sqa=sqq, sqb=sq, out=pd))
         t("rank_rows", lambda: sehip.rank_rows(pd, out=rk))
+        last["g"], last["q"] = g, (None if qs is g else qs)
 
     for _ in range(args.warmup):
         step()
@@ -139,32 +222,42 @@ def bench_retrieval(args, rank, world):
     for _ in range(args.steps):
         step()
     barrier_sync(world)
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = max_over_ranks(time.perf_counter() - t0, world, "cuda")
     kms = timer.avg_ms()
 
     pairs_per_step = float(q) * n * world
     value = pairs_per_step * args.steps / elapsed / 1e6
     # algorithmic bytes / flops per launch
-    pd_bytes = 4.0 * q * n + 4.0 * (q + n) * d
-    pd_flops = 2.0 * q * n * d
+    pd_bytes, pd_full, pd_exec, pd_floor = pdist_cost_model(q, n, d, symmetric=queries0 is None)
     rk_bytes = 4.0 * q * n + 4.0 * q * n
+    rk_lds_floor_ms = RANK_LDS_FLOOR_CYCLES_PER_KEY * q * n / (N_CUS * SHADER_CLOCK_GHZ * 1e9) * 1e3
+    pms, rms = kms["pairwise_dist"], kms["rank_rows"]
     kernels = {
-        "pairwise_dist": {"ms": kms.get("pairwise_dist"), "algorithmic_GB": pd_bytes / 1e9,
-                          "GBps": pd_bytes / 1e6 / kms["pairwise_dist"], "frac_hbm": pd_bytes / 1e6 / kms["pairwise_dist"] / HBM_PEAK_GBS,
-                          "TFLOPs": pd_flops / 1e9 / kms["pairwise_dist"], "frac_mfma_f32": pd_flops / 1e9 / kms["pairwise_dist"] / MFMA_F32_PEAK_TFLOPS},
-        "rank_rows": {"ms": kms.get("rank_rows"), "algorithmic_GB": rk_bytes / 1e9,
-                      "GBps": rk_bytes / 1e6 / kms["rank_rows"], "frac_hbm": rk_bytes / 1e6 / kms["rank_rows"] / HBM_PEAK_GBS},
+        "pairwise_dist": {"ms": pms, "algorithmic_GB": pd_bytes / 1e9, "GBps": pd_bytes / 1e6 / pms, "frac_hbm": pd_bytes / 1e6 / pms / HBM_PEAK_GBS,
+                          "mode": "symmetric (upper-triangle tiles, mirrored stores)" if queries0 is None else "general",
+                          "flops_full_matrix": pd_full, "flops_executed": pd_exec,
+                          "TFLOPs_executed": pd_exec / 1e9 / pms, "frac_mfma_f32": pd_exec / 1e9 / pms / MFMA_F32_PEAK_TFLOPS,
+                          "floor_ms": pd_floor, "floor": "max(executed flops / 157.3 TFLOP/s, algorithmic bytes / 8 TB/s)",
+                          "frac_of_floor": pd_floor / pms},
+        "rank_rows": {"ms": rms, "algorithmic_GB": rk_bytes / 1e9, "GBps": rk_bytes / 1e6 / rms, "frac_hbm": rk_bytes / 1e6 / rms / HBM_PEAK_GBS,
+                      "lds_floor_ms": rk_lds_floor_ms, "frac_of_lds_floor": rk_lds_floor_ms / rms,
+                      "lds_floor": "3-pass LSD radix, 17.25 LDS wave-instructions per 64 keys at their measured throughput "
+                                   "(DESIGN.md 5.2), 256 CUs x 2.4 GHz"},
     }
     dominant = max(("pairwise_dist", "rank_rows"), key=lambda k: kms[k])
     tr = pmc_traffic_gb(dominant, q, n, d)
-    roofline = {"kernel": dominant, "bound": "hbm", "achieved": kernels[dominant]["GBps"], "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": kernels[dominant]["frac_hbm"],
+    # `frac` is always the HBM fraction (algorithmic bytes / time / 8 TB/s).  The ranking kernel moves 1.03x its algorithmic bytes
+    # (PMC) and still sits far below the HBM roofline: what binds it is the LDS pipe, reported as such.
+    roofline = {"kernel": dominant, "bound": "lds" if dominant == "rank_rows" else "hbm", "achieved": kernels[dominant]["GBps"],
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kernels[dominant]["frac_hbm"],
                 "traffic": None if tr is None else tr["bytes"],          # HBM bytes per launch (PMC), vs algorithmic_GB below
                 "algorithmic_bytes": kernels[dominant]["algorithmic_GB"] * 1e9, "traffic_detail": tr}
+    if dominant == "rank_rows":
+        roofline["lds_floor_ms"] = rk_lds_floor_ms
+        roofline["frac_of_lds_floor"] = rk_lds_floor_ms / rms
+    else:
+        roofline["floor_ms"] = pd_floor
+        roofline["frac_of_floor"] = pd_floor / pms
     out = {
         "metric": "retrieval_Mpairs_per_sec", "value": value, "unit": "Mpairs/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -175,7 +268,29 @@ def bench_retrieval(args, rank, world):
                    "parallelism": "%d independent feature sets, one per GPU (no collective)" % world},
         "roofline": roofline, "kernels": kernels,
     }
+    if args.verify:
+        out.update(verify_last_step(last, pd, rk, metric, world))
     return out, feats_h
+
+
+def verify_last_step(last, pd, rk, metric, world):
+    """AFTER the timed region: the last step's distance matrix and ranking against the oracle (oracle/verify.py -- the checker,
+    never the thing measured): every row a permutation / sorted / index-ascending inside ties, the all-pairs matrix equal to its
+    transpose bitwise, >= 50 sampled rows bit-equal to canon.c's FMA chain and canonical ranking."""
+    try:
+        from oracle import verify
+        t0 = time.perf_counter()
+        feats = last["g"].cpu().numpy()
+        queries = None if last["q"] is None else last["q"].cpu().numpy()
+        ok, detail = verify.verify_retrieval_step(feats, pd, rk, metric, queries=queries)
+        detail["seconds"] = time.perf_counter() - t0
+    except Exception as e:       # a checker failure must not lose the measurement, but it must show
+        ok, detail = False, {"error": "%s: %s" % (type(e).__name__, e)}
+    if world > 1:
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        ok = bool(int(flag.item()))
+    return {"verified": bool(ok), "verify_detail": detail}
 
 
 def pmc_traffic_gb(kernel, q, n, d):
@@ -195,23 +310,130 @@ def pmc_traffic_gb(kernel, q, n, d):
 
 
 def cpu_baseline_retrieval(args, feats_h):
-    """The reference's NumPy op sequence (oracle port) on a bounded query sample, host cores."""
+    """The reference's NumPy op sequence (oracle port) on a bounded query sample, host cores.  `value` uses the reference's own
+    call, ``np.argsort`` with the default kind (evaluate_retrieval.py:67; NumPy 2.x: a vectorised quicksort); the stable kind
+    (the canonical tie order) is timed beside it."""
     from oracle import retrieval_oracle as ro
     qn = min(args.cpu_sample_queries, feats_h.shape[0])
     f = feats_h.copy()
     t0 = time.perf_counter()
-    rank = ro.pairwise_retrieval_numpy(f, normalize=(args.metric == "cosine"), queries=slice(0, qn))
-    dt = time.perf_counter() - t0
-    assert rank.shape == (qn, feats_h.shape[0])
-    return {"value": qn * feats_h.shape[0] / dt / 1e6, "unit": "Mpairs/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": "%d of %d queries x %d gallery, D=%d: np.linalg.norm + np.dot (BLAS threads = all cores) + "
-                      "np.argsort(kind='stable') (single-threaded in NumPy), %.1f s" % (qn, feats_h.shape[0], feats_h.shape[0], feats_h.shape[1], dt)}
+    pdm = ro.pdist_numpy(f, normalize=(args.metric == "cosine"), queries=slice(0, qn))
+    t1 = time.perf_counter()
+    rank = np.argsort(pdm, axis=-1)
+    t2 = time.perf_counter()
+    rank_s = np.argsort(pdm, axis=-1, kind="stable")
+    t3 = time.perf_counter()
+    assert rank.shape == rank_s.shape == (qn, feats_h.shape[0])
+    n = feats_h.shape[0]
+    return {"value": qn * n / (t2 - t0) / 1e6, "unit": "Mpairs/s", "cores": os.cpu_count(), "kind": "port",
+            "value_stable_argsort": qn * n / ((t1 - t0) + (t3 - t2)) / 1e6,
+            "seconds": {"norm_and_dot": t1 - t0, "argsort_default": t2 - t1, "argsort_stable": t3 - t2},
+            "sample": "%d of %d queries x %d gallery, D=%d: np.linalg.norm + np.dot (BLAS threads = all cores) + np.argsort "
+                      "(default kind as the reference calls it; single-threaded in NumPy), %.1f s" % (qn, n, n, feats_h.shape[1], t2 - t0)}
 
 
-def main():
-    args = parse()
+# ---------------------------------------------------------------------------------------------
+# sharded-gallery leg (BASELINE.json configs[4]; north_star: "retrieval shards the gallery with a final RCCL all-gather of
+# per-shard top-k")
+# ---------------------------------------------------------------------------------------------
+
+def bench_sharded_gallery(args, rank, world, reps=2):
+    """50,000 queries (replicated) x world * 160,146 gallery rows (sharded) x D = 1000, k = 251: per-shard fused distance +
+    top-k (se_retrieve_topk) -> RCCL all-gather of the [Q, k] (f32, i32) lists -> se_topk_merge; each phase timed separately
+    with barriers in between (HIP events on the launch stream for the kernels, host clock around the collective)."""
+    import sehip
+    Q, NS, D, K = args.shard_queries, args.shard_rows, args.shard_dim, args.shard_k
+    gen = torch.Generator(device="cuda").manual_seed(1000 + rank)
+    shard = torch.randn((NS, D), generator=gen, device="cuda", dtype=torch.float32)
+    gq = torch.Generator(device="cuda").manual_seed(7)              # the same queries on every rank
+    queries = torch.randn((Q, D), generator=gq, device="cuda", dtype=torch.float32)
+    sehip.normalize_rows_(shard)
+    sehip.normalize_rows_(queries)
+    off = rank * NS
+    all_d = torch.empty((world * Q, K), dtype=torch.float32, device="cuda")
+    all_i = torch.empty((world * Q, K), dtype=torch.int32, device="cuda")
+    t_local, t_gather, t_merge = [], [], []
+    md = mi = None
+    for it in range(reps + 1):
+        barrier_sync(world)
+        t0 = time.perf_counter()
+        d, i = sehip.retrieve_topk(queries, shard, K, metric=sehip.METRIC_COSINE, col_offset=off)
+        barrier_sync(world)
+        t1 = time.perf_counter()
+        if world > 1:
+            dist.all_gather_into_tensor(all_d, d)
+            dist.all_gather_into_tensor(all_i, i)
+        else:
+            all_d.copy_(d)
+            all_i.copy_(i)
+        barrier_sync(world)
+        t2 = time.perf_counter()
+        md, mi = sehip.topk_merge(all_d.view(world, Q, K), all_i.view(world, Q, K))
+        barrier_sync(world)
+        t3 = time.perf_counter()
+        if it > 0:            # first round: workspace allocation, RCCL channel set-up
+            t_local.append(t1 - t0)
+            t_gather.append(t2 - t1)
+            t_merge.append(t3 - t2)
+    loc, gat, mer = (max_over_ranks(float(np.mean(t)), world, "cuda") * 1e3 for t in (t_local, t_gather, t_merge))
+    # size-independent sanity of the merged lists (the per-kernel parity tests carry the bit-exact checks)
+    sorted_ok = bool((md[:, 1:] >= md[:, :-1]).all()) and bool(((md[:, 1:] > md[:, :-1]) | (mi[:, 1:] > mi[:, :-1])).all())
+    in_range = bool(((mi >= 0) & (mi < world * NS)).all())
+    total = loc + gat + mer
+    flops = 2.0 * Q * NS * D
+    return {"metric": "sharded_retrieval_Mpairs_per_sec", "value": float(Q) * NS * world / total / 1e3, "unit": "Mpairs/s", "n_gpus": world,
+            "ms": {"local_topk": loc, "all_gather": gat, "merge": mer, "total": total}, "reps": reps,
+            "config": {"workload": "ILSVRC-sized sharded-gallery retrieval: %d queries x %d x %d gallery rows, D=%d, k=%d, cosine"
+                                   % (Q, world, NS, D, K), "queries": Q, "gallery_rows_per_gpu": NS, "dim": D, "k": K,
+                       "parallelism": "gallery sharded %d ways, RCCL all-gather of per-shard top-k, canonical merge" % world},
+            "all_gather_bytes_per_rank": Q * K * 8, "all_gather_GBps_per_rank": (world - 1) * Q * K * 8 / 1e6 / gat if world > 1 else None,
+            "local_topk_TFLOPs": flops / 1e9 / loc, "local_topk_frac_mfma_f32": flops / 1e9 / loc / MFMA_F32_PEAK_TFLOPS,
+            "merged_lists_sorted_with_index_tiebreak": sorted_ok, "merged_indices_in_range": in_range, "scaling": "weak",
+            "data": "synthetic"}
+
+
+# ---------------------------------------------------------------------------------------------
+# dry mode (CPU plumbing test of the launcher / process-group / line assembly; no kernels, no measurement)
+# ---------------------------------------------------------------------------------------------
+
+def bench_dry(args, rank, world):
+    from oracle import retrieval_oracle as ro
+    import sharded_retrieval as sr
+    rng = np.random.default_rng(0)
+    gallery = rng.standard_normal((64 * world, 16)).astype(np.float32)
+    queries = torch.from_numpy(gallery[:8].copy())
+    lo, hi = sr.shard_bounds(len(gallery), world)[rank]
+
+    def local_topk(q, g, k, off):
+        d, i = ro.canon_topk_rows(ro.canon_pdist(q.numpy(), g.numpy(), ro.METRIC_COSINE), k, col_offset=off)
+        return torch.from_numpy(d), torch.from_numpy(i)
+
+    def merge(d, i):
+        md, mi = ro.canon_topk_merge(d.numpy(), i.numpy())
+        return torch.from_numpy(md), torch.from_numpy(mi)
+
+    barrier_sync(world, dry=True)
+    t0 = time.perf_counter()
+    d, i = sr.sharded_topk(queries, torch.from_numpy(gallery[lo:hi]), 5, lo, local_topk=local_topk, merge=merge)
+    barrier_sync(world, dry=True)
+    dt = max_over_ranks(time.perf_counter() - t0, world, "cpu")
+    want = ro.canon_topk_rows(ro.canon_pdist(gallery[:8], gallery, ro.METRIC_COSINE), 5)[1]
+    return {"metric": "dry_run", "value": 0.0, "unit": "none", "n_gpus": world, "dry": True, "steps": 1, "warmup": 0,
+            "ms_per_step": dt * 1e3, "sharded_topk_matches_unsharded": bool(np.array_equal(i.numpy(), want)), "data": "synthetic"}
+
+
+# ---------------------------------------------------------------------------------------------
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse(argv)
+    rc = maybe_spawn(args, argv)
+    if rc is not None:
+        sys.exit(rc)
     rank, world, _ = init_dist(args)
-    if args.workload == "train":
+    if args.dry:
+        out = bench_dry(args, rank, world)
+    elif args.workload == "train":
         from train_bench import bench_train
         out = bench_train(args, rank, world)
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -219,12 +441,21 @@ def main():
             out["cpu_baseline"] = cpu_baseline_train(args)
     else:
         out, feats_h = bench_retrieval(args, rank, world)
-        if args.with_train:
+
+        def leg(name, fn):        # the retrieval line must survive a failure of a secondary leg -- but every rank must agree
             try:
-                from train_bench import bench_train
-                out["train"] = bench_train(args, rank, world)
-            except Exception as e:   # the retrieval line must survive a training-side failure
-                out["train"] = {"error": "%s: %s" % (type(e).__name__, e)}
+                out[name] = fn()
+            except Exception as e:
+                out[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+
+        if args.with_sharded:
+            leg("sharded_gallery", lambda: bench_sharded_gallery(args, rank, world))
+            torch.cuda.empty_cache()
+        if args.with_train:
+            from train_bench import bench_train
+            leg("train", lambda: bench_train(args, rank, world))
+            r50 = argparse.Namespace(**dict(vars(args), arch="resnet-50", batch=64))
+            leg("train_r50", lambda: bench_train(r50, rank, world))
         if rank == 0 and world == 1 and not args.no_cpu_baseline:      # reported baselines: rank 0 at N = 1 only, bounded samples
             out["cpu_baseline"] = cpu_baseline_retrieval(args, feats_h)
             if args.with_train and "error" not in out["train"]:
@@ -235,6 +466,7 @@ def main():
                     out["train"]["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if rank == 0:
         print(json.dumps(out))
+        sys.stdout.flush()
     if world > 1:
         dist.destroy_process_group()
 

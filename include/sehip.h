@@ -140,6 +140,26 @@ int se_labelembed_loss_bwd(const float *out1, int64_t ld1, const float *out2, in
                            float alpha, float beta, const float *aux, float *d_out1, int64_t ldd1,
                            float *d_out2, int64_t ldd2, float *d_tar, int64_t lddt, se_stream_t stream);
 
+/*
+ * DeViSE ranking loss on the class-embedding contraction, forward + backward.
+ * Replaces: utils.devise_ranking_loss(embedding, margin)(y_true, y_pred)  (utils.py:103-122)
+ *           loss_i = sum_c relu(margin - <y_true_i, y_pred_i> + (y_pred . E^T)[i, c]) - margin
+ *           and what TF autodiff derives from it w.r.t. y_pred.
+ *   y_pred [B, D] f32; the target rows are E[labels[i]] (labels != NULL, y_true == NULL: the gather of
+ *   learn_image_embeddings.py:48-50 done on the device) or the explicit matrix y_true [B, D] (the reference's convention);
+ *   emb [C, D] f32; loss_i [B] out.
+ *   aux: se_devise_aux_floats(B, C) floats, caller-owned: true_sim [B], active-hinge count [B] and the 0 / 1 hinge mask [B, C]
+ *        written by the forward pass and consumed by the backward pass (d y_pred = g_i (mask . E - count_i y_true_i)).
+ *   grad_loss_i [B] or NULL (then every sample uses grad_scale).
+ */
+int64_t se_devise_aux_floats(int64_t B, int64_t C);
+int se_devise_loss_fwd(const float *y_pred, int64_t ldp, const int64_t *labels, const float *y_true, int64_t ldt,
+                       const float *emb, int64_t lde, int64_t B, int64_t D, int64_t C, float margin, float *loss_i,
+                       float *aux, se_stream_t stream);
+int se_devise_loss_bwd(const int64_t *labels, const float *y_true, int64_t ldt, const float *emb, int64_t lde,
+                       const float *grad_loss_i, float grad_scale, int64_t B, int64_t D, int64_t C, const float *aux,
+                       float *d_pred, int64_t lddp, se_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Retrieval side  (evaluate_retrieval.pairwise_retrieval, evaluate_retrieval.py:22-73)
  * ------------------------------------------------------------------------------------------ */

@@ -1,0 +1,227 @@
+// devise.hip -- DeViSE ranking loss on the class-embedding contraction, forward + backward.
+//
+// Replaces `utils.devise_ranking_loss(embedding, margin)(y_true, y_pred)` (utils.py:103-122):
+//     true_sim_i  = sum_d y_true[i, d] * y_pred[i, d]
+//     other_sim   = y_pred . E^T                                  [B, C]
+//     loss_i      = sum_c relu(margin - true_sim_i + other_sim[i, c]) - margin
+// and what TF autodiff derives from it w.r.t. y_pred (y_true is the target):
+//     d y_pred[i, :] = g_i * ( sum_c a_ic * E[c, :]  -  n_i * y_true[i, :] ),   a_ic = [margin - true_sim_i + other_sim[i, c] > 0],
+//                                                                               n_i = sum_c a_ic.
+// Both contractions run on v_mfma_f32_32x32x2_f32 (one wave per 32 x 32 output tile, operands staged through LDS in K-chunks
+// of 64 with even / odd k de-interleaved so every lane feeds four MFMA steps from one 16-byte LDS read -- the layout of
+// se_nn_accuracy); the hinge, its row sums and the active mask are fused into the forward epilogue, the mask is the left
+// operand of the backward contraction (0 / 1 entries: the sums of E rows are exact in chain order).
+// y_true is either gathered on the device from the resident class embeddings (labels; learn_image_embeddings.py:48-50 feeds
+// embedding[y]) or an explicit [B, D] matrix (the reference's calling convention).
+#include "se_common.h"
+
+namespace se {
+
+typedef float dv_f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int DV_BK = 64;            // k per staged chunk
+constexpr int DV_LD = DV_BK + 4;     // padded row pitch (floats): conflict-free ds_read_b128
+
+// 32 rows x 64 k of a row-major [rows, K] matrix -> LDS, even k to [0, 32), odd k to [32, 64) of each row; zero outside
+__device__ __forceinline__ void dv_stage(float *lds, const float *src, int64_t ld, int64_t row0, int64_t nrows, int64_t k0, int64_t K)
+{
+    const int lane = lane_id();
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+        const int idx = it * 64 + lane;
+        const int r = idx >> 4, kq = (idx & 15) * 4;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (row0 + r < nrows) {
+            const float *p = src + (row0 + r) * ld + k0 + kq;
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (k0 + kq + j < K) v[j] = p[j];
+        }
+        float *o = lds + r * DV_LD;
+        o[(kq >> 1)] = v[0];
+        o[(kq >> 1) + 1] = v[2];
+        o[32 + (kq >> 1)] = v[1];
+        o[32 + (kq >> 1) + 1] = v[3];
+    }
+}
+
+// the same tile of the TRANSPOSE of a row-major [K, cols] matrix: LDS row r = column col0 + r of `src`, k = its row index
+__device__ __forceinline__ void dv_stage_t(float *lds, const float *src, int64_t ld, int64_t col0, int64_t ncols, int64_t k0, int64_t K)
+{
+    const int lane = lane_id();
+    const int r = lane & 31;
+#pragma unroll
+    for (int it = 0; it < 32; it++) {
+        const int k = it * 2 + (lane >> 5);                                 // 32 consecutive columns of one source row per half-wave
+        float v = 0.f;
+        if (k0 + k < K && col0 + r < ncols) v = src[(k0 + k) * ld + col0 + r];
+        lds[r * DV_LD + ((k & 1) ? 32 : 0) + (k >> 1)] = v;
+    }
+}
+
+__device__ __forceinline__ dv_f32x16 dv_mma_chunk(dv_f32x16 acc, const float *sA, const float *sB, int col, int hi, int64_t kc)
+{
+    const int steps = (int)((kc + 1) / 2);
+    const float *pa = sA + col * DV_LD + hi * 32;
+    const float *pb = sB + col * DV_LD + hi * 32;
+    for (int s = 0; s < steps; s += 4) {
+        const float4 a4 = *(const float4 *)(pa + s);
+        const float4 b4 = *(const float4 *)(pb + s);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.x, b4.x, acc, 0, 0, 0);
+        if (s + 1 < steps) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.y, b4.y, acc, 0, 0, 0);
+        if (s + 2 < steps) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.z, b4.z, acc, 0, 0, 0);
+        if (s + 3 < steps) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.w, b4.w, acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+// aux layout: true_sim [B] | n_active [B] | mask [B, C]
+__global__ __launch_bounds__(64) void devise_fwd_kernel(const float *__restrict__ yp, int64_t ldp, const int64_t *__restrict__ labels,
+                                                        const float *__restrict__ yt, int64_t ldt, const float *__restrict__ emb, int64_t lde,
+                                                        int64_t B, int64_t D, int64_t C, float margin, float *__restrict__ loss_i,
+                                                        float *__restrict__ aux)
+{
+    __shared__ __attribute__((aligned(16))) float sA[32 * DV_LD];
+    __shared__ __attribute__((aligned(16))) float sB[32 * DV_LD];
+    __shared__ float sTrue[32];
+    const int lane = lane_id();
+    const int col = lane & 31, hi = lane >> 5;
+    const int64_t row0 = (int64_t)blockIdx.x * 32;
+    float *mask = aux + 2 * B;
+
+    // true_sim (utils.py:118): one k-ascending fmaf chain per sample, split over the two half-waves (even / odd half of D)
+    {
+        const int64_t r = row0 + col;
+        float t = 0.f;
+        if (r < B) {
+            const float *p = yp + r * ldp;
+            const float *e;
+            if (yt) e = yt + r * ldt;
+            else {
+                int64_t y = labels[r];
+                y = y < 0 ? 0 : (y >= C ? C - 1 : y);
+                e = emb + y * lde;
+            }
+            const int64_t half = (D + 1) / 2, d0 = hi ? half : 0, d1 = hi ? D : half;
+            for (int64_t d = d0; d < d1; d++) t = fmaf(p[d], e[d], t);
+        }
+        t += __shfl_xor(t, 32, 64);
+        if (hi == 0) sTrue[col] = t;
+    }
+    __syncthreads();
+
+    float hinge[16], nact[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) { hinge[r] = 0.f; nact[r] = 0.f; }
+
+    for (int64_t c0 = 0; c0 < C; c0 += 32) {
+        dv_f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[r] = 0.f;
+        for (int64_t k0 = 0; k0 < D; k0 += DV_BK) {
+            __syncthreads();
+            dv_stage(sA, yp, ldp, row0, B, k0, D);
+            dv_stage(sB, emb, lde, c0, C, k0, D);
+            __syncthreads();
+            acc = dv_mma_chunk(acc, sA, sB, col, hi, (D - k0 < DV_BK) ? (D - k0) : DV_BK);
+        }
+        const int64_t c = c0 + col;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int lr = (r & 3) + 8 * (r >> 2) + 4 * hi;      // row of this accumulator register
+            const bool valid = (c < C) && (row0 + lr < B);
+            const float h = (margin - sTrue[lr]) + acc[r];       // margin - true_sim[:, None] + other_sim (utils.py:120)
+            const bool on = valid && h > 0.f;
+            if (on) { hinge[r] += h; nact[r] += 1.f; }
+            if (valid) mask[(row0 + lr) * C + c] = on ? 1.f : 0.f;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+#pragma unroll
+        for (int off = 1; off < 32; off <<= 1) {
+            hinge[r] += __shfl_xor(hinge[r], off, 64);
+            nact[r] += __shfl_xor(nact[r], off, 64);
+        }
+        const int lr = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (col == 0 && row0 + lr < B) {
+            loss_i[row0 + lr] = hinge[r] - margin;
+            aux[row0 + lr] = sTrue[lr];
+            aux[B + row0 + lr] = nact[r];
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void devise_bwd_kernel(const int64_t *__restrict__ labels, const float *__restrict__ yt, int64_t ldt,
+                                                        const float *__restrict__ emb, int64_t lde, const float *__restrict__ grad_loss_i,
+                                                        float grad_scale, int64_t B, int64_t D, int64_t C, const float *__restrict__ aux,
+                                                        float *__restrict__ dpred, int64_t lddp)
+{
+    __shared__ __attribute__((aligned(16))) float sA[32 * DV_LD];
+    __shared__ __attribute__((aligned(16))) float sB[32 * DV_LD];
+    const int lane = lane_id();
+    const int col = lane & 31, hi = lane >> 5;
+    const int64_t row0 = (int64_t)blockIdx.x * 32, d0 = (int64_t)blockIdx.y * 32;
+    const float *mask = aux + 2 * B;
+    dv_f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = 0.f;
+    for (int64_t c0 = 0; c0 < C; c0 += DV_BK) {          // contraction over the classes
+        __syncthreads();
+        dv_stage(sA, mask, C, row0, B, c0, C);
+        dv_stage_t(sB, emb, lde, d0, D, c0, C);
+        __syncthreads();
+        acc = dv_mma_chunk(acc, sA, sB, col, hi, (C - c0 < DV_BK) ? (C - c0) : DV_BK);
+    }
+    const int64_t d = d0 + col;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int64_t i = row0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (i < B && d < D) {
+            float t;
+            if (yt) t = yt[i * ldt + d];
+            else {
+                int64_t y = labels[i];
+                y = y < 0 ? 0 : (y >= C ? C - 1 : y);
+                t = emb[y * lde + d];
+            }
+            const float g = grad_loss_i ? grad_loss_i[i] : grad_scale;
+            dpred[i * lddp + d] = g * (acc[r] - aux[B + i] * t);
+        }
+    }
+}
+
+}  // namespace se
+
+using namespace se;
+
+extern "C" int64_t se_devise_aux_floats(int64_t B, int64_t C) { return (B > 0 && C > 0) ? 2 * B + B * C : 0; }
+
+extern "C" int se_devise_loss_fwd(const float *y_pred, int64_t ldp, const int64_t *labels, const float *y_true, int64_t ldt,
+                                  const float *emb, int64_t lde, int64_t B, int64_t D, int64_t C, float margin, float *loss_i,
+                                  float *aux, se_stream_t stream)
+{
+    if (B < 0 || D <= 0 || C <= 0) return fail(SE_ERR_INVALID, "se_devise_loss_fwd: bad shape B=%lld D=%lld C=%lld", (long long)B, (long long)D, (long long)C);
+    if (B == 0) return SE_OK;
+    if (!y_pred || !emb || !loss_i || !aux || (!labels && !y_true)) return fail(SE_ERR_INVALID, "se_devise_loss_fwd: null pointer");
+    if (ldp < D || lde < D || (y_true && ldt < D)) return fail(SE_ERR_INVALID, "se_devise_loss_fwd: leading dimension < D");
+    hipLaunchKernelGGL(devise_fwd_kernel, dim3((unsigned)((B + 31) / 32)), dim3(64), 0, (hipStream_t)stream, y_pred, ldp, labels, y_true, ldt,
+                       emb, lde, B, D, C, margin, loss_i, aux);
+    SE_LAUNCH_CHECK();
+    return SE_OK;
+}
+
+extern "C" int se_devise_loss_bwd(const int64_t *labels, const float *y_true, int64_t ldt, const float *emb, int64_t lde,
+                                  const float *grad_loss_i, float grad_scale, int64_t B, int64_t D, int64_t C, const float *aux,
+                                  float *d_pred, int64_t lddp, se_stream_t stream)
+{
+    if (B < 0 || D <= 0 || C <= 0) return fail(SE_ERR_INVALID, "se_devise_loss_bwd: bad shape");
+    if (B == 0) return SE_OK;
+    if (!emb || !aux || !d_pred || (!labels && !y_true)) return fail(SE_ERR_INVALID, "se_devise_loss_bwd: null pointer");
+    if (lde < D || lddp < D || (y_true && ldt < D)) return fail(SE_ERR_INVALID, "se_devise_loss_bwd: leading dimension < D");
+    if ((D + 31) / 32 > 65535) return fail(SE_ERR_UNSUPPORTED, "se_devise_loss_bwd: D too large");
+    hipLaunchKernelGGL(devise_bwd_kernel, dim3((unsigned)((B + 31) / 32), (unsigned)((D + 31) / 32)), dim3(64), 0, (hipStream_t)stream, labels,
+                       y_true, ldt, emb, lde, grad_loss_i, grad_scale, B, D, C, aux, d_pred, lddp);
+    SE_LAUNCH_CHECK();
+    return SE_OK;
+}

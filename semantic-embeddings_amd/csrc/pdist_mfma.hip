@@ -268,8 +268,12 @@ __global__ __launch_bounds__(PD_THREADS, 2 * PD_WGS_PER_CU) void pdist_kernel(
     bool first_kb = true;
 
     // tuning aid (SE_PD_PROFILE=1): shader-clock cycles per phase of every workgroup's wave 0
+#ifdef SE_TUNING
     uint64_t t_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_last = prof ? __builtin_amdgcn_s_memtime() : 0;
 #define PD_T(i) if (prof) { const uint64_t now = __builtin_amdgcn_s_memtime(); t_acc[i] += now - t_last; t_last = now; }
+#else
+#define PD_T(i)
+#endif
     const int64_t total = my_tiles * nchunks;
 #pragma unroll 1
     for (int64_t it = 0; it < total; it++) {
@@ -424,21 +428,22 @@ __global__ __launch_bounds__(PD_THREADS, 2 * PD_WGS_PER_CU) void pdist_kernel(
             PD_T(5)
         }
     }
+#ifdef SE_TUNING
     if (prof && threadIdx.x == 0)
         for (int i = 0; i < 12; i++) atomicAdd(&prof[i], (unsigned long long)t_acc[i]);
+#endif
 #undef PD_T
 #undef PD_FETCH
 }
 
 static int pd_num_cus()
 {
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0;
+    static const int cus = [] {   // (thread-safe one-time initialisation; one process drives one GPU model)
+        int dev = 0, n = 0;
         hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-        if (cus <= 0) cus = 256;
-    }
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        return n > 0 ? n : 256;
+    }();
     return cus;
 }
 
@@ -453,9 +458,18 @@ static int launch_pdist3(const float *a, int64_t lda, const float *b, int64_t ld
     if ((lda % 4 == 0) && ((((uintptr_t)a) & 15) == 0)) flags |= PDF_VEC_A;
     if ((ldb % 4 == 0) && ((((uintptr_t)b) & 15) == 0)) flags |= PDF_VEC_B;
     if ((ldo % 4 == 0) && ((((uintptr_t)out) & 15) == 0)) flags |= PDF_VEC_O;
-    if (const char *e = getenv("SE_PD_ABLATE")) { const int a = atoi(e); flags |= (a & 3) * PDF_NO_STORE; if (a & 4) flags |= PDF_NO_GSTORE; }   // tuning aid: 1 = no epilogue, 2 = no MFMA, 4 = epilogue without global stores
-    if (!getenv("SE_PD_NOSTAGGER")) flags |= PDF_STAGGER;
-    if (getenv("SE_PD_PLAIN_ST")) flags |= PDF_PLAIN_ST;
+    flags |= PDF_STAGGER;
+    if (kTuning) {   // -DSE_TUNING build only (the product library never skips work): ablations of the tuning sessions
+        static const int tune = [] {
+            int f = 0;
+            if (const char *e = tuning_env("SE_PD_ABLATE")) { const int a = atoi(e); f |= (a & 3) * PDF_NO_STORE; if (a & 4) f |= PDF_NO_GSTORE; }   // 1 = no epilogue, 2 = no MFMA, 4 = epilogue without global stores
+            if (tuning_env("SE_PD_NOSTAGGER")) f |= 1 << 30;
+            if (tuning_env("SE_PD_PLAIN_ST")) f |= PDF_PLAIN_ST;
+            return f;
+        }();
+        flags |= tune & ~(1 << 30);
+        if (tune & (1 << 30)) flags &= ~PDF_STAGGER;
+    }
     int nchunks = 0;
     for (int i = 0; i < kbs.n; i++) nchunks += (kbs.len[i] + PD_BK - 1) / PD_BK;
     int64_t grid = (int64_t)pd_num_cus() * PD_WGS_PER_CU;
@@ -464,7 +478,7 @@ static int launch_pdist3(const float *a, int64_t lda, const float *b, int64_t ld
     if (grid < 1) grid = 1;
     auto kern = pdist_kernel<METRIC, MULTI, SYM, VEC>;
     SE_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    static const bool profile = getenv("SE_PD_PROFILE") != nullptr;   // tuning aid only: allocates, synchronises, prints
+    static const bool profile = tuning_env("SE_PD_PROFILE") != nullptr;   // -DSE_TUNING build only: allocates, synchronises, prints
     unsigned long long *prof = nullptr;
     if (profile) {
         SE_HIP_CHECK(hipMalloc((void **)&prof, 12 * sizeof(unsigned long long)));
@@ -517,11 +531,14 @@ static int launch_pdist(const float *a, int64_t lda, const float *b, int64_t ldb
 
 }  // namespace se
 
+#ifdef SE_PD_WS_BUILD
 namespace se {
-// pdist_ws.hip: wave-specialised variant; SE_OK = done, 1 = not applicable (use the kernel in this file)
+// tools/experiments/pdist_ws.hip: wave-specialised variant, measured slower (3.8 vs 3.4 ms) and therefore NOT part of the product
+// library; a tuning build can link it in with -DSE_PD_WS_BUILD.  SE_OK = done, 1 = not applicable (use the kernel in this file)
 int pdist_ws_try(const float *a, int64_t lda, const float *b, int64_t ldb, const float *sqa, const float *sqb, int64_t q, int64_t n,
                  int64_t d, int metric, float *out, int64_t ldo, hipStream_t s);
 }
+#endif
 
 using namespace se;
 
@@ -553,10 +570,12 @@ extern "C" int se_pairwise_dist(const float *a, int64_t lda, const float *b, int
         multi = true;
     }
     hipStream_t s = (hipStream_t)stream;
+#ifdef SE_PD_WS_BUILD
     if (!multi && (metric == SE_METRIC_COSINE || metric == SE_METRIC_EUCLID || metric == SE_METRIC_DOT)) {
         const int rc = pdist_ws_try(a, lda, b, ldb, sqa, sqb, q, n, d, metric, out, ldo, s);
         if (rc != 1) return rc;
     }
+#endif
     switch (metric) {
         case SE_METRIC_COSINE: return launch_pdist<SE_METRIC_COSINE>(a, lda, b, ldb, sqa, sqb, q, n, d, kbs, multi, out, ldo, s);
         case SE_METRIC_EUCLID: return launch_pdist<SE_METRIC_EUCLID>(a, lda, b, ldb, sqa, sqb, q, n, d, kbs, multi, out, ldo, s);

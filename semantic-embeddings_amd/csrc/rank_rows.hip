@@ -22,6 +22,7 @@
 // HBM-side algorithmic traffic: 4 N bytes in (distances) + 4 N bytes out (int32 ranks) per row.
 #include "se_common.h"
 #include <stdlib.h>
+#include <atomic>
 
 namespace se {
 
@@ -802,7 +803,7 @@ static int64_t rank_npad(int64_t n) { return (n + 63) / 64 * 64; }
 
 static bool rank_use_tiled(int64_t n)
 {
-    static const bool force = getenv("SE_RANK_TILED") != nullptr;   // tuning / test aid: always take the general kernel
+    static const bool force = tuning_env("SE_RANK_TILED") != nullptr;   // -DSE_TUNING build only: always take the general kernel
     return force || n > RR_MAX_N;
 }
 
@@ -840,20 +841,22 @@ static int launch_rank_reg_variant(const float *pdist, int64_t ldp, int64_t q, i
 {
     const size_t cnt_words = HW ? (size_t)(1 << RR_HW_BITS) / 2 : (size_t)RK_NB;   // per wave (packed 16-bit vs 32-bit counters)
     const size_t lds = (RR_WAVES * cnt_words + 16) * sizeof(uint32_t) + (size_t)RR_THREADS * ITEMS * sizeof(uint16_t);
-    static const bool profile = getenv("SE_RR_PROFILE") != nullptr;   // tuning aid only: allocates, synchronises, prints
-    auto kern = profile ? rank_rows_reg_kernel<ITEMS, (ITEMS == 98), HW, PEEL> : rank_rows_reg_kernel<ITEMS, false, HW, PEEL>;
-    static int per_cu = 0, cus = 0;   // per instantiation
-    if (per_cu == 0) {
-        SE_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    static const bool profile = tuning_env("SE_RR_PROFILE") != nullptr;   // -DSE_TUNING build only: allocates, synchronises, prints
+    auto kern = (kTuning && profile) ? rank_rows_reg_kernel<ITEMS, kTuning && (ITEMS == 98), HW, PEEL> : rank_rows_reg_kernel<ITEMS, false, HW, PEEL>;
+    // per instantiation, computed once (thread-safe static initialisation): resident workgroups = CUs x occupancy
+    struct Resident { hipError_t err; int64_t grid; };
+    static const Resident res = [&]() -> Resident {
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         int dev = 0, occ = 0;
         hipDeviceProp_t prop;
-        SE_HIP_CHECK(hipGetDevice(&dev));
-        SE_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
-        SE_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)kern, RR_THREADS, lds));
-        cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-        per_cu = occ > 0 ? occ : 1;
-    }
-    int64_t grid = (int64_t)cus * per_cu;
+        if (e == hipSuccess) e = hipGetDevice(&dev);
+        if (e == hipSuccess) e = hipGetDeviceProperties(&prop, dev);
+        if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)kern, RR_THREADS, lds);
+        if (e != hipSuccess) return {e, 0};
+        return {hipSuccess, (int64_t)(prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256) * (occ > 0 ? occ : 1)};
+    }();
+    if (res.err != hipSuccess) return fail(SE_ERR_HIP, "se_rank_rows: kernel set-up failed: %s", hipGetErrorString(res.err));
+    int64_t grid = res.grid;
     if (grid > q) grid = q;
     const size_t esz = idx64 ? 8 : 4;
     const int vec_ok = ((((uintptr_t)rank) & 15) == 0) && ((ldr * esz) % 16 == 0);
@@ -890,7 +893,7 @@ static int launch_rank_reg(const float *pdist, int64_t ldp, int64_t q, int n, vo
                            hipStream_t s)
 {
     if (!hw) return launch_rank_reg_variant<ITEMS, false, false>(pdist, ldp, q, n, rank, idx64, ldr, nullptr, s);
-    static const char *force = getenv("SE_RANK_PEEL");   // tuning aid: "0" / "1" pins the variant
+    static const char *force = tuning_env("SE_RANK_PEEL");   // -DSE_TUNING build only: "0" / "1" pins the variant
     if (force || !scratch) {
         if (force && force[0] == '1') return launch_rank_reg_variant<ITEMS, true, true>(pdist, ldp, q, n, rank, idx64, ldr, nullptr, s);
         return launch_rank_reg_variant<ITEMS, true, false>(pdist, ldp, q, n, rank, idx64, ldr, nullptr, s);
@@ -943,10 +946,11 @@ static int rank_hw_order_ok(void *workspace, int64_t workspace_bytes, hipStream_
 {
     static const bool forced_safe = getenv("SE_RANK_SAFE") != nullptr;
     if (forced_safe) return 0;
-    static int state[64] = {0};   // per device: 0 unknown, 1 verified, -1 refuted
+    static std::atomic<int> state[64];   // per device: 0 unknown, 1 verified, -1 refuted (zero-initialised; two threads racing here
+                                         // both run the probe on their own workspace and store the same verdict)
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
-    if (state[dev] == 0) {
+    if (state[dev].load(std::memory_order_acquire) == 0) {
         if (!workspace || workspace_bytes < 256) return 0;   // cannot probe without scratch: stay on the safe kernel
         uint32_t *res = (uint32_t *)workspace, h[2] = {1u, 0u};
         if (hipMemsetAsync(res, 0, 8, s) != hipSuccess) return 0;
@@ -954,12 +958,13 @@ static int rank_hw_order_ok(void *workspace, int64_t workspace_bytes, hipStream_
         if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess ||
             hipMemcpy(h, res, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess)
             return 0;
-        state[dev] = (h[0] == 0u && h[1] == (uint32_t)(RR_PROBE_BLOCKS * RR_WAVES)) ? 1 : -1;
+        const int verdict = (h[0] == 0u && h[1] == (uint32_t)(RR_PROBE_BLOCKS * RR_WAVES)) ? 1 : -1;
+        state[dev].store(verdict, std::memory_order_release);
         if (getenv("SE_RANK_VERBOSE"))
             fprintf(stderr, "[se_rank_rows] LDS returning-add order probe on device %d: %u mismatches, %u waves -> %s kernel\n", dev,
-                    h[0], h[1], state[dev] == 1 ? "hardware-ordered" : "ballot");
+                    h[0], h[1], verdict == 1 ? "hardware-ordered" : "ballot");
     }
-    return state[dev] == 1;
+    return state[dev].load(std::memory_order_acquire) == 1;
 }
 
 extern "C" int64_t se_rank_rows_workspace_bytes(int64_t q, int64_t n)

@@ -4,6 +4,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include "../../include/sehip.h"
 
@@ -30,6 +31,18 @@ int fail(int code, const char *fmt, ...);
     } while (0)
 
 constexpr int WAVE = 64;
+
+// Tuning / test switches (environment variables that pin a kernel variant, print phase profiles or make a kernel skip work)
+// exist only in the -DSE_TUNING build (sehip/libsehip_tuning.so, loaded by tests / tools through SEHIP_LIB): the product
+// library ignores them all, so no environment variable can change what an entry point computes.  Product switches that stay:
+// SE_RANK_SAFE=1 (guaranteed-order ranking kernel) and SE_RANK_VERBOSE=1 (says which ranking kernel the probe selected).
+#ifdef SE_TUNING
+inline const char *tuning_env(const char *name) { return getenv(name); }
+constexpr bool kTuning = true;
+#else
+inline const char *tuning_env(const char *) { return nullptr; }
+constexpr bool kTuning = false;
+#endif
 
 // Order-preserving float32 -> uint32 key of the canonical ranking order:
 // ascending value, -0.0 == +0.0, every NaN maps to 0xFFFFFFFF (sorted last).

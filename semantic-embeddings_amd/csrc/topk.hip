@@ -379,7 +379,7 @@ extern "C" int se_topk_rows(const float *pdist, int64_t ldp, int64_t q, int64_t 
     hipStream_t s = (hipStream_t)stream;
     // sample-select fast path: pivot = sample of rank r, r - 4 sqrt(r) >= m = k S / N  (r = (2 + sqrt(4 + m))^2 + 4);
     // taken when the 4-sigma upper bound of the candidate count fits the LDS candidate buffer
-    static const bool exact_only = getenv("SE_TOPK_EXACT") != nullptr;   // test / tuning aid
+    static const bool exact_only = tuning_env("SE_TOPK_EXACT") != nullptr;   // -DSE_TUNING build only: exact radix select for every row
     const double m = (double)k * TK_SAMPLES / (double)n;
     const double rr = (2.0 + sqrt(4.0 + m)) * (2.0 + sqrt(4.0 + m)) + 4.0;
     const int r = (int)ceil(rr);

@@ -187,7 +187,9 @@ class Trainer(object):
         if self.memory_format is not None and X.dim() == 4:
             X = X.contiguous(memory_format=self.memory_format)     # no-op when the loader already produces this layout
         if self.autocast_dtype is not None and X.is_cuda:
-            with torch.autocast('cuda', dtype=self.autocast_dtype):
+            # cache_enabled=False: the weight-cast cache keeps tensors that were created inside a HIP-graph capture alive across
+            # replays (every weight is used once per forward here, so the cache saves nothing anyway)
+            with torch.autocast('cuda', dtype=self.autocast_dtype, cache_enabled=False):
                 out = self.model(X)
         else:
             out = self.model(X)
@@ -431,10 +433,10 @@ class Trainer(object):
 
     def fit(self, train_seq, validation_data=None, epochs=1, initial_epoch=0, callbacks=(), verbose=True, log_every=50):
         self.model.train()
-        # fp32 steps are replayed as HIP graphs unless SE_TRAIN_GRAPHS=0 (bf16 autocast replays fail the capture-time
-        # validation on this stack, so they are not even tried)
-        if (not self._graph_tried and self.autocast_dtype is None and len(train_seq) > 0
-                and os.environ.get('SE_TRAIN_GRAPHS', '1') != '0'):
+        # steps are replayed as HIP graphs unless SE_TRAIN_GRAPHS=0; a capture that fails its validation against the eager
+        # gradient (enable_graphs) leaves the trainer eager and says so
+        if (not self._graph_tried and len(train_seq) > 0 and os.environ.get('SE_TRAIN_GRAPHS', '1') != '0'
+                and (self.autocast_dtype is None or os.environ.get('SE_TRAIN_BF16_GRAPHS', '1') != '0')):
             self._graph_tried = True
             X0, y0 = train_seq[0]
             if X0.is_cuda:

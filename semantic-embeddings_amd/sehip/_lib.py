@@ -11,6 +11,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
 LIB_PATH = os.environ.get("SEHIP_LIB") or os.path.join(_HERE, "libsehip.so")   # SEHIP_LIB: tuning builds only
+TUNING_LIB_PATH = os.path.join(_HERE, "libsehip_tuning.so")   # -DSE_TUNING build: honours the SE_* variant / profile switches
 
 SE_OK = 0
 DTYPE_F32, DTYPE_BF16 = 0, 1
@@ -22,6 +23,7 @@ EXPORTS = (
     "se_version", "se_last_error", "se_build_arch",
     "se_cosine_loss_fwd", "se_cosine_loss_bwd", "se_l2norm_fwd", "se_l2norm_bwd", "se_nn_accuracy",
     "se_labelembed_aux_floats", "se_labelembed_loss_fwd", "se_labelembed_loss_bwd",
+    "se_devise_aux_floats", "se_devise_loss_fwd", "se_devise_loss_bwd",
     "se_row_sqnorm", "se_normalize_rows", "se_pairwise_dist",
     "se_rank_rows_workspace_bytes", "se_rank_rows",
     "se_topk_rows", "se_topk_merge",
@@ -37,8 +39,9 @@ def build(force=False, verbose=False):
     """Compile csrc/*.hip for gfx950 into sehip/libsehip.so (cross-compiles without a GPU)."""
     srcs = [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith((".hip", ".h"))]
     srcs.append(os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include", "sehip.h"))
-    stale = (not os.path.exists(LIB_PATH)) or any(
-        os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs if os.path.exists(s))
+    built = [os.path.join(_HERE, "libsehip.so"), TUNING_LIB_PATH]
+    stale = any((not os.path.exists(b)) or any(os.path.getmtime(s) > os.path.getmtime(b) for s in srcs if os.path.exists(s))
+                for b in built)
     if force or stale:
         cmd = ["make", "-C", _CSRC, "-j8"] + (["-B"] if force else [])
         out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
@@ -77,6 +80,10 @@ def lib():
     L.se_labelembed_loss_fwd.argtypes = [vp, c_i64, vp, c_i64, vp, c_i64, vp, c_i64, c_i64, c_f, c_f, c_f, vp, vp, vp]
     L.se_labelembed_loss_bwd.argtypes = [vp, c_i64, vp, c_i64, vp, c_i64, vp, vp, c_f, c_i64, c_i64, c_f, c_f, c_f, vp,
                                          vp, c_i64, vp, c_i64, vp, c_i64, vp]
+    L.se_devise_aux_floats.argtypes = [c_i64, c_i64]
+    L.se_devise_aux_floats.restype = c_i64
+    L.se_devise_loss_fwd.argtypes = [vp, c_i64, vp, vp, c_i64, vp, c_i64, c_i64, c_i64, c_i64, c_f, vp, vp, vp]
+    L.se_devise_loss_bwd.argtypes = [vp, vp, c_i64, vp, c_i64, vp, c_f, c_i64, c_i64, c_i64, vp, vp, c_i64, vp]
     L.se_row_sqnorm.argtypes = [vp, c_i64, c_i64, c_i64, vp, vp]
     L.se_normalize_rows.argtypes = [vp, c_i64, c_i64, c_i64, vp]
     L.se_pairwise_dist.argtypes = [vp, c_i64, vp, c_i64, vp, vp, c_i64, c_i64, c_i64, c_int,

@@ -14,6 +14,7 @@ from ._lib import (DTYPE_BF16, DTYPE_F32, METRIC_COSINE, METRIC_DOT, METRIC_EUCL
 
 __all__ = [
     "cosine_embedding_loss", "cosine_loss_forward", "cosine_loss_backward", "l2norm", "nn_accuracy", "labelembed_loss",
+    "devise_ranking_loss",
     "row_sqnorm", "normalize_rows_", "pairwise_dist", "rank_rows", "topk_rows", "topk_merge", "retrieve_topk",
     "hierarchical_precision",
     "METRIC_COSINE", "METRIC_EUCLID", "METRIC_DOT",
@@ -212,6 +213,48 @@ def labelembed_loss(out1, out2, tar, targets, tau=2.0, alpha=0.9, beta=0.5):
 
 # --------------------------------------------------------------------------------------------
 # retrieval side
+class _DeviseLoss(torch.autograd.Function):
+    """reference: utils.devise_ranking_loss (utils.py:103-122) and its TF-autodiff backward w.r.t. y_pred."""
+
+    @staticmethod
+    def forward(ctx, y_pred, target, embedding, margin):
+        require_gpu(y_pred, target, embedding)
+        yp = _rows(y_pred.to(torch.float32), "y_pred")
+        yp = yp if yp.stride(1) == 1 else yp.contiguous()
+        _rows(embedding, "embedding")
+        B, D = yp.shape
+        C = embedding.shape[0]
+        if target.dim() == 1 and not target.is_floating_point():
+            labels, yt, ldt = target.long().contiguous(), None, 0
+        else:
+            labels, yt = None, _rows(target.to(torch.float32).contiguous(), "y_true")
+            ldt = yt.stride(0)
+        loss_i = torch.empty((B,), dtype=torch.float32, device=yp.device)
+        aux = torch.empty((max(int(lib().se_devise_aux_floats(B, C)), 1),), dtype=torch.float32, device=yp.device)
+        check(lib().se_devise_loss_fwd(ptr(yp), yp.stride(0), ptr(labels), ptr(yt), ldt, ptr(embedding), embedding.stride(0), B, D, C,
+                                       ctypes.c_float(margin), ptr(loss_i), ptr(aux), stream_ptr()), "se_devise_loss_fwd")
+        ctx.save_for_backward(aux, embedding, labels if labels is not None else yt)
+        ctx.by_label, ctx.shape, ctx.in_dtype = labels is not None, (B, D, C), y_pred.dtype
+        return loss_i
+
+    @staticmethod
+    def backward(ctx, grad_loss_i):
+        aux, embedding, tgt = ctx.saved_tensors
+        B, D, C = ctx.shape
+        g = grad_loss_i.to(torch.float32).contiguous()
+        dp = torch.empty((B, D), dtype=torch.float32, device=g.device)
+        labels, yt = (tgt, None) if ctx.by_label else (None, tgt)
+        check(lib().se_devise_loss_bwd(ptr(labels), ptr(yt), 0 if yt is None else yt.stride(0), ptr(embedding), embedding.stride(0),
+                                       ptr(g), ctypes.c_float(1.0), B, D, C, ptr(aux), ptr(dp), D, stream_ptr()), "se_devise_loss_bwd")
+        return dp.to(ctx.in_dtype), None, None, None
+
+
+def devise_ranking_loss(y_pred, target, embedding, margin=0.1):
+    """Per-sample DeViSE ranking loss [B] (utils.py:103-122), differentiable w.r.t. ``y_pred``; ``target`` = int64 labels [B]
+    (rows of ``embedding`` gathered on the device) or an explicit float ``y_true`` [B, D]."""
+    return _DeviseLoss.apply(y_pred, target, embedding, float(margin))
+
+
 # --------------------------------------------------------------------------------------------
 
 def _f32_rows(t, what):

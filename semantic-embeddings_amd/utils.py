@@ -113,14 +113,35 @@ def nn_accuracy(embedding, dot_prod_sim=False, k=1):
     def _labels(y_true, emb):
         if _is_labels(y_true):
             return y_true.long()
-        # gathered rows -> indices (exact match of the float32 rows)
-        d = torch.cdist(y_true.float(), emb)
-        return d.argmin(dim=-1)
+        # Gathered rows -> class indices by EXACT row match (learn_image_embeddings.py:48-50 feeds embedding[y]).  Identical
+        # rows of the embedding (e.g. the zero rows of nab.sim*) are interchangeable for the metric -- same true score, same
+        # class scores -- so the first match is taken; a row that is no class embedding at all cannot use the label kernel.
+        yt = y_true.float()
+        d = torch.cdist(yt, emb, compute_mode='donot_use_mm_for_euclid_dist')
+        idx = d.argmin(dim=-1)
+        if not bool((emb[idx] == yt).all()):
+            return None
+        return idx
+
+    def _generic(y_true, y_pred, dot, emb):
+        # y_true is not a row of the embedding: evaluate utils.py:73-95 as written, on the kernel's score matrix
+        yp, yt = y_pred.float().contiguous(), y_true.float()
+        dummy = torch.zeros((yp.shape[0],), dtype=torch.int64, device=yp.device)
+        _, scores = sehip.nn_accuracy(yp, dummy, emb, dot_prod_sim=dot, k=1, want_scores=True)
+        if dot:
+            true = torch.sum(yp * yt, dim=-1)
+            top = scores.topk(min(max(k, 1), scores.shape[1]), dim=-1).values
+        else:
+            true = torch.sum(torch.square(yp - yt), dim=-1)
+            top = -(-scores).topk(min(max(k, 1), scores.shape[1]), dim=-1).values
+        return (torch.abs(top - true[:, None]) < 1e-6).any(dim=-1).float()
 
     def _run(y_true, y_pred, dot):
         emb = _emb(y_pred.device)
-        return sehip.nn_accuracy(y_pred.float().contiguous(), _labels(y_true, emb).contiguous(), emb,
-                                 dot_prod_sim=dot, k=k)
+        labels = _labels(y_true, emb)
+        if labels is None:
+            return _generic(y_true, y_pred, dot, emb)
+        return sehip.nn_accuracy(y_pred.float().contiguous(), labels.contiguous(), emb, dot_prod_sim=dot, k=k)
 
     def nn_accuracy(y_true, y_pred):
         return _run(y_true, y_pred, False)
@@ -134,18 +155,16 @@ def nn_accuracy(embedding, dot_prod_sim=False, k=1):
 
 
 def devise_ranking_loss(embedding, margin=0.1):
-    """DeViSE ranking loss (utils.py:103-122)."""
-    emb_t = {}
+    """DeViSE ranking loss (utils.py:103-122): fused HIP kernel (MFMA contraction with the hinge, its row sums and the
+    active mask in the epilogue; the mask feeds the backward contraction).  ``y_true``: gathered embeddings [B, D] (the
+    reference's convention) or integer labels [B]."""
+    emb_dev = {}
 
     def _loss(y_true, y_pred):
-        if y_pred.device not in emb_t:
+        if y_pred.device not in emb_dev:
             e = embedding if torch.is_tensor(embedding) else torch.from_numpy(np.asarray(embedding, dtype=np.float32))
-            emb_t[y_pred.device] = e.to(device=y_pred.device, dtype=torch.float32)
-        e = emb_t[y_pred.device]
-        t = e[y_true] if _is_labels(y_true) else y_true.float()
-        true_sim = torch.sum(t * y_pred.float(), dim=-1)
-        other_sim = y_pred.float() @ e.t()
-        return torch.sum(torch.relu(margin - true_sim[:, None] + other_sim), dim=-1) - margin
+            emb_dev[y_pred.device] = e.to(device=y_pred.device, dtype=torch.float32).contiguous()
+        return sehip.devise_ranking_loss(y_pred, y_true, emb_dev[y_pred.device], margin)
 
     return _loss
 

@@ -74,3 +74,43 @@ def test_product_never_imports_the_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), os.path.join(dirpath, f)
+
+
+def test_product_library_carries_no_tuning_switches():
+    """The product .so ignores every tuning / ablation environment variable (none of their names is even compiled in); the
+    -DSE_TUNING build next to it -- loaded only by tests / tools through SEHIP_LIB -- honours them.  SE_RANK_SAFE / SE_RANK_VERBOSE
+    are product switches (guaranteed-order ranking kernel, probe verdict)."""
+    import sehip
+    from sehip import _lib
+    product = subprocess.run(["strings", os.path.join(os.path.dirname(_lib.TUNING_LIB_PATH), "libsehip.so")], capture_output=True, text=True).stdout
+    tuning = subprocess.run(["strings", _lib.TUNING_LIB_PATH], capture_output=True, text=True).stdout
+    for name in ("SE_PD_ABLATE", "SE_PD_NOSTAGGER", "SE_PD_PLAIN_ST", "SE_PD_PROFILE", "SE_RR_PROFILE", "SE_RANK_PEEL", "SE_RANK_TILED",
+                 "SE_TOPK_EXACT"):
+        assert name not in product, name
+        assert name in tuning, name
+    assert "SE_RANK_SAFE" in product
+    assert "pdist_ws" not in product          # the slower wave-specialised experiment is not shipped
+    assert not os.path.exists(os.path.join(ROOT, "semantic-embeddings_amd", "csrc", "pdist_ws.hip"))
+
+
+def test_tuning_library_exports_the_same_abi():
+    import ctypes
+    from sehip import _lib
+    lib = ctypes.CDLL(_lib.TUNING_LIB_PATH)
+    for name in header_symbols():
+        assert hasattr(lib, name), name
+
+
+def test_no_unsynchronised_function_local_state_in_the_library():
+    """include/sehip.h promises re-entrancy: function-local statics of the host code are const (thread-safe one-time
+    initialisation) or atomics."""
+    csrc = os.path.join(ROOT, "semantic-embeddings_amd", "csrc")
+    bad = []
+    for f in sorted(os.listdir(csrc)):
+        if not f.endswith((".hip", ".h")):
+            continue
+        for ln, line in enumerate(open(os.path.join(csrc, f)), 1):
+            m = re.match(r"\s+static\s+(?!const\b|constexpr\b|thread_local\b|std::atomic|__device__|inline\b)(\w[\w:<> \*]*)\s+\w+.*[=;]", line)
+            if m and "(" not in line.split("=")[0]:
+                bad.append("%s:%d: %s" % (f, ln, line.strip()))
+    assert not bad, bad

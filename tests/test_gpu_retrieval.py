@@ -70,35 +70,6 @@ def test_pairwise_dist_bit_exact(sehip, metric, q, n, d):
     assert np.array_equal(got, want)
 
 
-def test_pairwise_dist_wave_specialised_kernel_in_subprocess():
-    """The opt-in wave-specialised distance kernel (SE_PD_WS=1, read once per process): symmetric (upper triangle +
-    mirrored tiles, ragged last tile row / column) and general shapes, every metric, chunk splits with a short last
-    chunk -- bit-exact vs the canonical FMA chain."""
-    import subprocess
-    import sys
-    code = (
-        "import sys, numpy as np, torch\n"
-        "sys.path[:0] = %r\n"
-        "import sehip\n"
-        "from oracle import retrieval_oracle as ro\n"
-        "for metric in (ro.METRIC_COSINE, ro.METRIC_EUCLID, ro.METRIC_DOT):\n"
-        "    for n, d in ((1300, 100), (777, 16), (1024, 64), (2100, 132), (600, 36)):\n"
-        "        rng = np.random.default_rng(n + d)\n"
-        "        x = rng.standard_normal((n, d)).astype(np.float32); y = rng.standard_normal((640, d)).astype(np.float32)\n"
-        "        xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()\n"
-        "        sq = sehip.row_sqnorm(xd) if metric == ro.METRIC_EUCLID else None\n"
-        "        sqy = sehip.row_sqnorm(yd) if metric == ro.METRIC_EUCLID else None\n"
-        "        got = sehip.pairwise_dist(xd, None, metric=metric, sqa=sq, sqb=sq).cpu().numpy()\n"
-        "        assert np.array_equal(got, ro.canon_pdist(x, None, metric)), (metric, n, d)\n"
-        "        got2 = sehip.pairwise_dist(yd, xd, metric=metric, sqa=sqy, sqb=sq).cpu().numpy()\n"
-        "        assert np.array_equal(got2, ro.canon_pdist(y, x, metric)), (metric, n, d, 'general')\n"
-        "print('ws-ok')\n"
-    ) % ([PKG_DIR, ROOT_DIR],)
-    env = dict(os.environ, SE_PD_WS="1")
-    out = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
-    assert out.returncode == 0 and "ws-ok" in out.stdout, out.stdout
-
-
 def test_pairwise_dist_self_is_symmetric_and_transpose_detecting(sehip):
     x = gauss(260, 100, seed=5)
     got = sehip.pairwise_dist(dev(x), None, metric=ro.METRIC_COSINE).cpu().numpy()
@@ -246,7 +217,8 @@ def test_rank_rows_pinned_peel_variants_in_subprocess(peel):
         "    assert np.array_equal(got, ro.canon_rank_rows(pd)), n\n"
         "print('peel-ok')\n"
     ) % ([PKG_DIR, ROOT_DIR],)
-    env = dict(os.environ, SE_RANK_PEEL=peel)
+    # variant switches exist only in the -DSE_TUNING build of the library (the product ignores them)
+    env = dict(os.environ, SE_RANK_PEEL=peel, SEHIP_LIB=os.path.join(PKG_DIR, "sehip", "libsehip_tuning.so"))
     out = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert out.returncode == 0 and "peel-ok" in out.stdout, out.stdout
 

@@ -7,6 +7,8 @@ import numpy as np
 import pytest
 import torch
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 
 
@@ -252,3 +254,43 @@ def test_bench_traffic_record_matches_the_committed_pmc_profile():
     assert tr is not None and os.path.exists(os.path.join(os.path.dirname(bench.__file__), tr["source"].split(" ")[0]))
     assert 0.95 < tr["bytes"] / 20e9 < 1.15 and abs(tr["read_GB"] + tr["write_GB"] - tr["bytes"] / 1e9) < 1e-6
     assert bench.pmc_traffic_gb("rank_rows", 1000, 50000, 100) is None and bench.pmc_traffic_gb("nope", 50000, 50000, 100) is None
+
+
+def test_bench_gpus_flag_spawns_that_many_ranks():
+    """`python bench.py --gpus 2` without a launcher re-launches itself as 2 ranks (torch.distributed.run, 127.0.0.1) and
+    reports the size of the live process group; --dry keeps it on CPU/gloo with stand-in kernels."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry"], env=env, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["dry"] is True and rec["sharded_topk_matches_unsharded"] is True
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() >= 64:
+        pytest.skip("unexpectedly many devices")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64"], env=env, stdout=subprocess.PIPE,
+                         stderr=subprocess.PIPE, text=True, timeout=300)
+    assert out.returncode != 0 and "visible" in (out.stderr + out.stdout)
+
+
+def test_bench_cost_model_counts_executed_flops():
+    import bench
+    b, full, ex, floor = bench.pdist_cost_model(50000, 50000, 100, symmetric=True)
+    assert b == 4.0 * 50000 * 50000 + 4.0 * 100000 * 100
+    assert full == 5.0e11
+    t = 391
+    assert ex == (t * (t + 1) // 2) * 128 * 128 * 200.0 and 0.5 * full < ex < 0.51 * full
+    assert abs(floor - max(ex / 157.3e12, b / 8e12) * 1e3) < 1e-12 and 1.5 < floor < 1.7
+    _, _, ex_g, floor_g = bench.pdist_cost_model(50000, 50000, 100, symmetric=False)
+    assert ex_g == full and 3.1 < floor_g < 3.3
