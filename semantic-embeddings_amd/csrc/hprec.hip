@@ -94,7 +94,9 @@ __global__ __launch_bounds__(HP_THREADS) void hprec_kernel(const int32_t *__rest
                     if (i < L && rrow[i] == self) atomicMin(s_qpos, (int)i);
                 }
                 __syncthreads();
-                if (*s_qpos != 0x7FFFFFFF) break;
+                const int found = *s_qpos;      // read into a register BEFORE the second barrier: a fast wave must not start the next
+                __syncthreads();                // chunk's atomicMin while a slow wave has yet to read the flag (the waves would take
+                if (found != 0x7FFFFFFF) break; // different exits and pair their barriers out of order)
             }
         }
         __syncthreads();

@@ -32,7 +32,10 @@ class DeviceBatchSequence(object):
             self.rng.shuffle(self.perm)
 
     def __getitem__(self, idx):
-        sel = self.perm[idx * self.batch_size:(idx + 1) * self.batch_size][self.rank::self.world_size]
+        glob = self.perm[idx * self.batch_size:(idx + 1) * self.batch_size]
+        sel = glob[self.rank::self.world_size]
+        if len(sel) == 0 and len(glob):     # a short last batch with fewer rows than ranks: no rank may see an empty batch (its mean
+            sel = glob[[self.rank % len(glob)]]   # would be NaN and the all-reduce would spread it): re-use one of the rows
         X = self.generator.compose_batch(self.indices[sel], train=self.train, augment=self.augment)
         y = torch.from_numpy(self.labels[sel].astype(np.int64)).to(X.device, non_blocking=True)
         if self.batch_transform is not None:
@@ -112,24 +115,29 @@ class SyntheticGenerator(_GeneratorBase):
 
 
 class InMemoryDatasetGenerator(_GeneratorBase):
-    """Small-image datasets held entirely in HBM (the reference's TinyDatasetGenerator,
-    datasets/common.py:635-844): feature-wise standardisation with training-set statistics and, for
-    training batches, random horizontal flips and shifts of up to 15 % (zero... nearest fill) done
-    with tensor ops on the device."""
+    """Small-image datasets held entirely in HBM (the reference's TinyDatasetGenerator, datasets/common.py:635-844).
+
+    Pre-processing follows Keras' ``ImageDataGenerator(featurewise_center, featurewise_std_normalization).fit(X_train)`` +
+    ``standardize`` [third party: keras_preprocessing 1.0.x]: PER-CHANNEL mean and standard deviation of the training set
+    (reduced over samples, rows and columns), float32, ``x = (x - mean) / (std + 1e-6)``.  Training batches get a random
+    horizontal flip and random width / height shifts drawn uniformly from +-15 % of the image size -- continuous offsets,
+    bilinear interpolation (Keras ``order = 1``) with edge replication (``fill_mode = 'nearest'``) -- as tensor ops on the
+    device.  (The random numbers come from torch's device generator, not NumPy's: same distribution, different draws.)"""
 
     def __init__(self, X_train, X_test, y_train, y_test, shift_range=0.15, horizontal_flip=True):
         self.X_train_h, self.X_test_h = X_train, X_test      # NHWC float32 host arrays
         self.y_train, self.y_test = list(y_train), list(y_test)
         self.shift_range, self.horizontal_flip = shift_range, horizontal_flip
-        self.mean = X_train.mean(axis=0, keepdims=True).astype(np.float32)
-        self.std = (X_train.std(axis=0, keepdims=True) + 1e-6).astype(np.float32)   # Keras featurewise_std + epsilon
+        X32 = np.asarray(X_train, dtype=np.float32)
+        self.mean = np.mean(X32, axis=(0, 1, 2), keepdims=True)                       # [1, 1, 1, C]
+        self.std = np.std(X32 - self.mean, axis=(0, 1, 2), keepdims=True) + np.float32(1e-6)
         self.num_channels = X_train.shape[-1]
         self._dev_data = None
 
     def _data(self):
         if self._dev_data is None:
             dev = self._dev()
-            prep = lambda a: torch.from_numpy(((a - self.mean) / self.std).transpose(0, 3, 1, 2).copy()).to(dev)
+            prep = lambda a: torch.from_numpy(((np.asarray(a, dtype=np.float32) - self.mean) / self.std).transpose(0, 3, 1, 2).copy()).to(dev)
             self._dev_data = (prep(self.X_train_h), prep(self.X_test_h))
         return self._dev_data
 
@@ -143,11 +151,13 @@ class InMemoryDatasetGenerator(_GeneratorBase):
                 flip = torch.rand(b, device=x.device) < 0.5
                 x = torch.where(flip[:, None, None, None], x.flip(3), x)
             if self.shift_range:
-                # per-sample integer shifts with edge replication (Keras fill_mode='nearest')
-                dy = torch.randint(-int(self.shift_range * h), int(self.shift_range * h) + 1, (b,), device=x.device)
-                dx = torch.randint(-int(self.shift_range * w), int(self.shift_range * w) + 1, (b,), device=x.device)
-                rows = (torch.arange(h, device=x.device)[None, :] - dy[:, None]).clamp_(0, h - 1)
-                cols = (torch.arange(w, device=x.device)[None, :] - dx[:, None]).clamp_(0, w - 1)
-                x = x.gather(2, rows[:, None, :, None].expand(b, x.shape[1], h, w))
-                x = x.gather(3, cols[:, None, None, :].expand(b, x.shape[1], h, w))
+                # per-sample continuous shifts, bilinear, edges replicated: out[r, c] = in[r + ty, c + tx]
+                ty = (torch.rand(b, device=x.device) * 2 - 1) * (self.shift_range * h)
+                tx = (torch.rand(b, device=x.device) * 2 - 1) * (self.shift_range * w)
+                rr = torch.arange(h, device=x.device, dtype=torch.float32)[None, :] + ty[:, None]       # source row of every output row
+                cc = torch.arange(w, device=x.device, dtype=torch.float32)[None, :] + tx[:, None]
+                gy = (rr / max(h - 1, 1) * 2 - 1)[:, :, None].expand(b, h, w)
+                gx = (cc / max(w - 1, 1) * 2 - 1)[:, None, :].expand(b, h, w)
+                x = torch.nn.functional.grid_sample(x, torch.stack((gx, gy), dim=-1), mode='bilinear', padding_mode='border',
+                                                    align_corners=True)
         return x.contiguous(memory_format=torch.channels_last)

@@ -120,8 +120,18 @@ class BucketedAllReduce(object):
                 self.buckets.append([start, end, count])
                 end, count = start, 0
         self.pending = [b[2] for b in self.buckets]
-        for idx, p in enumerate(flat.params):
-            p.register_post_accumulate_grad_hook(self._make_hook(idx))
+        self.hook_handles = [p.register_post_accumulate_grad_hook(self._make_hook(idx)) for idx, p in enumerate(flat.params)]
+
+    def close(self):
+        """Detach from the parameters (a second Trainer over the same model -- e.g. after the --finetune warm-up -- must not
+        inherit hooks that all-reduce this one's dead gradient buffer)."""
+        for h in getattr(self, 'hook_handles', ()):
+            h.remove()
+        self.hook_handles = []
+        for h in self.handles:
+            h.wait()
+        self.handles = []
+        self.enabled = False
 
     def _make_hook(self, idx):
         def hook(param):
@@ -307,6 +317,11 @@ class Trainer(object):
         self._graph_steps = 0
         return True
 
+    def close(self):
+        """Release what this trainer attached to the model (gradient hooks); the model keeps its current weights."""
+        self.reducer.close()
+        self._graph = None
+
     def _eager_core(self, X, y, logs):
         """Zero / forward / loss + metrics / backward; leaves the (rank-local) gradient in ``flat.flat_g``.
         Without bucket hooks to feed (single process, or graph mode where the all-reduce is one call after backward) the
@@ -417,18 +432,21 @@ class Trainer(object):
         self.model.train()
         return self._reduce_logs(logs, n)
 
-    def predict(self, seq, steps=None):
-        """Model outputs for every batch of ``seq`` (rank-local rows), concatenated on the host."""
+    def predict(self, seq, steps=None, to_host=True):
+        """Model outputs for every batch of ``seq`` (rank-local rows), concatenated: NumPy arrays on the host (``to_host``, what
+        the pickle dumps need) or float32 DEVICE tensors -- features go straight from the network into
+        ``ClassHierarchy.hierarchical_precision_device`` / ``evaluate_retrieval.ranking_tiles`` without a host hop
+        (learn_image_embeddings.py:270-275 -> evaluate_retrieval.py:43-54)."""
         self.model.eval()
         outs = None
         with torch.no_grad():
             for i in range(len(seq) if steps is None else steps):
                 batch = seq[i]
                 X = batch[0] if isinstance(batch, (tuple, list)) else batch
-                o = [t.float().cpu() for t in self._forward(X)]
+                o = [t.float().cpu() if to_host else t.float() for t in self._forward(X)]
                 outs = [[t] for t in o] if outs is None else [a + [t] for a, t in zip(outs, o)]
         self.model.train()
-        cat = [torch.cat(a).numpy() for a in outs]
+        cat = [torch.cat(a).numpy() if to_host else torch.cat(a) for a in outs]
         return cat[0] if len(cat) == 1 else cat
 
     def fit(self, train_seq, validation_data=None, epochs=1, initial_epoch=0, callbacks=(), verbose=True, log_every=50):

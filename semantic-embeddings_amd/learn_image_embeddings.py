@@ -32,22 +32,36 @@ from models.cifar_resnet import keras_bn, keras_dense
 
 class ClsModel(nn.Module):
     """Embedding model + classifier head (ReLU -> BN -> Dense softmax named ``prob``), two outputs
-    (reference: cls_model, learn_image_embeddings.py:16-45).  The head emits log-probabilities'
-    pre-image (logits); the categorical cross-entropy is applied on them."""
+    (reference: cls_model, learn_image_embeddings.py:16-45).  The reference appends the classifier to the model that
+    already ENDS in the ``l2norm`` Lambda layer (``--loss inv_corr``) or the ``softmax`` activation (``softmax_corr``)
+    (learn_image_embeddings.py:127-133), so its base is the normalised / soft-maxed output; that tensor is also the first
+    output, which loss and metrics consume.  The head emits logits; the categorical cross-entropy is applied on them."""
 
-    def __init__(self, embed_model, num_classes, cls_base=None):
+    def __init__(self, embed_model, num_classes, cls_base=None, head=None, width=None):
         super().__init__()
         if cls_base is not None:
             raise NotImplementedError('--cls_base: tapping an intermediate layer is not supported in this build')
+        if head not in (None, 'l2norm', 'softmax'):
+            raise ValueError('head must be None, "l2norm" or "softmax"')
         self.embed_model = embed_model
-        width = embed_model.head.out_features
+        self.head = head
+        if width is None:       # width of what the embedding model emits (resnet-32 / -110 without -fc: the pooled features)
+            width = embed_model.head.out_features if getattr(embed_model, 'head', None) is not None else None
+        if width is None:
+            raise ValueError('ClsModel needs the output width of the embedding model')
         self.bn = nn.BatchNorm1d(width, eps=1e-3, momentum=0.01)
         self.prob = keras_dense(width, num_classes)
         self.cls_l2 = 5e-4
 
     def forward(self, x):
         emb = self.embed_model(x)
-        return emb, self.prob(self.bn(torch.relu(emb.float())))
+        if self.head == 'l2norm':
+            base = utils.l2norm(emb)                    # HIP kernel with autograd (utils.py:125-127)
+        elif self.head == 'softmax':
+            base = torch.softmax(emb.float(), -1)
+        else:
+            base = emb.float()
+        return base, self.prob(self.bn(torch.relu(base)))
 
 
 def transform_inputs(X, y, embedding=None, num_classes=None):
@@ -156,7 +170,13 @@ def main(argv=None):
     embed_model = utils.build_network(embedding.shape[1], args.architecture, input_channels=data_generator.num_channels).to(dev)
     model = embed_model
     if args.cls_weight > 0:
-        model = ClsModel(embed_model, data_generator.num_classes, args.cls_base).to(dev)
+        with torch.no_grad():    # output width of the embedding model (not every architecture ends in a Dense layer)
+            was = embed_model.training
+            embed_model.eval()
+            width = int(embed_model(torch.zeros((1, data_generator.num_channels, 32, 32), device=dev)).shape[-1])
+            embed_model.train(was)
+        model = ClsModel(embed_model, data_generator.num_classes, args.cls_base,
+                         head={'inv_corr': 'l2norm', 'softmax_corr': 'softmax'}.get(args.loss), width=width).to(dev)
     if args.snapshot and os.path.exists(args.snapshot):
         print('Resuming from snapshot {}'.format(args.snapshot))
         model.load_state_dict(torch.load(args.snapshot, map_location=dev)['model'])
@@ -169,12 +189,19 @@ def main(argv=None):
 
     # ---- loss / metrics (learn_image_embeddings.py:160-180)
     onehot_like = (args.loss == 'softmax_corr') or (args.embedding == 'onehot')
-    if args.loss == 'inv_corr':
+    if args.loss == 'inv_corr' and args.cls_weight > 0:
+        # the classifier branch needs the normalised embedding as a tensor of the graph (ClsModel applies the l2norm kernel);
+        # the cosine loss is then the plain inv_correlation on it, like the reference (utils.py:44-46)
+        loss = lambda y, o: utils.inv_correlation(emb_dev[y], o)
+        metrics = [accuracy if onehot_like else utils.nn_accuracy(emb_dev, dot_prod_sim=True)]
+        metrics += [utils.top_k_acc(k) if onehot_like else utils.nn_accuracy(emb_dev, dot_prod_sim=True, k=k) for k in args.top_k_acc]
+    elif args.loss == 'inv_corr':
         loss = utils.CosineEmbeddingLoss(emb_dev)          # fused l2norm + gather + 1 - <.,.>
         metrics = [accuracy if onehot_like else utils.nn_accuracy(emb_dev, dot_prod_sim=True)]
         metrics += [utils.top_k_acc(k) if onehot_like else utils.nn_accuracy(emb_dev, dot_prod_sim=True, k=k) for k in args.top_k_acc]
     elif args.loss.endswith('_corr'):
-        post = (lambda o: torch.softmax(o.float(), -1)) if args.loss == 'softmax_corr' else (lambda o: o.float())
+        # (with --cls_weight the model already emits the soft-maxed output, see ClsModel)
+        post = (lambda o: torch.softmax(o.float(), -1)) if (args.loss == 'softmax_corr' and args.cls_weight <= 0) else (lambda o: o.float())
         loss = lambda y, o: utils.inv_correlation(emb_dev[y], post(o))
         metrics = [accuracy if onehot_like else utils.nn_accuracy(emb_dev, dot_prod_sim=True)]
         metrics += [utils.top_k_acc(k) if onehot_like else utils.nn_accuracy(emb_dev, dot_prod_sim=True, k=k) for k in args.top_k_acc]
@@ -206,6 +233,7 @@ def main(argv=None):
         pre = Trainer(model, losses, all_metrics, lr=args.sgd_lr, momentum=0.9, nesterov=args.nesterov, clipnorm=args.clipgrad,
                       autocast_dtype=mode[0], memory_format=mode[1], l2_of=l2_of, trainable=lambda n: ('embedding' in n) or ('prob' in n))
         pre.fit(train_seq(), val_seq(), epochs=args.finetune_init, verbose=not args.no_progress)
+        pre.close()            # drop its gradient hooks before the second trainer registers its own
         for p in model.parameters():
             p.requires_grad_(True)
         print('Full model training')
@@ -245,7 +273,9 @@ def main(argv=None):
         if args.feature_dump:
             feats = trainer.predict(data_generator.test_sequence(max(args.val_batch_size, 256)))
             feats = feats[0] if args.cls_weight > 0 else feats
-            if args.loss == 'inv_corr':     # the reference's model ends in the l2norm layer
+            if args.cls_weight > 0:
+                pass                        # ClsModel's first output already is the l2norm / softmax layer's
+            elif args.loss == 'inv_corr':   # the reference's model ends in the l2norm layer
                 feats = utils.l2norm(torch.from_numpy(feats).to(dev)).cpu().numpy()
             elif args.loss == 'softmax_corr':
                 feats = torch.softmax(torch.from_numpy(feats), -1).numpy()

@@ -45,8 +45,19 @@ def sharded_topk(queries, gallery_shard, k, shard_offset, metric=None, group=Non
     if world == 1:
         return d, i
     q = d.shape[0]
-    all_d = torch.empty((world * q, k), dtype=d.dtype, device=d.device)     # rank-major concatenation
-    all_i = torch.empty((world * q, k), dtype=i.dtype, device=i.device)
-    dist.all_gather_into_tensor(all_d, d.contiguous(), group=group)
-    dist.all_gather_into_tensor(all_i, i.contiguous(), group=group)
+    all_d = _all_gather_rows(d.contiguous(), world, group)                  # rank-major concatenation
+    all_i = _all_gather_rows(i.contiguous(), world, group)
     return merge(all_d.view(world, q, k), all_i.view(world, q, k))
+
+
+def _all_gather_rows(t, world, group=None):
+    """[rows, k] per rank -> [world * rows, k].  RCCL ("nccl") gathers device tensors directly over xGMI; the gloo backend
+    (CPU tests, or two test processes sharing one GPU -- RCCL refuses two ranks on one device) has no device all-gather, so
+    the lists take the host route there."""
+    if t.is_cuda and dist.get_backend(group) == 'gloo':
+        host = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype)
+        dist.all_gather_into_tensor(host, t.cpu(), group=group)
+        return host.to(t.device)
+    out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out, t, group=group)
+    return out

@@ -321,3 +321,122 @@ def test_training_graph_mode_world2_keeps_ranks_in_sync(tmp_path):
     mp.spawn(_graph_dp_worker, args=(2, 29637, out), nprocs=2, join=True)
     got = torch.load(out)
     assert got["ok"] and got["mode"] and got["same"] and got["finite"], got
+
+
+def test_nearest_centroid_classification_on_device():
+    """evaluate_classification_accuracy.nn_classification (reference :51-71: cdist(feat, centroids, 'sqeuclidean').argsort)
+    on se_pairwise_dist + se_rank_rows: equals SciPy's float64 ranking wherever adjacent class distances are clearly apart,
+    equals the canonical oracle bit for bit, and feeds `evaluate` (flat / top-5 / balanced / hierarchical accuracy)."""
+    import evaluate_classification_accuracy as eca
+    from scipy.spatial.distance import cdist
+    from oracle import retrieval_oracle as ro
+    g = np.load(os.path.join(GOLDEN, "embeddings.npz"))
+    E = g["cifar100_unitsphere"]
+    rng = np.random.default_rng(4)
+    y = rng.integers(0, 100, size=700)
+    feats = (E[y] + 0.25 * rng.standard_normal((700, 100))).astype(np.float32)
+    rank = eca.nn_classification(feats, {"embedding": E})
+    assert rank.shape == (700, 100)
+    want = ro.canon_rank_rows(ro.canon_pdist(feats, E.astype(np.float32), ro.METRIC_EUCLID))
+    assert np.array_equal(rank, want)
+    d64 = cdist(feats, E, "sqeuclidean")
+    ref = d64.argsort(axis=-1)
+    srt = np.sort(d64, axis=-1)
+    clear = np.concatenate([np.ones((700, 1), bool), (srt[:, 1:] - srt[:, :-1]) > 1e-4], axis=1)
+    clear &= np.concatenate([clear[:, 1:], np.ones((700, 1), bool)], axis=1)
+    assert clear.mean() > 0.95 and np.array_equal(rank[clear], ref[clear])
+    # device tensor in, device ranking out
+    rk_dev = eca.nn_classification(torch.from_numpy(feats).cuda(), torch.from_numpy(E).cuda(), return_device=True)
+    assert rk_dev.is_cuda and np.array_equal(rk_dev.cpu().numpy(), rank)
+
+    class Data(object):
+        labels_test = y.tolist()
+        classes = list(range(100))
+
+    import class_hierarchy as ch
+    h = np.load(os.path.join(GOLDEN, "hierarchy_cifar.npz"))
+    parents, children = {}, {}
+    for p, c in h["edges"].tolist():
+        parents.setdefault(c, []).append(p)
+        children.setdefault(p, []).append(c)
+    hier = ch.ClassHierarchy(parents, children)
+    perf = eca.evaluate(rank, Data, hier)
+    top1 = rank[:, 0]
+    assert perf["Accuracy"] == pytest.approx(np.mean(top1 == y))
+    assert perf["Top-5 Accuracy"] == pytest.approx(np.mean((rank[:, :5] == y[:, None]).any(1)))
+    freq = np.bincount(y)
+    assert perf["Avg. Accuracy"] == pytest.approx(((top1 == y) / freq[y]).sum() / len(freq))
+    assert perf["Hierarchical Accuracy"] == pytest.approx(np.mean([1.0 - hier.lcs_height(int(a), int(b)) for a, b in zip(top1, y)]))
+    assert perf["Accuracy"] > 0.9 and perf["Hierarchical Accuracy"] >= perf["Accuracy"]
+
+
+def test_predict_keeps_features_on_the_device_for_the_metric_path(tmp_path):
+    """Trainer.predict(..., to_host=False) -> ClassHierarchy.hierarchical_precision_device with no host hop; the
+    values equal the pickle route (features through the host) exactly."""
+    import utils
+    import class_hierarchy as ch
+    from datasets import get_data_generator
+    from engine import Trainer
+    gen = get_data_generator("synthetic:10x32x64x96", ".")
+    torch.manual_seed(0)
+    model = utils.build_network(16, "resnet-32", input_channels=3).cuda()   # pooled 64-d features
+    tr = Trainer(model, {}, {}, autocast_dtype=None)
+    seq = gen.test_sequence(32)
+    f_dev = tr.predict(seq, to_host=False)
+    f_host = tr.predict(seq)
+    assert torch.is_tensor(f_dev) and f_dev.is_cuda and f_dev.dtype == torch.float32
+    assert np.array_equal(f_dev.cpu().numpy(), f_host)
+    parents = {i: [100 + i // 5] for i in range(10)}
+    parents.update({100: [200], 101: [200]})
+    children = {}
+    for c, ps in parents.items():
+        for p in ps:
+            children.setdefault(p, []).append(c)
+    hier = ch.ClassHierarchy(parents, children)
+    labels = gen.labels_test
+    a, _ = hier.hierarchical_precision_device(f_dev, labels, [1, 5, 10], compute_ahp=True, compute_ap=True, normalize=True)
+    b, _ = hier.hierarchical_precision_device(f_host, labels, [1, 5, 10], compute_ahp=True, compute_ap=True, normalize=True)
+    assert a == b
+
+
+def _sharded_topk_worker(rank, world, port, out):
+    import torch.distributed as dist
+    for p in (os.path.join(ROOT, "semantic-embeddings_amd"), ROOT):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)     # RCCL refuses two ranks on one device
+    torch.cuda.set_device(0)
+    import sehip
+    import sharded_retrieval as sr
+    rng = np.random.default_rng(0)
+    gallery = rng.standard_normal((3001, 200)).astype(np.float32)
+    gallery[1500:1510] = gallery[0:10]                                # exact ties ACROSS the two shards
+    queries = gallery[:300].copy()
+    lo_, hi_ = sr.shard_bounds(len(gallery), world)[rank]
+    g = torch.from_numpy(gallery[lo_:hi_]).cuda()
+    q = torch.from_numpy(queries).cuda()
+    sehip.normalize_rows_(g)
+    sehip.normalize_rows_(q)
+    d, i = sr.sharded_topk(q, g, 251, lo_, metric=sehip.METRIC_COSINE)      # the real kernels: se_retrieve_topk + se_topk_merge
+    both = [None] * world
+    dist.all_gather_object(both, i.cpu().numpy().tobytes())
+    if rank == 0:
+        np.savez(out, d=d.cpu().numpy(), i=i.cpu().numpy(), gallery=gallery, queries=queries, same=both[0] == both[1])
+    dist.destroy_process_group()
+
+
+def test_sharded_gallery_topk_two_processes_real_kernels(tmp_path):
+    """The north_star retrieval split with the HIP kernels on both ranks (two processes on the one GPU, gloo transport):
+    per-shard se_retrieve_topk -> all-gather -> se_topk_merge == canonical top-k over the whole gallery, identical on both
+    ranks, ties across shards broken by the GLOBAL index."""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "st.npz")
+    mp.spawn(_sharded_topk_worker, args=(2, 29641, out), nprocs=2, join=True)
+    g = np.load(out)
+    assert bool(g["same"])
+    gal = ro.canon_normalize_rows(g["gallery"])
+    qs = ro.canon_normalize_rows(g["queries"])
+    wd, wi = ro.canon_topk_rows(ro.canon_pdist(qs, gal, ro.METRIC_COSINE), 251)
+    assert np.array_equal(g["i"], wi) and np.array_equal(g["d"], wd)

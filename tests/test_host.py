@@ -294,3 +294,70 @@ def test_bench_cost_model_counts_executed_flops():
     assert abs(floor - max(ex / 157.3e12, b / 8e12) * 1e3) < 1e-12 and 1.5 < floor < 1.7
     _, _, ex_g, floor_g = bench.pdist_cost_model(50000, 50000, 100, symmetric=False)
     assert ex_g == full and 3.1 < floor_g < 3.3
+
+
+def _write_cifar100(root, n_train=60, n_test=24, seed=0):
+    import pickle
+    rng = np.random.default_rng(seed)
+    for name, n in (("train", n_train), ("test", n_test)):
+        dump = {b"data": rng.integers(0, 256, size=(n, 3072), dtype=np.uint8), b"fine_labels": rng.integers(0, 100, size=n).tolist()}
+        with open(os.path.join(root, name), "wb") as f:
+            pickle.dump(dump, f)
+
+
+def test_cifar_reader_standardisation_matches_keras_featurewise(tmp_path):
+    """the CIFAR python-pickle reader (datasets/cifar.py:9-84) + TinyDatasetGenerator's pre-processing
+    (datasets/common.py:635-669,771-796): Keras ImageDataGenerator(featurewise_center, featurewise_std_normalization)
+    statistics are PER CHANNEL over (samples, rows, columns); standardize is (x - mean) / (std + 1e-6)."""
+    import pickle
+    from datasets import get_data_generator
+    root = str(tmp_path)
+    _write_cifar100(root)
+    gen = get_data_generator("cifar-100", root)
+    assert gen.num_train == 60 and gen.num_test == 24 and gen.num_channels == 3 and gen.num_classes == max(gen.labels_train) + 1
+    with open(os.path.join(root, "train"), "rb") as f:
+        tr = pickle.load(f)
+    with open(os.path.join(root, "test"), "rb") as f:
+        te = pickle.load(f)
+    X = tr[b"data"].reshape(-1, 3, 32, 32).transpose(0, 2, 3, 1).astype(np.float32)       # datasets/cifar.py: NHWC float images
+    mean = X.mean(axis=(0, 1, 2))
+    std = (X - mean).std(axis=(0, 1, 2))
+    assert gen.mean.shape == (1, 1, 1, 3) and np.allclose(gen.mean.ravel(), mean, rtol=1e-6)
+    assert np.allclose(gen.std.ravel(), std + 1e-6, rtol=1e-6)
+    Xt = te[b"data"].reshape(-1, 3, 32, 32).transpose(0, 2, 3, 1).astype(np.float32)
+    want = ((Xt - mean) / (std + 1e-6)).transpose(0, 3, 1, 2)
+    got = gen.compose_batch(np.arange(24), train=False, augment=False).cpu().numpy()
+    assert got.shape == (24, 3, 32, 32) and np.allclose(got, want, rtol=1e-5, atol=1e-5)
+    assert gen.labels_test == list(te[b"fine_labels"])
+    # sequences: labels travel with the rows, the short last batch survives data-parallel sharding without empty shards
+    seq = gen.test_sequence(batch_size=10)
+    assert len(seq) == 3
+    Xb, yb = seq[2]
+    assert Xb.shape[0] == 4 and yb.tolist() == gen.labels_test[20:24]
+    shards = [gen.test_sequence(batch_size=10, rank=r, world_size=8)[2] for r in range(8)]
+    assert all(s[0].shape[0] >= 1 for s in shards)
+
+
+def test_cifar_reader_augmentation_is_flip_plus_bilinear_shift(tmp_path):
+    from datasets.common import InMemoryDatasetGenerator
+    h = w = 32
+    rr, cc = np.meshgrid(np.arange(h, dtype=np.float32), np.arange(w, dtype=np.float32), indexing="ij")
+    ramp = np.stack([rr, cc, rr + 2 * cc], axis=-1)[None].repeat(40, axis=0)               # linear ramps: bilinear shifts are exact
+    gen = InMemoryDatasetGenerator(ramp, ramp[:4], [0] * 40, [0] * 4, shift_range=0.15, horizontal_flip=False)
+    gen.mean, gen.std = np.zeros((1, 1, 1, 3), np.float32), np.ones((1, 1, 1, 3), np.float32)
+    torch.manual_seed(3)
+    out = gen.compose_batch(np.arange(40), train=True, augment=True).cpu().numpy()
+    ty = out[:, 0, 16, 16] - 16.0
+    tx = out[:, 1, 16, 16] - 16.0
+    assert np.abs(ty).max() <= 0.15 * h + 1e-4 and np.abs(tx).max() <= 0.15 * w + 1e-4
+    assert ty.std() > 1.0 and tx.std() > 1.0 and np.abs(ty - np.round(ty)).max() > 0.05      # continuous, per-sample offsets
+    inner = slice(6, 26)
+    assert np.allclose(out[:, 0, inner, inner], rr[inner, inner][None] + ty[:, None, None], atol=1e-3)
+    assert np.allclose(out[:, 2, inner, inner], (rr + 2 * cc)[inner, inner][None] + (ty + 2 * tx)[:, None, None], atol=1e-3)
+    assert out.min() >= -1e-4 and out[:, 0].max() <= 31 + 1e-4                                # edges replicated, nothing extrapolated
+    flip = InMemoryDatasetGenerator(ramp, ramp[:4], [0] * 40, [0] * 4, shift_range=0.0, horizontal_flip=True)
+    flip.mean, flip.std = gen.mean, gen.std
+    f = flip.compose_batch(np.arange(40), train=True, augment=True).cpu().numpy()
+    mirrored = np.isclose(f[:, 1, 0, 0], 31.0)
+    assert 5 < mirrored.sum() < 35
+    assert np.allclose(f[mirrored][:, 1], cc[:, ::-1][None]) and np.allclose(f[~mirrored][:, 1], cc[None])
