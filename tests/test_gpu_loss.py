@@ -214,7 +214,7 @@ def test_hip_loss_kernels_vs_reference_lines(sehip, path):
     assert np.abs(xhat.cpu().numpy() - g["xhat_64"]).max() <= 2e-6 * scale
     assert np.abs(xhat.cpu().numpy() - g["xhat_32"]).max() <= 1e-4 * scale
     xhat_f, inv, loss_i, loss = sehip.cosine_loss_forward(xd, yd, Ed)
-    assert torch.equal(xhat_f, xhat)
+    assert float((xhat_f - xhat).abs().max()) <= 1e-6 * scale          # fused and stand-alone heads: same formula, different reduction trees
     # inv_correlation (utils.py:44-46) on transform_inputs' gather (learn_image_embeddings.py:48-50)
     li = loss_i.cpu().numpy()
     assert np.abs(li - g["inv_correlation_32"]).max() <= LOSS_TOL
