@@ -236,16 +236,11 @@ __global__ __launch_bounds__(RK_THREADS) void rank_rows_kernel(const float *__re
 //   * indices travel as 16 bits (N <= 65536 by construction) packed with the 16-bit destination;
 //   * after the last pass the exchange buffer IS the ranking: it is streamed to HBM with 16-byte
 //     stores.
-#ifndef SE_RR_THREADS
-#define SE_RR_THREADS 512   // 512 (8 waves, 2 per SIMD, <= 256 VGPRs) or 768 (12 waves, 3 per SIMD, <= 168 VGPRs)
-#endif
-constexpr int RR_THREADS = SE_RR_THREADS;
+constexpr int RR_THREADS = 512;
 constexpr int RR_WAVES = RR_THREADS / WAVE;
-constexpr int RR_SCAN_THREADS = 512;                  // threads that scan the packed counters (2 words each of the 1024 per wave)
-constexpr int RR_SCAN_WAVES = RR_SCAN_THREADS / WAVE;
-constexpr int RR_MAX_ITEMS = (53248 + RR_THREADS - 1) / RR_THREADS;   // 104 (512 threads) / 70 (768 threads)
+constexpr int RR_MAX_ITEMS = 104;
 constexpr int RR_G = 8;                               // steps ranked together (latency overlap vs live registers)
-constexpr int RR_MAX_N = 53248;
+constexpr int RR_MAX_N = RR_THREADS * RR_MAX_ITEMS;   // 53248
 
 // Wave multisplit on an 8-bit digit: bit mask of the lanes whose digit DIFFERS from this lane's, as
 // OR_b (ballot_b ^ own_bit_b): per bit one v_bfe_i32, one v_cmp (the ballot) and one v_bitop3 per mask half.
@@ -299,10 +294,7 @@ __device__ __forceinline__ void lds_ld16(uint32_t &dst, uint32_t addr) { asm vol
 template <int K>
 __device__ __forceinline__ void lds_wait_le(uint32_t &landed) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(landed) : "n"(K) : "memory"); }
 
-#ifndef SE_RR_RING
-#define SE_RR_RING 12
-#endif
-constexpr int RR_RING = SE_RR_RING;   // 16-bit loads in flight per lane (lgkmcnt counts to 15)
+constexpr int RR_RING = 12;   // 16-bit loads in flight per lane (lgkmcnt counts to 15)
 // Software-pipelined read of this lane's ITEMS new 16-bit values (read slot of step s = addr + 128 s)
 // into the HIGH (HI = true) or LOW half of a[s]: read i is issued RR_RING - 1 reads ahead of its merge.
 template <int ITEMS, bool HI, int I = 0>
@@ -476,7 +468,7 @@ struct RRRankHW {
 };
 
 template <int ITEMS, bool PROF, bool HWORD, bool PEEL>
-__global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_kernel(const float *__restrict__ pdist, int64_t ldp, int64_t Q,
+__global__ __launch_bounds__(RR_THREADS, 2) void rank_rows_reg_kernel(const float *__restrict__ pdist, int64_t ldp, int64_t Q,
                                                                     int N, void *rank, int64_t ldr, int idx64, int vec_ok,
                                                                     unsigned long long *prof, const uint32_t *skew_flag)
 {
@@ -495,7 +487,7 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
     constexpr bool WIDE = HWORD && ((size_t)RR_THREADS * ITEMS * sizeof(uint16_t) >= (size_t)RR_WAVES * RR_WIDE_WORDS * sizeof(uint32_t));
     uint32_t *wcnt = reinterpret_cast<uint32_t *>(rr_raw);              // [RR_WAVES][CNT_WORDS]
     uint32_t *wave_tot = wcnt + RR_WAVES * CNT_WORDS;                   // [8] (+pad)
-    uint16_t *xbuf = reinterpret_cast<uint16_t *>(wave_tot + 32);       // [RR_THREADS * ITEMS]
+    uint16_t *xbuf = reinterpret_cast<uint16_t *>(wave_tot + 16);       // [RR_THREADS * ITEMS]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wpos0 = wave * (ITEMS * WAVE) + lane;                     // position of (step s) = wpos0 + 64 s
     const uint32_t xb = lds_off(xbuf);                                  // exchange buffer, byte address
@@ -613,19 +605,17 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
                 // 8 waves x pcw words of 16-bit counts, two per word (low half: digit w, high half: digit pcw + w).  Thread t owns the
                 // words 2t and 2t+1 of every wave (one 8-byte LDS access each; the 12-bit pass: also 1024 + 2t and 1025 + 2t) and all
                 // arithmetic stays PACKED: a half never exceeds the 53,248 keys of a row, so the low halves cannot carry into the high ones.
-                const bool scanner = tid < RR_SCAN_THREADS;   // (with 768 threads the last 4 waves only take part in the barriers)
-                const int st = scanner ? tid : 0;
                 uint32_t T0 = 0, T1 = 0, U0 = 0, U1 = 0;   // per-word totals over the waves (U: second word group of the wide pass)
 #pragma unroll
                 for (int w = 0; w < RR_WAVES; w++) {
-                    const uint2 v = *reinterpret_cast<const uint2 *>(pcnt + w * pcw + 2 * st);
+                    const uint2 v = *reinterpret_cast<const uint2 *>(pcnt + w * pcw + 2 * tid);
                     T0 += v.x; T1 += v.y;
                 }
                 if (wide) {
                     __builtin_amdgcn_sched_barrier(0);   // one word group at a time: 2 x ITEMS registers are live across the scan
 #pragma unroll
                     for (int w = 0; w < RR_WAVES; w++) {
-                        const uint2 v = *reinterpret_cast<const uint2 *>(pcnt + w * pcw + CNT_WORDS + 2 * st);
+                        const uint2 v = *reinterpret_cast<const uint2 *>(pcnt + w * pcw + CNT_WORDS + 2 * tid);
                         U0 += v.x; U1 += v.y;
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -633,12 +623,12 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
                 uint32_t wtot, wtot2 = 0, ex2 = 0;
                 uint32_t ex = wave_excl_scan(T0 + T1, wtot);   // both halves scanned at once
                 if (wide) ex2 = wave_excl_scan(U0 + U1, wtot2);
-                if (scanner && lane == 63) { wave_tot[wave] = wtot; wave_tot[RR_SCAN_WAVES + wave] = wtot2; }
+                if (lane == 63) { wave_tot[wave] = wtot; wave_tot[RR_WAVES + wave] = wtot2; }
                 __syncthreads();
                 uint32_t all = 0, all2 = 0;
 #pragma unroll
-                for (int w = 0; w < RR_SCAN_WAVES; w++) {
-                    const uint32_t wt = wave_tot[w], wt2 = wave_tot[RR_SCAN_WAVES + w];
+                for (int w = 0; w < RR_WAVES; w++) {
+                    const uint32_t wt = wave_tot[w], wt2 = wave_tot[RR_WAVES + w];
                     all += wt; all2 += wt2;
                     ex += (w < wave) ? wt : 0u;
                     ex2 += (w < wave) ? wt2 : 0u;
@@ -647,7 +637,6 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
                 const uint32_t hi = (all + all2) << 16;   // the high-half digits follow ALL low-half digits
                 ex += hi; ex2 += hi;
                 // digit-major / wave-minor: counts -> first destination of (wave, digit), written back in place
-                if (scanner) {
                 uint32_t s0 = ex, s1 = ex + T0;
 #pragma unroll
                 for (int w = 0; w < RR_WAVES; w++) {
@@ -666,7 +655,6 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
                         *wp = make_uint2(s0, s1);
                         s0 += v.x; s1 += v.y;
                     }
-                }
                 }
             }
             __syncthreads();
@@ -800,6 +788,310 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
 #undef RR_T
 }
 
+
+// =================================================================================================
+// Register-resident variant, second generation ("hw32"): the hardware-ordered kernel re-cut for VALU issue.
+//
+// Measured on MI355X: the first-generation kernel issues ~63 VALU instructions per key and row next to ~17 LDS
+// operations; with two waves per SIMD its ~11k instructions per wave and row, not the LDS pipe, set the pace (adding 15 VALU per
+// key while REMOVING a quarter of the LDS reads made it 16 % slower).  This version removes VALU work instead:
+//   * 32-bit wave-private counters (ds_add_rtn_u32 of the constant 1, returned value = rank): no half select, no packed increment,
+//     no per-key byte selector -- rank phase 3 VALU per key (digit, counter address, merge) instead of 6, destination phase 3
+//     instead of 4.  8 waves x 2048 counters x 4 B = 64 KB do not fit next to the 100 KB exchange buffer, so they ALIAS it in every
+//     pass: the buffer is idle from the last exchange read of one pass to the first scatter of the next (one more barrier before
+//     the counters are zeroed, one between the last counter look-up and the first scatter);
+//   * the exchange buffer starts at LDS address 0 and the scatter address 2 * (ir & 0xFFFF) is ONE sub-dword-addressed shift
+//     (v_lshlrev_b32_sdwa ... src1_sel:WORD_0) instead of shift + mask + base add: 6 scatters per key -> 6 VALU instead of 18;
+//   * digits of 10 + 11 + 11 bits (the most significant digit keeps the 11 bits whose lower skew the 12-bit pass was introduced for).
+// Everything else -- stable one-returning-add-per-key ranks (hardware lane order, probed at first use), software-pipelined adds and
+// 16-bit exchange reads, group peeling for skewed top digits, the row pipeline over HBM -- is the first generation's.
+constexpr int R32_CW = 2048;                                  // counter words per wave (every pass; pass 0 uses the first 1024)
+constexpr int R32_CNT_BYTES = RR_WAVES * R32_CW * 4;          // 64 KB, aliased onto the exchange buffer
+
+__device__ __forceinline__ uint32_t r32_slot_addr(uint32_t ir, uint32_t one)   // byte address of exchange slot ir & 0xFFFF (buffer at LDS address 0)
+{
+    uint32_t a;
+    asm volatile("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(a) : "s"(one), "v"(ir));
+    return a;
+}
+
+template <int ITEMS, bool PEEL, int S = 0>
+struct R32Rank {
+    static __device__ __forceinline__ void run(uint32_t (&ir)[ITEMS], uint32_t (&key)[ITEMS], uint32_t (&r)[RR_GH], uint32_t (&grp)[RR_GH],
+                                               uint32_t shift, uint32_t bits, uint32_t cb, uint32_t vone, int lane, bool peel)
+    {
+        constexpr int SLOT = S % RR_GH;
+        uint32_t ca = 0, inc = vone, g = 0xFFFFFFFFu;
+        uint64_t part = ~0ull;
+        if constexpr (S < ITEMS) {
+            const uint32_t d = __builtin_amdgcn_ubfe(key[S], shift, bits);
+            ca = cb + (d << 2);
+            if constexpr (PEEL) {
+                if (peel) {   // wave-uniform: lanes sharing lane 0's digit (most significant pass only) are ranked by one ballot and ONE add of the group size
+                    const bool in = (d == (uint32_t)__builtin_amdgcn_readfirstlane((int)d));
+                    const uint64_t m = __ballot(in);
+                    if (in) g = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    if (lane == 0) inc = (uint32_t)__popcll(m);
+                    part = ~m | 1ull;                // only lane 0 and the lanes outside its group issue the add
+                }
+            }
+        }
+        if constexpr (S >= RR_GH) {                  // retire step J: wait until only the adds issued after it are outstanding
+            constexpr int J = S - RR_GH;
+            constexpr int younger = ((S < ITEMS ? S : ITEMS) - 1) - J;
+            lds_wait_le<younger>(r[SLOT]);
+            if constexpr (PEEL) {
+                const uint32_t lead = (uint32_t)__builtin_amdgcn_readfirstlane((int)r[SLOT]);   // lane 0's counter before its add
+                const uint32_t rank = (grp[SLOT] != 0xFFFFFFFFu) ? lead + grp[SLOT] : r[SLOT];
+                ir[J] = (ir[J] & 0xFFFF0000u) | rank;
+            } else {
+                ir[J] = __builtin_amdgcn_perm(ir[J], r[SLOT], 0x07060100u);   // low half <- returned rank
+            }
+            opaque(ir[J]);    // materialise now: nothing but key/ir stays live per key
+            opaque(key[J]);
+        }
+        if constexpr (S < ITEMS) {
+            grp[SLOT] = g;
+            if constexpr (PEEL) {
+                uint64_t saved;
+                r[SLOT] = 0;
+                asm volatile("s_and_saveexec_b64 %0, %4\n\tds_add_rtn_u32 %1, %2, %3\n\ts_mov_b64 exec, %0"
+                             : "=&s"(saved), "+v"(r[SLOT])
+                             : "v"(ca), "v"(inc), "s"(part)
+                             : "memory");
+            } else {
+                asm volatile("ds_add_rtn_u32 %0, %1, %2" : "=v"(r[SLOT]) : "v"(ca), "v"(inc) : "memory");
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (S + 1 < ITEMS + RR_GH) R32Rank<ITEMS, PEEL, S + 1>::run(ir, key, r, grp, shift, bits, cb, vone, lane, peel);
+    }
+};
+
+template <int ITEMS, bool PEEL>
+__global__ __launch_bounds__(RR_THREADS, 2) void rank_rows_hw32_kernel(const float *__restrict__ pdist, int64_t ldp, int64_t Q, int N, void *rank,
+                                                                      int64_t ldr, int idx64, int vec_ok, const uint32_t *skew_flag)
+{
+    if (skew_flag && ((*skew_flag != 0) != PEEL)) return;   // two launches behind the skew detector: the other build handles this call
+    extern __shared__ __attribute__((aligned(16))) unsigned char rr_raw[];
+    constexpr int XBYTES = RR_THREADS * ITEMS * 2;
+    constexpr int REGION = XBYTES > R32_CNT_BYTES ? XBYTES : R32_CNT_BYTES;
+    uint16_t *xbuf = reinterpret_cast<uint16_t *>(rr_raw);                 // exchange buffer at LDS address 0 ...
+    uint32_t *cnt = reinterpret_cast<uint32_t *>(rr_raw);                  // ... aliased by the counters [RR_WAVES][R32_CW]
+    uint32_t *wave_tot = reinterpret_cast<uint32_t *>(rr_raw + REGION);    // [RR_WAVES] (+ pad)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wpos0 = wave * (ITEMS * WAVE) + lane;                        // position of (step s) = wpos0 + 64 s
+    const uint32_t rb = 2u * (uint32_t)wpos0;                              // this lane's read slot of step 0
+    uint32_t *mycnt = cnt + wave * R32_CW;
+    const uint32_t cb = (uint32_t)(wave * R32_CW * 4);
+    uint32_t key[ITEMS], ir[ITEMS], ring[RR_RING];
+    uint32_t one = 1u;
+    asm volatile("" : "+s"(one));     // a scalar register holding 1 (SDWA takes no inline constants)
+    uint32_t vone = 1u;
+    asm volatile("" : "+v"(vone));    // and a vector register holding 1: the increment of every returning add
+#define R32_LOAD_ONE(DROW, WPOS, S)                                                             \
+    {                                                                                           \
+        const int pos = (WPOS) + (S) * WAVE;                                                    \
+        uint32_t gi = (uint32_t)(pos < N ? pos : N - 1);                                        \
+        opaque(gi);                                                                             \
+        key[S] = __float_as_uint((DROW)[gi]);                                                   \
+    }
+#define R32_CANON()                                                                             \
+    {                                                                                           \
+        int wpos_ = wpos0;                                                                      \
+        opaque(wpos_);                                                                          \
+        _Pragma("unroll") for (int s = 0; s < ITEMS; s++) key[s] = rr_key(key[s], wpos_ + s * WAVE >= N); \
+    }
+    if ((int64_t)blockIdx.x < Q) {
+        const float *drow = pdist + (int64_t)blockIdx.x * ldp;
+        int wpos = wpos0;
+        opaque(wpos);
+#pragma unroll
+        for (int s = 0; s < ITEMS; s++) R32_LOAD_ONE(drow, wpos, s)
+        R32_CANON()
+    }
+    uint32_t pf_sink = 0;
+    for (int64_t row = blockIdx.x; row < Q; row += gridDim.x) {
+        const bool more = row + gridDim.x < Q;
+        {
+            int wpos = wpos0;
+            opaque(wpos);
+#pragma unroll
+            for (int s = 0; s < ITEMS; s++) ir[s] = (uint32_t)(wpos + s * WAVE) << 16;
+        }
+#pragma unroll 1
+        for (int p = 0; p < 3; p++) {
+            const uint32_t shift = p == 0 ? 0u : (p == 1 ? 10u : 21u), bits = p == 0 ? 10u : 11u;
+            // ---- counters (aliased onto the exchange buffer): every wave has finished reading the buffer ----
+            __syncthreads();
+            {
+                const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+                for (int j = 0; j < R32_CW / (WAVE * 4); j++) *reinterpret_cast<uint4 *>(mycnt + (j * WAVE + lane) * 4) = z;
+            }
+            // ---- R: stable rank inside the wave: one returning add of 1 per key ----
+            {
+                uint32_t hr[RR_GH], hg[RR_GH];
+                R32Rank<ITEMS, PEEL>::run(ir, key, hr, hg, shift, bits, cb, vone, lane, p == 2);
+            }
+            lds_wait();
+            __syncthreads();
+            // L2 prefetch of this workgroup's next row (one dword per 128-byte line) while the last pass runs
+            if (p == 2 && more) {
+                const char *nrow = (const char *)(pdist + (row + gridDim.x) * ldp);
+                const uint32_t row_bytes = (uint32_t)N * 4u;
+                for (uint32_t off = (uint32_t)tid * 128u; off < row_bytes; off += RR_THREADS * 128u)
+                    asm volatile("global_load_dword %0, %1, off" : "=v"(pf_sink) : "v"(nrow + off) : "memory");
+            }
+            // ---- S: counters -> first destination of every (wave, digit), digit-major / wave-minor; thread t owns digits 4t .. 4t+3 ----
+            {
+                uint32_t t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+#pragma unroll
+                for (int w = 0; w < RR_WAVES; w++) {
+                    const uint4 v = *reinterpret_cast<const uint4 *>(cnt + w * R32_CW + 4 * tid);
+                    t0 += v.x; t1 += v.y; t2 += v.z; t3 += v.w;
+                }
+                uint32_t wtot;
+                uint32_t ex = wave_excl_scan(t0 + t1 + t2 + t3, wtot);
+                if (lane == 63) wave_tot[wave] = wtot;
+                __syncthreads();
+#pragma unroll
+                for (int w = 0; w < RR_WAVES; w++) ex += (w < wave) ? wave_tot[w] : 0u;
+                uint32_t s0 = ex, s1 = ex + t0, s2 = s1 + t1, s3 = s2 + t2;
+#pragma unroll
+                for (int w = 0; w < RR_WAVES; w++) {
+                    uint4 *wp = reinterpret_cast<uint4 *>(cnt + w * R32_CW + 4 * tid);
+                    const uint4 v = *wp;
+                    *wp = make_uint4(s0, s1, s2, s3);
+                    s0 += v.x; s1 += v.y; s2 += v.z; s3 += v.w;
+                }
+            }
+            __syncthreads();
+            // ---- destinations: rank + first destination of (wave, digit) ----
+#pragma unroll
+            for (int s0 = 0; s0 < ITEMS; s0 += 8) {
+                uint32_t first[8];
+#pragma unroll
+                for (int g = 0; g < 8; g++)
+                    if (s0 + g < ITEMS) first[g] = mycnt[__builtin_amdgcn_ubfe(key[s0 + g], shift, bits)];
+#pragma unroll
+                for (int g = 0; g < 8; g++)
+                    if (s0 + g < ITEMS) {
+                        ir[s0 + g] += first[g];   // low half: rank -> destination (< 65536)
+                        opaque(ir[s0 + g]);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __syncthreads();   // the scatter below overwrites the (aliased) counters other waves may still be looking up
+            // ---- X: the 2-byte exchanges ----
+#pragma unroll
+            for (int s = 0; s < ITEMS; s += 2) {                                                                                 // index
+                // two at a time: the second address is computed in the shadow of the first (an SDWA result needs a wait state before
+                // the LDS instruction that uses it, and so does a reused address register behind an LDS write)
+                opaque(ir[s]);
+                const uint32_t a0 = r32_slot_addr(ir[s], one);
+                if (s + 1 < ITEMS) {
+                    opaque(ir[s + 1]);
+                    const uint32_t a1 = r32_slot_addr(ir[s + 1], one);
+                    lds_st16_hi(a0, ir[s]);
+                    lds_st16_hi(a1, ir[s + 1]);
+                } else lds_st16_hi(a0, ir[s]);
+            }
+            lds_wait();
+            __syncthreads();
+            if (p == 2) break;   // last pass: the index buffer is the ranking
+            RRRead<ITEMS, true>::run(ir, ring, rb);
+            lds_wait();
+            __syncthreads();
+#pragma unroll
+            for (int s = 0; s < ITEMS; s += 2) {                                                                                 // key bits 16-31
+                opaque(ir[s]);
+                const uint32_t a0 = r32_slot_addr(ir[s], one);
+                if (s + 1 < ITEMS) {
+                    opaque(ir[s + 1]);
+                    const uint32_t a1 = r32_slot_addr(ir[s + 1], one);
+                    lds_st16_hi(a0, key[s]);
+                    lds_st16_hi(a1, key[s + 1]);
+                } else lds_st16_hi(a0, key[s]);
+            }
+            lds_wait();
+            __syncthreads();
+            RRRead<ITEMS, true>::run(key, ring, rb);
+            lds_wait();
+            if (p == 0) {                                                                                                      // key bits 10-15: still needed by pass 1
+                __syncthreads();
+#pragma unroll
+                for (int s = 0; s < ITEMS; s += 2) {                                                                             // (low half is still the old key's)
+                    opaque(ir[s]);
+                    const uint32_t a0 = r32_slot_addr(ir[s], one);
+                    if (s + 1 < ITEMS) {
+                        opaque(ir[s + 1]);
+                        const uint32_t a1 = r32_slot_addr(ir[s + 1], one);
+                        lds_st16_lo(a0, key[s]);
+                        lds_st16_lo(a1, key[s + 1]);
+                    } else lds_st16_lo(a0, key[s]);
+                }
+                lds_wait();
+                __syncthreads();
+                RRRead<ITEMS, false>::run(key, ring, rb);
+                lds_wait();
+            }
+            // (the next pass's first barrier orders these reads before the counters are zeroed)
+        }
+        // ---- the exchange buffer now holds the ranking: load the next row (before the rank stores are issued), stream the ranks out, canonicalise ----
+        {
+            const float *drow = pdist + (more ? row + gridDim.x : row) * ldp;
+            int wpos = wpos0;
+            opaque(wpos);
+#pragma unroll
+            for (int s = 0; s < ITEMS; s++) R32_LOAD_ONE(drow, wpos, s)
+        }
+        int wt = tid;
+        opaque(wt);
+        if (idx64) {
+            int64_t *o = (int64_t *)rank + row * ldr;
+            uint2 nv = *reinterpret_cast<const uint2 *>(xbuf + (wt * 4 < N ? wt * 4 : 0));
+            _Pragma("unroll 1") for (int j = wt * 4; j < N; j += RR_THREADS * 4) {
+                const uint2 v = nv;
+                const int jn = j + RR_THREADS * 4;
+                nv = *reinterpret_cast<const uint2 *>(xbuf + (jn < N ? jn : 0));
+                const int64_t e0 = v.x & 0xFFFFu, e1 = v.x >> 16, e2 = v.y & 0xFFFFu, e3 = v.y >> 16;
+                if (vec_ok && j + 3 < N) {
+                    *reinterpret_cast<longlong2 *>(o + j) = make_longlong2(e0, e1);
+                    *reinterpret_cast<longlong2 *>(o + j + 2) = make_longlong2(e2, e3);
+                } else {
+                    o[j] = e0;
+                    if (j + 1 < N) o[j + 1] = e1;
+                    if (j + 2 < N) o[j + 2] = e2;
+                    if (j + 3 < N) o[j + 3] = e3;
+                }
+            }
+        } else {
+            int32_t *o = (int32_t *)rank + row * ldr;
+            uint2 nv = *reinterpret_cast<const uint2 *>(xbuf + (wt * 4 < N ? wt * 4 : 0));
+            _Pragma("unroll 1") for (int j = wt * 4; j < N; j += RR_THREADS * 4) {
+                const uint2 v = nv;
+                const int jn = j + RR_THREADS * 4;
+                nv = *reinterpret_cast<const uint2 *>(xbuf + (jn < N ? jn : 0));
+                const int e0 = v.x & 0xFFFFu, e1 = v.x >> 16, e2 = v.y & 0xFFFFu, e3 = v.y >> 16;
+                if (vec_ok && j + 3 < N) {
+                    *reinterpret_cast<int4 *>(o + j) = make_int4(e0, e1, e2, e3);
+                } else {
+                    o[j] = e0;
+                    if (j + 1 < N) o[j + 1] = e1;
+                    if (j + 2 < N) o[j + 2] = e2;
+                    if (j + 3 < N) o[j + 3] = e3;
+                }
+            }
+        }
+        R32_CANON()
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf_sink) : : "memory");   // prefetch dwords landed too
+        // (the next row's first barrier orders the write-out reads before the counters are zeroed)
+    }
+#undef R32_LOAD_ONE
+#undef R32_CANON
+}
+
 }  // namespace se
 
 using namespace se;
@@ -852,7 +1144,7 @@ static int launch_rank_reg_variant(const float *pdist, int64_t ldp, int64_t q, i
                                    const uint32_t *skew_flag, hipStream_t s)
 {
     const size_t cnt_words = HW ? (size_t)(1 << RR_HW_BITS) / 2 : (size_t)RK_NB;   // per wave (packed 16-bit vs 32-bit counters)
-    const size_t lds = (RR_WAVES * cnt_words + 32) * sizeof(uint32_t) + (size_t)RR_THREADS * ITEMS * sizeof(uint16_t);
+    const size_t lds = (RR_WAVES * cnt_words + 16) * sizeof(uint32_t) + (size_t)RR_THREADS * ITEMS * sizeof(uint16_t);
     static const bool profile = tuning_env("SE_RR_PROFILE") != nullptr;   // -DSE_TUNING build only: allocates, synchronises, prints
     auto kern = (kTuning && profile) ? rank_rows_reg_kernel<ITEMS, kTuning && (ITEMS == 98), HW, PEEL> : rank_rows_reg_kernel<ITEMS, false, HW, PEEL>;
     // per instantiation, computed once (thread-safe static initialisation): resident workgroups = CUs x occupancy
@@ -898,6 +1190,34 @@ static int launch_rank_reg_variant(const float *pdist, int64_t ldp, int64_t q, i
     return SE_OK;
 }
 
+template <int ITEMS, bool PEEL>
+static int launch_rank_hw32_variant(const float *pdist, int64_t ldp, int64_t q, int n, void *rank, int idx64, int64_t ldr,
+                                    const uint32_t *skew_flag, hipStream_t s)
+{
+    const size_t xbytes = (size_t)RR_THREADS * ITEMS * sizeof(uint16_t);
+    const size_t lds = (xbytes > (size_t)R32_CNT_BYTES ? xbytes : (size_t)R32_CNT_BYTES) + 16 * sizeof(uint32_t);
+    auto kern = rank_rows_hw32_kernel<ITEMS, PEEL>;
+    struct Resident { hipError_t err; int64_t grid; };
+    static const Resident res = [&]() -> Resident {   // per instantiation, once (thread-safe static initialisation)
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        int dev = 0, occ = 0;
+        hipDeviceProp_t prop;
+        if (e == hipSuccess) e = hipGetDevice(&dev);
+        if (e == hipSuccess) e = hipGetDeviceProperties(&prop, dev);
+        if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)kern, RR_THREADS, lds);
+        if (e != hipSuccess) return {e, 0};
+        return {hipSuccess, (int64_t)(prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256) * (occ > 0 ? occ : 1)};
+    }();
+    if (res.err != hipSuccess) return fail(SE_ERR_HIP, "se_rank_rows: kernel set-up failed: %s", hipGetErrorString(res.err));
+    int64_t grid = res.grid;
+    if (grid > q) grid = q;
+    const size_t esz = idx64 ? 8 : 4;
+    const int vec_ok = ((((uintptr_t)rank) & 15) == 0) && ((ldr * esz) % 16 == 0);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(RR_THREADS), lds, s, pdist, ldp, q, n, rank, ldr, idx64, vec_ok, skew_flag);
+    SE_LAUNCH_CHECK();
+    return SE_OK;
+}
+
 // hw: hardware-ordered variant allowed (capability probe passed).  scratch: >= 256 bytes of caller workspace or NULL;
 // with scratch the skew detector picks between the plain and the group-peeling hardware-ordered kernels.
 template <int ITEMS>
@@ -906,6 +1226,19 @@ static int launch_rank_reg(const float *pdist, int64_t ldp, int64_t q, int n, vo
 {
     if (!hw) return launch_rank_reg_variant<ITEMS, false, false>(pdist, ldp, q, n, rank, idx64, ldr, nullptr, s);
     static const char *force = tuning_env("SE_RANK_PEEL");   // -DSE_TUNING build only: "0" / "1" pins the variant
+    static const bool gen1 = tuning_env("SE_RANK_GEN1") != nullptr;   // -DSE_TUNING build only: the first-generation (packed 16-bit counter) kernel
+    if (!gen1) {   // second generation: 32-bit counters aliased onto the exchange buffer, SDWA scatter addresses
+        if (force || !scratch) {
+            if (force && force[0] == '1') return launch_rank_hw32_variant<ITEMS, true>(pdist, ldp, q, n, rank, idx64, ldr, nullptr, s);
+            return launch_rank_hw32_variant<ITEMS, false>(pdist, ldp, q, n, rank, idx64, ldr, nullptr, s);
+        }
+        uint32_t *flag32 = (uint32_t *)scratch + 16;   // (words 0-1 belong to the capability probe)
+        hipLaunchKernelGGL(rank_skew_detect_kernel, dim3(1), dim3(256), 0, s, pdist, ldp, q, n, 21, flag32);   // most significant digit: bits 21-31
+        SE_LAUNCH_CHECK();
+        int rc32 = launch_rank_hw32_variant<ITEMS, false>(pdist, ldp, q, n, rank, idx64, ldr, flag32, s);
+        if (rc32 != SE_OK) return rc32;
+        return launch_rank_hw32_variant<ITEMS, true>(pdist, ldp, q, n, rank, idx64, ldr, flag32, s);
+    }
     if (force || !scratch) {
         if (force && force[0] == '1') return launch_rank_reg_variant<ITEMS, true, true>(pdist, ldp, q, n, rank, idx64, ldr, nullptr, s);
         return launch_rank_reg_variant<ITEMS, true, false>(pdist, ldp, q, n, rank, idx64, ldr, nullptr, s);
@@ -998,11 +1331,7 @@ extern "C" int se_rank_rows(const float *pdist, int64_t ldp, int64_t q, int64_t 
         const bool hw = rank_hw_order_ok(workspace, workspace_bytes, s) != 0;
         void *scratch = (workspace && workspace_bytes >= 256) ? workspace : nullptr;
 #define SE_RR_CASE(I) if (items <= I) return launch_rank_reg<I>(pdist, ldp, q, (int)n, rank, idx64, ldr, hw, scratch, s);
-#if SE_RR_THREADS == 512
         SE_RR_CASE(2) SE_RR_CASE(8) SE_RR_CASE(20) SE_RR_CASE(40) SE_RR_CASE(64) SE_RR_CASE(80) SE_RR_CASE(98) SE_RR_CASE(104)
-#else
-        SE_RR_CASE(2) SE_RR_CASE(6) SE_RR_CASE(14) SE_RR_CASE(28) SE_RR_CASE(44) SE_RR_CASE(56) SE_RR_CASE(66) SE_RR_CASE(70)
-#endif
 #undef SE_RR_CASE
     }
     const int64_t need = (int64_t)rank_grid(q) * 4 * rank_npad(n) * (int64_t)sizeof(uint32_t);

@@ -236,16 +236,11 @@ __global__ __launch_bounds__(RK_THREADS) void rank_rows_kernel(const float *__re
 //   * indices travel as 16 bits (N <= 65536 by construction) packed with the 16-bit destination;
 //   * after the last pass the exchange buffer IS the ranking: it is streamed to HBM with 16-byte
 //     stores.
-#ifndef SE_RR_THREADS
-#define SE_RR_THREADS 512   // 512 (8 waves, 2 per SIMD, <= 256 VGPRs) or 768 (12 waves, 3 per SIMD, <= 168 VGPRs)
-#endif
-constexpr int RR_THREADS = SE_RR_THREADS;
+constexpr int RR_THREADS = 512;
 constexpr int RR_WAVES = RR_THREADS / WAVE;
-constexpr int RR_SCAN_THREADS = 512;                  // threads that scan the packed counters (2 words each of the 1024 per wave)
-constexpr int RR_SCAN_WAVES = RR_SCAN_THREADS / WAVE;
-constexpr int RR_MAX_ITEMS = (53248 + RR_THREADS - 1) / RR_THREADS;   // 104 (512 threads) / 70 (768 threads)
+constexpr int RR_MAX_ITEMS = 104;
 constexpr int RR_G = 8;                               // steps ranked together (latency overlap vs live registers)
-constexpr int RR_MAX_N = 53248;
+constexpr int RR_MAX_N = RR_THREADS * RR_MAX_ITEMS;   // 53248
 
 // Wave multisplit on an 8-bit digit: bit mask of the lanes whose digit DIFFERS from this lane's, as
 // OR_b (ballot_b ^ own_bit_b): per bit one v_bfe_i32, one v_cmp (the ballot) and one v_bitop3 per mask half.
@@ -299,10 +294,7 @@ __device__ __forceinline__ void lds_ld16(uint32_t &dst, uint32_t addr) { asm vol
 template <int K>
 __device__ __forceinline__ void lds_wait_le(uint32_t &landed) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(landed) : "n"(K) : "memory"); }
 
-#ifndef SE_RR_RING
-#define SE_RR_RING 12
-#endif
-constexpr int RR_RING = SE_RR_RING;   // 16-bit loads in flight per lane (lgkmcnt counts to 15)
+constexpr int RR_RING = 12;   // 16-bit loads in flight per lane (lgkmcnt counts to 15)
 // Software-pipelined read of this lane's ITEMS new 16-bit values (read slot of step s = addr + 128 s)
 // into the HIGH (HI = true) or LOW half of a[s]: read i is issued RR_RING - 1 reads ahead of its merge.
 template <int ITEMS, bool HI, int I = 0>
@@ -321,6 +313,151 @@ struct RRRead {
         if constexpr (I + 1 < ITEMS + D) RRRead<ITEMS, HI, I + 1>::run(a, t, addr);
     }
 };
+
+typedef int rr_i32x4 __attribute__((ext_vector_type(4)));
+// ---- paired exchange slots (SE_RR_PAIR) ------------------------------------------------------------------------
+// The exchange slot of sorted position k = (wave w, step s, lane l) -- k = w ITEMS 64 + 64 s + l -- does not have to sit at byte
+// 2 k of the buffer: ANY bijection works as long as the scatter and the read-back agree.  With the low seven bits of k rotated
+// left by one ([j l5..l0] -> [l5..l0 j], j = s & 1) the two values a lane needs for steps 2g and 2g+1 are the two halves of ONE
+// dword, so the read-back is ITEMS / 2 ds_read_b32 (conflict-free, 128 B per clock) instead of ITEMS ds_read_u16.  The rotation is
+// applied once per key and pass to the destination (4 VALU, in the destination phase); the last pass keeps the plain mapping
+// because its buffer is the ranking that the write-out streams linearly.
+#ifndef SE_RR_PAIR
+#define SE_RR_PAIR 1
+#endif
+#ifndef SE_RR_EARLY
+#define SE_RR_EARLY 1   // next row's loads issued inside the last pass's index scatter (exec-masked, no C++ control flow around them)
+#endif
+#ifndef SE_RR_WOV
+#define SE_RR_WOV 1     // the write-out of row r is interleaved into the pass-0 rank phase of row r + 1
+#endif
+__device__ __forceinline__ uint32_t rr_pair_slot(uint32_t ir)   // low half: k -> rotated slot; high half (the index) untouched
+{
+    return (ir & ~0x7Fu) | ((ir << 1) & 0x7Eu) | ((ir >> 6) & 1u);
+}
+template <int OFF>
+__device__ __forceinline__ void lds_ld32(uint32_t &dst, uint32_t addr) { asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory"); }
+// Software-pipelined read of this lane's ITEMS new 16-bit values, two per dword (dword g = steps 2g, 2g+1; read slot = addr + 256 g),
+// into the HIGH (HI) or LOW half of a[]: read g is issued RR_RING - 1 reads ahead of its two merges.
+template <int ITEMS, bool HI, int G = 0>
+struct RRReadPair {
+    static __device__ __forceinline__ void run(uint32_t (&a)[ITEMS], uint32_t (&t)[RR_RING], uint32_t addr)
+    {
+        static_assert(ITEMS % 2 == 0, "paired slots need an even number of steps");
+        constexpr int NP = ITEMS / 2, D = RR_RING - 1;
+        if constexpr (G < NP) lds_ld32<G * 256>(t[G % RR_RING], addr);
+        if constexpr (G >= D) {
+            constexpr int J = G - D;
+            constexpr int newest = (G < NP ? G : NP - 1);
+            lds_wait_le<newest - J>(t[J % RR_RING]);
+            // low half of t -> step 2J, high half -> step 2J + 1
+            a[2 * J] = __builtin_amdgcn_perm(t[J % RR_RING], a[2 * J], HI ? 0x05040100u : 0x03020504u);
+            a[2 * J + 1] = __builtin_amdgcn_perm(t[J % RR_RING], a[2 * J + 1], HI ? 0x07060100u : 0x03020706u);
+        }
+        if constexpr (G + 1 < NP + D) RRReadPair<ITEMS, HI, G + 1>::run(a, t, addr);
+    }
+};
+
+// Two keys of the NEXT row, loaded straight into their registers when the wave-uniform flag `on` is set, skipped otherwise.  The exec mask
+// is switched INSIDE the statement: a C++ `if` around an asynchronous load would let hipcc copy the (not yet landed) registers at
+// the join.  vb = 4 * (position of step 0), A / B = 256 * step, lim = 4 (N - 1) clamps the padding positions onto the last column.
+// The two key registers are declared as INPUTS although the loads overwrite them: as outputs they would be re-definitions inside the
+// pass loop, and hipcc then moves all of them through scratch at the loop exit -- while the loads are still in flight.  What makes
+// this sound: the old values are dead (last pass, behind its destination phase -- the only pass in which the flag is set), nothing
+// reads the registers before the `s_waitcnt vmcnt(0)` behind the loop, and every key register is re-defined for the compiler there
+// by an (empty) volatile statement before its first use.  The build is checked for scratch traffic (tests/test_abi.py).
+template <int A, int B>
+__device__ __forceinline__ void rr_gload2(uint32_t &ka, uint32_t &kb, const float *row, uint32_t vb, uint32_t lim, uint32_t on)
+{
+    uint64_t saved, m;
+    uint32_t t0, t1;
+    asm volatile("s_cmp_lg_u32 %[on], 0\n\t"
+                 "s_cselect_b64 %[m], -1, 0\n\t"
+                 "s_and_saveexec_b64 %[sv], %[m]\n\t"
+                 "s_cbranch_execz 1f\n\t"
+                 "v_add_u32 %[t0], %[ca], %[vb]\n\t"
+                 "v_add_u32 %[t1], %[cb], %[vb]\n\t"
+                 "v_min_u32 %[t0], %[t0], %[lim]\n\t"
+                 "v_min_u32 %[t1], %[t1], %[lim]\n\t"
+                 "global_load_dword %[ka], %[t0], %[base]\n\t"
+                 "global_load_dword %[kb], %[t1], %[base]\n"
+                 "1:\n\t"
+                 "s_mov_b64 exec, %[sv]"
+                 : [sv] "=&s"(saved), [m] "=&s"(m), [t0] "=&v"(t0), [t1] "=&v"(t1)
+                 : [ka] "v"(ka), [kb] "v"(kb), [on] "s"(on), [vb] "v"(vb), [lim] "v"(lim), [base] "s"(row), [ca] "n"(A), [cb] "n"(B)
+                 : "memory", "scc");
+}
+
+// Index scatter of a pass (two steps per level) with the next row's loads riding along (template recursion: every step index must be
+// a compile-time constant -- the offsets are instruction literals, and a dynamically indexed register array would go to scratch).
+template <int ITEMS, int S = 0>
+struct RRScatterLoad {
+    static __device__ __forceinline__ void run(uint32_t (&ir)[ITEMS], uint32_t (&key)[ITEMS], uint32_t xb, const float *nrow, uint32_t vb,
+                                               uint32_t lim, uint32_t on)
+    {
+        opaque(ir[S]);
+        lds_st16_hi(xb + ((ir[S] & 0xFFFFu) << 1), ir[S]);
+        opaque(ir[S + 1]);
+        lds_st16_hi(xb + ((ir[S + 1] & 0xFFFFu) << 1), ir[S + 1]);
+        rr_gload2<S * 256, (S + 1) * 256>(key[S], key[S + 1], nrow, vb, lim, on);
+        if constexpr (S + 2 < ITEMS) RRScatterLoad<ITEMS, S + 2>::run(ir, key, xb, nrow, vb, lim, on);
+    }
+};
+
+// ---- write-out of the PREVIOUS row's ranking inside the pass-0 rank phase of the current row (SE_RR_WOV) ----------------------
+// After the last pass the exchange buffer holds the ranking (16-bit indices) and nothing writes the buffer again before the index
+// scatter of the next row's pass 0 -- which only starts behind the barrier that closes that pass's rank phase.  The rank phase is
+// bound by LDS atomics and leaves the vector-memory pipe idle, so the 16-byte rank stores (and their linear ds_read_b64) ride
+// along: one piece of 4 ranks per lane every fourth step.  Only the common case is interleaved (int32 ranks, 16-byte aligned rows).
+struct RRWout {
+    uint32_t flag;      // the same as a scalar 0 / 1 (the LDS reads switch their exec mask on it)
+    int32_t *o;         // previous row's output
+    uint32_t xb;        // byte address of the exchange buffer
+    int e0;             // 4 * tid
+    int n;              // row length
+    int last;           // last readable element group start (clamp for the unconditional reads)
+};
+__device__ __forceinline__ void rr_wout_read(uint64_t &nv, const RRWout &w, int j)
+{
+    int e0 = w.e0;
+    opaque(e0);         // recomputed at every slot: hipcc would otherwise hoist all ~26 row-invariant offsets out of the row loop and keep them live
+    int e = e0 + j * (RR_THREADS * 4);
+    e = e < w.last ? e : w.last;
+    const uint32_t addr = w.xb + 2u * (uint32_t)e;
+    uint64_t saved, m;
+    asm volatile("s_cmp_lg_u32 %[on], 0\n\ts_cselect_b64 %[m], -1, 0\n\ts_and_saveexec_b64 %[sv], %[m]\n\tds_read_b64 %[d], %[a]\n\ts_mov_b64 exec, %[sv]"
+                 : [sv] "=&s"(saved), [m] "=&s"(m), [d] "+v"(nv)
+                 : [on] "s"(w.flag), [a] "v"(addr)
+                 : "memory", "scc");
+}
+// wait until at most K DS operations are outstanding -- only when the write-out is riding along (no C++ control flow: see rr_gload2)
+template <int K>
+__device__ __forceinline__ void rr_wout_wait(uint64_t &landed, const RRWout &w)
+{
+    asm volatile("s_cmp_lg_u32 %[on], 0\n\ts_cbranch_scc0 1f\n\ts_waitcnt lgkmcnt(%[k])\n1:" : "+v"(landed) : [on] "s"(w.flag), [k] "n"(K) : "memory", "scc");
+}
+// 4 ranks (16-bit indices in `nv`) -> one 16-byte store at element e0 + 2048 j of the previous row; lanes beyond the row and waves
+// without a deferred row are masked out inside the statement.  (Rows whose length is not a multiple of 4 are never deferred.)
+__device__ __forceinline__ void rr_wout_store(uint64_t nv, const RRWout &w, int j)
+{
+    int e0 = w.e0;
+    opaque(e0);
+    const uint32_t e = (uint32_t)(e0 + j * (RR_THREADS * 4));
+    const uint32_t lo = (uint32_t)nv, hi = (uint32_t)(nv >> 32);
+    const rr_i32x4 v = {(int)(lo & 0xFFFFu), (int)(lo >> 16), (int)(hi & 0xFFFFu), (int)(hi >> 16)};
+    const uint32_t off = e * 4u;
+    uint64_t saved, m;
+    asm volatile("s_cmp_lg_u32 %[on], 0\n\t"
+                 "s_cselect_b64 %[m], -1, 0\n\t"
+                 "v_cmp_gt_u32 vcc, %[n], %[e]\n\t"
+                 "s_and_b64 %[m], %[m], vcc\n\t"
+                 "s_and_saveexec_b64 %[sv], %[m]\n\t"
+                 "global_store_dwordx4 %[off], %[v], %[base]\n\t"
+                 "s_mov_b64 exec, %[sv]"
+                 : [sv] "=&s"(saved), [m] "=&s"(m)
+                 : [on] "s"(w.flag), [n] "s"((uint32_t)w.n), [e] "v"(e), [off] "v"(off), [v] "v"(v), [base] "s"(w.o)
+                 : "memory", "scc", "vcc");
+}
 
 // ---- R phase, one group of V <= RR_G consecutive steps starting at step S0 -------------------------------
 // Per step: every lane READS its digit's counter (equal digits: one broadcast read), then the first lane of
@@ -379,7 +516,6 @@ struct RRRank {
 #ifndef SE_RR_NT
 #define SE_RR_NT 0   // 1: nontemporal rank stores (build-time tuning aid)
 #endif
-typedef int rr_i32x4 __attribute__((ext_vector_type(4)));
 typedef long long rr_i64x2 __attribute__((ext_vector_type(2)));
 #ifndef SE_RR_PF
 #define SE_RR_PF 1
@@ -408,7 +544,7 @@ struct RRRankHW {
     // `peel` is wave-uniform (one code instance for all passes: two instances of this unrolled body make hipcc spill)
     static __device__ __forceinline__ void run(uint32_t (&ir)[ITEMS], uint32_t (&key)[ITEMS], uint32_t (&r)[RR_GH], uint32_t (&sh)[RR_GH],
                                                uint32_t (&grp)[RR_GH], uint32_t shift, uint32_t hshift, uint32_t wlo, uint32_t whi, uint32_t cb,
-                                               int lane, bool peel)
+                                               int lane, bool peel, uint64_t &nv, const RRWout &wo)
     {
         constexpr int SLOT = S % RR_GH;
         uint32_t ca = 0, inc = 0, shv = 0, g = 0xFFFFFFFFu;
@@ -469,14 +605,26 @@ struct RRRankHW {
                 asm volatile("ds_add_rtn_u32 %0, %1, %2" : "=v"(r[SLOT]) : "v"(ca), "v"(inc) : "memory");
             }
         }
+        if constexpr (SE_RR_WOV && (ITEMS <= 98) && (S % 4 == 2)) {
+            // write-out slot JW (see RRWout): store the piece read four steps ago, read the next one.  The returning adds retire with
+            // waits that count only the adds issued behind them: with these reads in flight too they wait a little longer, never less.
+            constexpr int JW = S / 4;
+            if constexpr (JW > 0) {
+                constexpr int lastadd = (S < ITEMS ? S : ITEMS - 1);
+                constexpr int younger = (lastadd - (S - 4) > 0) ? lastadd - (S - 4) : 0;   // adds of steps S-3 .. S issued behind that read
+                rr_wout_wait<younger>(nv, wo);
+                rr_wout_store(nv, wo, JW - 1);
+            }
+            rr_wout_read(nv, wo, JW);
+        }
         // the scheduling fence keeps hipcc from hoisting the address arithmetic of all ITEMS steps (live registers -> spills)
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (S + 1 < ITEMS + RR_GH) RRRankHW<ITEMS, PEEL, S + 1>::run(ir, key, r, sh, grp, shift, hshift, wlo, whi, cb, lane, peel);
+        if constexpr (S + 1 < ITEMS + RR_GH) RRRankHW<ITEMS, PEEL, S + 1>::run(ir, key, r, sh, grp, shift, hshift, wlo, whi, cb, lane, peel, nv, wo);
     }
 };
 
 template <int ITEMS, bool PROF, bool HWORD, bool PEEL>
-__global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_kernel(const float *__restrict__ pdist, int64_t ldp, int64_t Q,
+__global__ __launch_bounds__(RR_THREADS, 2) void rank_rows_reg_kernel(const float *__restrict__ pdist, int64_t ldp, int64_t Q,
                                                                     int N, void *rank, int64_t ldr, int idx64, int vec_ok,
                                                                     unsigned long long *prof, const uint32_t *skew_flag)
 {
@@ -495,11 +643,17 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
     constexpr bool WIDE = HWORD && ((size_t)RR_THREADS * ITEMS * sizeof(uint16_t) >= (size_t)RR_WAVES * RR_WIDE_WORDS * sizeof(uint32_t));
     uint32_t *wcnt = reinterpret_cast<uint32_t *>(rr_raw);              // [RR_WAVES][CNT_WORDS]
     uint32_t *wave_tot = wcnt + RR_WAVES * CNT_WORDS;                   // [8] (+pad)
-    uint16_t *xbuf = reinterpret_cast<uint16_t *>(wave_tot + 32);       // [RR_THREADS * ITEMS]
+    uint16_t *xbuf = reinterpret_cast<uint16_t *>(wave_tot + 16);       // [RR_THREADS * ITEMS]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wpos0 = wave * (ITEMS * WAVE) + lane;                     // position of (step s) = wpos0 + 64 s
     const uint32_t xb = lds_off(xbuf);                                  // exchange buffer, byte address
     const uint32_t rb = xb + 2u * (uint32_t)wpos0;                      // this lane's read slot of step 0
+    // new structure of the hardware-ordered build (the ballot build keeps the round-1 flow): paired exchange slots, next-row
+    // loads inside the last index scatter, write-out inside the next row's first rank phase
+    constexpr bool PAIR = HWORD && SE_RR_PAIR && (ITEMS % 2 == 0);
+    constexpr bool EARLY = HWORD && SE_RR_EARLY && (ITEMS % 2 == 0);
+    constexpr bool WOV = HWORD && SE_RR_WOV && (ITEMS <= 98);   // (the 104-key build has no registers to spare for it)
+    const uint32_t rbp = xb + 2u * (uint32_t)(wave * (ITEMS * WAVE)) + 4u * (uint32_t)lane;   // paired slots: dword of steps 0 / 1
 #define RR_DST(IR) (xb + (((IR) & 0xFFFFu) << 1))
     // tuning aid (SE_RR_PROFILE=1): shader-clock cycles per phase, summed over every workgroup's wave 0
     uint64_t t_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_pp[24] = {}, t_last = PROF ? __builtin_amdgcn_s_memtime() : 0;
@@ -530,7 +684,7 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
         }                                                                                                             \
     }
 #define RR_PREFETCH_NEXT_ROW() \
-    if (p == NPASS - 1 && more) { \
+    if (!EARLY && p == NPASS - 1 && more) { \
                 const char *nrow = (const char *)(pdist + (row + gridDim.x) * ldp); \
                 const uint32_t row_bytes = (uint32_t)N * 4u; \
                 for (uint32_t off = (uint32_t)tid * 128u; off < row_bytes; off += RR_THREADS * 128u) \
@@ -546,6 +700,12 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
     }
     uint32_t pf_sink = 0;
     [[maybe_unused]] int rr_pass = -1;   // profile build: pass index for the per-pass phase times
+    // deferred write-out (WOV): the previous row's ranking is still in the exchange buffer
+    [[maybe_unused]] uint64_t wo_nv = 0;
+    RRWout wo;
+    wo.flag = 0; wo.o = nullptr; wo.xb = xb; wo.e0 = tid * 4; wo.n = N;
+    wo.last = RR_THREADS * ITEMS - 4;
+    const bool wov_ok = WOV && !PROF && !idx64 && vec_ok && (N % 4 == 0);   // interleaved write-out: int32 ranks, 16-byte aligned rows
     for (int64_t row = blockIdx.x; row < Q; row += gridDim.x) {
         const bool more = row + gridDim.x < Q;
         {
@@ -581,7 +741,15 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
             [[maybe_unused]] const uint32_t wlo = wide ? 11u : 10u, whi = (uint32_t)(end - shift) - wlo, hshift = (uint32_t)(shift + (int)wlo) & 31u;
             if constexpr (HWORD) {
                 uint32_t hr[RR_GH], hs[RR_GH], hg[RR_GH];
-                RRRankHW<ITEMS, PEEL>::run(ir, key, hr, hs, hg, (uint32_t)shift, hshift, wlo, whi, cb, lane, p == NPASS - 1);
+                RRWout wcur = wo;                      // the deferred write-out rides along in pass 0 only (no exchange write before its barrier)
+                if (p != 0) wcur.flag = 0;
+                wcur.flag = (uint32_t)__builtin_amdgcn_readfirstlane((int)wcur.flag);
+                RRRankHW<ITEMS, PEEL>::run(ir, key, hr, hs, hg, (uint32_t)shift, hshift, wlo, whi, cb, lane, p == NPASS - 1, wo_nv, wcur);
+                lds_wait();
+                if constexpr (WOV) {
+                    constexpr int SMAX = ((ITEMS + RR_GH - 1 - 2) / 4) * 4 + 2;   // last step with a write-out slot
+                    rr_wout_store(wo_nv, wcur, SMAX / 4);
+                }
             }
             else RRRank<ITEMS>::run(ir, key, shift, lane, cb);
             lds_wait();
@@ -613,19 +781,17 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
                 // 8 waves x pcw words of 16-bit counts, two per word (low half: digit w, high half: digit pcw + w).  Thread t owns the
                 // words 2t and 2t+1 of every wave (one 8-byte LDS access each; the 12-bit pass: also 1024 + 2t and 1025 + 2t) and all
                 // arithmetic stays PACKED: a half never exceeds the 53,248 keys of a row, so the low halves cannot carry into the high ones.
-                const bool scanner = tid < RR_SCAN_THREADS;   // (with 768 threads the last 4 waves only take part in the barriers)
-                const int st = scanner ? tid : 0;
                 uint32_t T0 = 0, T1 = 0, U0 = 0, U1 = 0;   // per-word totals over the waves (U: second word group of the wide pass)
 #pragma unroll
                 for (int w = 0; w < RR_WAVES; w++) {
-                    const uint2 v = *reinterpret_cast<const uint2 *>(pcnt + w * pcw + 2 * st);
+                    const uint2 v = *reinterpret_cast<const uint2 *>(pcnt + w * pcw + 2 * tid);
                     T0 += v.x; T1 += v.y;
                 }
                 if (wide) {
                     __builtin_amdgcn_sched_barrier(0);   // one word group at a time: 2 x ITEMS registers are live across the scan
 #pragma unroll
                     for (int w = 0; w < RR_WAVES; w++) {
-                        const uint2 v = *reinterpret_cast<const uint2 *>(pcnt + w * pcw + CNT_WORDS + 2 * st);
+                        const uint2 v = *reinterpret_cast<const uint2 *>(pcnt + w * pcw + CNT_WORDS + 2 * tid);
                         U0 += v.x; U1 += v.y;
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -633,12 +799,12 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
                 uint32_t wtot, wtot2 = 0, ex2 = 0;
                 uint32_t ex = wave_excl_scan(T0 + T1, wtot);   // both halves scanned at once
                 if (wide) ex2 = wave_excl_scan(U0 + U1, wtot2);
-                if (scanner && lane == 63) { wave_tot[wave] = wtot; wave_tot[RR_SCAN_WAVES + wave] = wtot2; }
+                if (lane == 63) { wave_tot[wave] = wtot; wave_tot[RR_WAVES + wave] = wtot2; }
                 __syncthreads();
                 uint32_t all = 0, all2 = 0;
 #pragma unroll
-                for (int w = 0; w < RR_SCAN_WAVES; w++) {
-                    const uint32_t wt = wave_tot[w], wt2 = wave_tot[RR_SCAN_WAVES + w];
+                for (int w = 0; w < RR_WAVES; w++) {
+                    const uint32_t wt = wave_tot[w], wt2 = wave_tot[RR_WAVES + w];
                     all += wt; all2 += wt2;
                     ex += (w < wave) ? wt : 0u;
                     ex2 += (w < wave) ? wt2 : 0u;
@@ -647,7 +813,6 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
                 const uint32_t hi = (all + all2) << 16;   // the high-half digits follow ALL low-half digits
                 ex += hi; ex2 += hi;
                 // digit-major / wave-minor: counts -> first destination of (wave, digit), written back in place
-                if (scanner) {
                 uint32_t s0 = ex, s1 = ex + T0;
 #pragma unroll
                 for (int w = 0; w < RR_WAVES; w++) {
@@ -666,7 +831,6 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
                         *wp = make_uint2(s0, s1);
                         s0 += v.x; s1 += v.y;
                     }
-                }
                 }
             }
             __syncthreads();
@@ -689,6 +853,9 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
                 for (int g = 0; g < 8; g++)
                     if (s0 + g < ITEMS) {
                         ir[s0 + g] += first[g];   // low half: rank -> destination (< 65536)
+                        if constexpr (PAIR) {
+                            if (end < 32) ir[s0 + g] = rr_pair_slot(ir[s0 + g]);   // exchanges that are read back use the paired slots
+                        }
                         opaque(ir[s0 + g]);
                     }
                 __builtin_amdgcn_sched_barrier(0);
@@ -696,13 +863,28 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
             if (SE_RR_PF == 2) { RR_PREFETCH_NEXT_ROW() }
             if (wide) __syncthreads();   // the scatter below overwrites the (aliased) counters other waves may still be looking up
             RR_T(3)
+            if constexpr (EARLY) {
+                // last pass: the key registers are dead from here on -> the NEXT row is loaded into them while the indices are scattered
+                // (exec-masked statements: nothing happens in the other passes or behind the workgroup's last row)
+                const uint32_t ldmask = (uint32_t)__builtin_amdgcn_readfirstlane((end >= 32 && more) ? 1 : 0);
+                const float *nrow = pdist + (more ? row + gridDim.x : row) * ldp;
+                uint32_t vb = 4u * (uint32_t)wpos0, lim = 4u * (uint32_t)(N - 1);
+                opaque(vb);
+                opaque(lim);
+                RRScatterLoad<ITEMS>::run(ir, key, xb, nrow, vb, lim, ldmask);
+            } else {
 #pragma unroll
-            for (int s = 0; s < ITEMS; s++) { opaque(ir[s]); lds_st16_hi(RR_DST(ir[s]), ir[s]); }           // index
+                for (int s = 0; s < ITEMS; s++) { opaque(ir[s]); lds_st16_hi(RR_DST(ir[s]), ir[s]); }           // index
+            }
             lds_wait();
             __syncthreads();
             RR_T(4)
-            if (end >= 32) break;   // last pass: the index buffer is the ranking
-            RRRead<ITEMS, true>::run(ir, ring, rb);
+            // last pass: the index buffer is the ranking.  (EARLY: an `if` instead of a `break` -- with the next row's keys live across
+            // a mid-body loop exit hipcc moves all of them through scratch there)
+            if (end >= 32) { if constexpr (!EARLY) break; }
+            if (!EARLY || end < 32) {
+            if constexpr (PAIR) RRReadPair<ITEMS, true>::run(ir, ring, rbp);
+            else RRRead<ITEMS, true>::run(ir, ring, rb);
             lds_wait();
             __syncthreads();
             RR_T(5)
@@ -710,7 +892,8 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
             for (int s = 0; s < ITEMS; s++) { opaque(ir[s]); lds_st16_hi(RR_DST(ir[s]), key[s]); }          // key bits 16-31  (opaque: no cached addresses)
             lds_wait();
             __syncthreads();
-            RRRead<ITEMS, true>::run(key, ring, rb);
+            if constexpr (PAIR) RRReadPair<ITEMS, true>::run(key, ring, rbp);
+            else RRRead<ITEMS, true>::run(key, ring, rb);
             lds_wait();
             if (end < 16) {                                                              // key bits 0-15: still needed by a later pass
                 __syncthreads();
@@ -718,10 +901,12 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
                 for (int s = 0; s < ITEMS; s++) { opaque(ir[s]); lds_st16_lo(RR_DST(ir[s]), key[s]); }      // (low half is still the old key's)
                 lds_wait();
                 __syncthreads();
-                RRRead<ITEMS, false>::run(key, ring, rb);
+                if constexpr (PAIR) RRReadPair<ITEMS, false>::run(key, ring, rbp);
+                else RRRead<ITEMS, false>::run(key, ring, rb);
                 lds_wait();
             }
             RR_T(6)
+            }
             // (the next pass's barriers order these reads before its first exchange write)
         }
 #undef RR_DST
@@ -731,16 +916,22 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
         // hipcc copy all ITEMS index registers there, and a separate straight-line instance of the last pass -- measured, DESIGN.md 5.2 --
         // pushes the 98-key build into scratch; the row was prefetched into L2 during the last pass.  They are issued BEFORE the rank
         // stores and waited for after them: the memory pipeline serves them first and the write-out covers most of their latency.)
-        {
+        if constexpr (!EARLY) {
             const float *drow = pdist + (more ? row + gridDim.x : row) * ldp;
             int wpos = wpos0;
             opaque(wpos);   // per-row opaque: otherwise hipcc hoists ITEMS row-invariant clamps out of the row loop and keeps them live
 #pragma unroll
             for (int s = 0; s < ITEMS; s++) RR_LOAD_ONE(drow, wpos, s)
         }
+        // WOV: with a next row to sort, this row's ranking stays in the exchange buffer and is streamed out inside that row's first rank
+        // phase (wov_ok: int32 ranks, aligned rows); otherwise -- last row of the workgroup, int64 ranks, odd alignment -- right here
+        const bool defer = wov_ok && more;
+        wo.flag = defer ? 1u : 0u;
+        wo.o = (int32_t *)rank + row * ldr;
         int wt = tid;
         opaque(wt);   // per-row opaque: the write-out offsets are recomputed here instead of living (spilled) across the whole row loop
-        if (idx64) {
+        if (defer) {
+        } else if (idx64) {
             int64_t *o = (int64_t *)rank + row * ldr;
             // (the next row's keys are live: no unrolling, the LDS read of the next step is issued before this step's stores instead)
             uint2 nv = *reinterpret_cast<const uint2 *>(xbuf + (wt * 4 < N ? wt * 4 : 0));
@@ -784,6 +975,12 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
             }
         }
         RR_T(7)
+        if constexpr (EARLY) {
+            // the next row's keys were loaded by exec-masked statements hipcc knows nothing about: wait for them explicitly, then make
+            // every key register pass through an (empty) volatile statement so that no use can be scheduled above the wait
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            _Pragma("unroll") for (int s = 0; s < ITEMS; s++) opaque(key[s]);
+        }
         RR_CANON()
         if constexpr (PROF) {   // keep the canonicalisation (and with it the wait for the loads) inside the 'load' interval of the phase profile
             _Pragma("unroll") for (int s = 0; s < ITEMS; s++) opaque(key[s]);
@@ -852,7 +1049,7 @@ static int launch_rank_reg_variant(const float *pdist, int64_t ldp, int64_t q, i
                                    const uint32_t *skew_flag, hipStream_t s)
 {
     const size_t cnt_words = HW ? (size_t)(1 << RR_HW_BITS) / 2 : (size_t)RK_NB;   // per wave (packed 16-bit vs 32-bit counters)
-    const size_t lds = (RR_WAVES * cnt_words + 32) * sizeof(uint32_t) + (size_t)RR_THREADS * ITEMS * sizeof(uint16_t);
+    const size_t lds = (RR_WAVES * cnt_words + 16) * sizeof(uint32_t) + (size_t)RR_THREADS * ITEMS * sizeof(uint16_t);
     static const bool profile = tuning_env("SE_RR_PROFILE") != nullptr;   // -DSE_TUNING build only: allocates, synchronises, prints
     auto kern = (kTuning && profile) ? rank_rows_reg_kernel<ITEMS, kTuning && (ITEMS == 98), HW, PEEL> : rank_rows_reg_kernel<ITEMS, false, HW, PEEL>;
     // per instantiation, computed once (thread-safe static initialisation): resident workgroups = CUs x occupancy
@@ -998,11 +1195,7 @@ extern "C" int se_rank_rows(const float *pdist, int64_t ldp, int64_t q, int64_t 
         const bool hw = rank_hw_order_ok(workspace, workspace_bytes, s) != 0;
         void *scratch = (workspace && workspace_bytes >= 256) ? workspace : nullptr;
 #define SE_RR_CASE(I) if (items <= I) return launch_rank_reg<I>(pdist, ldp, q, (int)n, rank, idx64, ldr, hw, scratch, s);
-#if SE_RR_THREADS == 512
         SE_RR_CASE(2) SE_RR_CASE(8) SE_RR_CASE(20) SE_RR_CASE(40) SE_RR_CASE(64) SE_RR_CASE(80) SE_RR_CASE(98) SE_RR_CASE(104)
-#else
-        SE_RR_CASE(2) SE_RR_CASE(6) SE_RR_CASE(14) SE_RR_CASE(28) SE_RR_CASE(44) SE_RR_CASE(56) SE_RR_CASE(66) SE_RR_CASE(70)
-#endif
 #undef SE_RR_CASE
     }
     const int64_t need = (int64_t)rank_grid(q) * 4 * rank_npad(n) * (int64_t)sizeof(uint32_t);
