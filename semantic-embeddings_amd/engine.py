@@ -286,16 +286,30 @@ class Trainer(object):
             with torch.cuda.graph(gb, **mode):
                 self.apply_update(1.0 / self.world if hooks_were else 1.0, lr_tensor=self._lr_t, count=False)
             if validate:
+                # The yardstick is the eager step's OWN run-to-run spread on this batch: MIOpen's kernels are not bit-reproducible, and a
+                # deep randomly initialised network amplifies their rounding noise (measured, tools/grad_noise_probe.py: two eager
+                # backward passes of the bf16 ResNet-50 differ by 0.7 relative L2 in every layer, 7e-3 in fp32; the CIFAR ResNets 1e-5 /
+                # 1e-3).  A replay must be as close to an eager gradient as a second eager gradient is, have the same norm and loss.
                 self._eager_core(self._sX, sy, {})
                 ref = self.flat.flat_g.clone()
+                eager_logs = {}
+                self._eager_core(self._sX, sy, eager_logs)
                 ref_norm = float(torch.linalg.vector_norm(ref))
+                noise = float(torch.linalg.vector_norm(self.flat.flat_g - ref)) / max(ref_norm, 1e-30)
+                eager_loss = float(eager_logs.get('loss', self._g_loss))
+                self.graph_validation = {'eager_noise': noise, 'replay_error': []}
                 for r in range(validate):
                     ga.replay()
                     g = self.flat.flat_g
                     err = float(torch.linalg.vector_norm(g - ref)) / max(ref_norm, 1e-30)
-                    if not (err < tol) or not bool(torch.isfinite(self._g_loss)):      # NaN compares False
-                        raise RuntimeError('replay %d of the captured step does not reproduce the eager gradient '
-                                           '(relative L2 error %g, loss %g)' % (r, err, float(self._g_loss)))
+                    ratio = float(torch.linalg.vector_norm(g)) / max(ref_norm, 1e-30)
+                    self.graph_validation['replay_error'].append(err)
+                    ok = (err < max(tol, 2.0 * noise)) and (abs(ratio - 1.0) < max(0.05, noise)) and bool(torch.isfinite(g).all()) \
+                        and bool(torch.isfinite(self._g_loss)) and abs(float(self._g_loss) - eager_loss) < 0.05 * max(1.0, abs(eager_loss))
+                    if not ok:      # (NaN compares False)
+                        raise RuntimeError('replay %d of the captured step does not reproduce the eager gradient (relative L2 error %g '
+                                           'vs %g between two eager steps, norm ratio %g, loss %g vs %g)'
+                                           % (r, err, noise, ratio, float(self._g_loss), eager_loss))
             restore()
             graphs, why = (ga, gb), None
         except Exception as e:
