@@ -445,3 +445,47 @@ def test_sharded_gallery_topk_two_processes_real_kernels(tmp_path):
     qs = ro.canon_normalize_rows(g["queries"])
     wd, wi = ro.canon_topk_rows(ro.canon_pdist(qs, gal, ro.METRIC_COSINE), 251)
     assert np.array_equal(g["i"], wi) and np.array_equal(g["d"], wd)
+
+
+@pytest.mark.parametrize("arch,loss", [("resnet-32", "inv_corr"), ("resnet-110-fc", "softmax_corr")])
+def test_learn_image_embeddings_cli_with_classifier_head(tmp_path, arch, loss):
+    """--cls_weight > 0 (reference cls_model, learn_image_embeddings.py:16-45,127-135): the classifier branch sits on the model that
+    already ends in the l2norm (softmax) layer, also for architectures without a final Dense layer (resnet-32 emits its 64 pooled
+    features); both outputs are trained, logged under the reference's output names and the dumped features are the
+    normalised ones."""
+    import json
+    import learn_image_embeddings as lie
+    dim = 64 if arch == "resnet-32" else 100
+    rng = np.random.default_rng(0)
+    E = rng.standard_normal((100, dim))
+    E /= np.linalg.norm(E, axis=1, keepdims=True)
+    emb = str(tmp_path / "emb.pickle")
+    with open(emb, "wb") as f:
+        pickle.dump({"embedding": E, "ind2label": list(range(100)), "label2ind": {i: i for i in range(100)}}, f)
+    feat, logd = str(tmp_path / "feat.pickle"), str(tmp_path / "log")
+    final = lie.main(["--dataset", "synthetic:100x32x96x32", "--data_root", "-", "--embedding", emb, "--architecture", arch,
+                      "--loss", loss, "--cls_weight", "0.1", "--lr_schedule", "SGD", "--sgd_lr", "0.05", "--epochs", "1",
+                      "--batch_size", "32", "--val_batch_size", "32", "--feature_dump", feat, "--log_dir", logd, "--no_progress"])
+    head = "l2norm" if loss == "inv_corr" else "softmax"
+    assert np.isfinite(final["loss"]) and np.isfinite(final[head + "_loss"]) and np.isfinite(final["prob_loss"]), final
+    assert 0.0 <= final["prob_acc"] <= 1.0
+    with open(feat, "rb") as f:
+        feats = np.stack(list(pickle.load(f)["feat"].values()))
+    assert feats.shape == (32, dim)
+    if loss == "inv_corr":
+        assert np.allclose(np.linalg.norm(feats, axis=-1), 1.0, atol=1e-4)
+    else:
+        assert np.allclose(feats.sum(axis=-1), 1.0, atol=1e-4) and feats.min() >= 0
+
+
+def test_cls_model_base_is_the_normalised_output():
+    import utils
+    import learn_image_embeddings as lie
+    torch.manual_seed(0)
+    net = utils.build_network(16, "resnet-32", input_channels=3).cuda()        # no Dense head: 64 pooled features
+    m = lie.ClsModel(net, 10, head="l2norm", width=64).cuda().eval()
+    x = torch.randn(4, 3, 32, 32, device="cuda")
+    base, logits = m(x)
+    raw = net(x).float()
+    assert torch.allclose(base, raw / raw.norm(dim=-1, keepdim=True), atol=1e-6) and logits.shape == (4, 10)
+    assert torch.allclose(logits, m.prob(m.bn(torch.relu(base))), atol=1e-6)
