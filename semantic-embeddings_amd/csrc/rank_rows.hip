@@ -243,7 +243,7 @@ constexpr int RR_THREADS = SE_RR_THREADS;
 constexpr int RR_WAVES = RR_THREADS / WAVE;
 constexpr int RR_SCAN_THREADS = 512;                  // threads that scan the packed counters (2 words each of the 1024 per wave)
 constexpr int RR_SCAN_WAVES = RR_SCAN_THREADS / WAVE;
-constexpr int RR_MAX_ITEMS = (53248 + RR_THREADS - 1) / RR_THREADS;   // 104 (512 threads) / 70 (768 threads)
+static_assert((53248 + RR_THREADS - 1) / RR_THREADS <= 104, "rows of up to 53,248 columns: 104 keys per thread (512 threads) / 70 (768 threads)");
 constexpr int RR_G = 8;                               // steps ranked together (latency overlap vs live registers)
 constexpr int RR_MAX_N = 53248;
 
@@ -923,7 +923,8 @@ static int launch_rank_reg(const float *pdist, int64_t ldp, int64_t q, int n, vo
 // ---- capability probe for the hardware-ordered ranking --------------------------------------------------
 // Every wave of 64 workgroups issues returning LDS adds under four conflict patterns (one address, 4, 16,
 // 256 addresses) while its 7 sibling waves do the same, and compares each returned value with the stable rank
-// computed by the ballot multisplit.  res[0] = mismatches, res[1] = waves that reported.
+// computed by the ballot multisplit -- first with 32-bit counters and one add at a time, then the way the production kernel
+// uses them: packed 16-bit halves of a shared word and eight adds in flight per lane.  res[0] = mismatches, res[1] = waves that reported.
 constexpr int RR_PROBE_BLOCKS = 64, RR_PROBE_STEPS = 48;
 __global__ __launch_bounds__(RR_THREADS) void rank_order_probe_kernel(uint32_t *res)
 {
@@ -947,6 +948,41 @@ __global__ __launch_bounds__(RR_THREADS) void rank_order_probe_kernel(uint32_t *
         const uint32_t want = ref[wave][d] + rnk;
         if (rnk == 0) ref[wave][d] += 64u - (uint32_t)(__popc(dlo) + __popc(dhi));   // one lane per digit group
         bad += (got != want);
+    }
+    // ---- the same property under PRODUCTION conditions: packed 16-bit counter halves (increment 1 or 1 << 16 on the shared word),
+    // eight returning adds in flight per lane before the first result is looked at, all eight waves hammering their tables ----
+    __syncthreads();
+    for (int i = lane; i < RK_NB; i += WAVE) { cnt[wave][i] = 0; ref[wave][i] = 0; }   // ref: low half = expected count of (word, half 0), high half = of half 1
+    __syncthreads();
+    for (int batch = 0; batch < 6; batch++) {
+        uint32_t got[8], dw[8], dh[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            seed = seed * 1664525u + 1013904223u;
+            const uint32_t rnd = seed >> 23;
+            dw[j] = mode == 0 ? 7u : mode == 1 ? (rnd & 3u) : mode == 2 ? (rnd & 15u) * 16u : (rnd & 255u);
+            dh[j] = (rnd >> 8) & 1u;
+            const uint32_t ca = cb + (dw[j] << 2), inc = dh[j] ? 0x10000u : 1u;
+            asm volatile("ds_add_rtn_u32 %0, %1, %2" : "=v"(got[j]) : "v"(ca), "v"(inc) : "memory");   // no wait: 8 in flight
+        }
+        lds_wait_le<0>(got[0]);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            opaque(got[j]);
+            uint32_t dlo, dhi;
+            differ_mask(dw[j], dlo, dhi);
+            const uint64_t hb = __ballot(dh[j] != 0);
+            const uint64_t hdiff = dh[j] ? ~hb : hb;                                  // lanes whose half differs from mine
+            dlo |= (uint32_t)hdiff; dhi |= (uint32_t)(hdiff >> 32);
+            const uint32_t rnk = (uint32_t)lane - __builtin_amdgcn_mbcnt_hi(dhi, __builtin_amdgcn_mbcnt_lo(dlo, 0u));
+            const uint32_t packed = ref[wave][dw[j]];
+            const uint32_t want = (dh[j] ? (packed >> 16) : (packed & 0xFFFFu)) + rnk;
+            const uint32_t mine = dh[j] ? (got[j] >> 16) : (got[j] & 0xFFFFu);
+            bad += (mine != want);
+            __builtin_amdgcn_s_barrier();   // (every lane has read ref before the group leaders update it; whole workgroup in lockstep)
+            if (rnk == 0) atomicAdd(&ref[wave][dw[j]], (64u - (uint32_t)(__popc(dlo) + __popc(dhi))) << (dh[j] ? 16 : 0));
+            __builtin_amdgcn_s_barrier();
+        }
     }
     for (int off = 32; off > 0; off >>= 1) bad += __shfl_xor(bad, off, 64);
     if (lane == 0) { atomicAdd(&res[0], bad); atomicAdd(&res[1], 1u); }
