@@ -489,3 +489,49 @@ def test_cls_model_base_is_the_normalised_output():
     raw = net(x).float()
     assert torch.allclose(base, raw / raw.norm(dim=-1, keepdim=True), atol=1e-6) and logits.shape == (4, 10)
     assert torch.allclose(logits, m.prob(m.bn(torch.relu(base))), atol=1e-6)
+
+
+def test_labelembed_model_mirrors_the_reference_head():
+    """learn_labelembedding.labelembed_model (reference :40-56): three outputs, identity-initialised label embeddings, out2 behind a
+    stop-gradient, the loss output produced by the fused kernel and trainable end to end."""
+    import utils
+    import learn_labelembedding as ll
+    torch.manual_seed(0)
+    base = utils.build_network(32, "resnet-32", input_channels=3).cuda()          # pooled 64-d embedding (no Dense head)
+    m = ll.labelembed_model(base, 10).cuda()
+    x = torch.randn(16, 3, 32, 32, device="cuda")
+    y = torch.randint(0, 10, (16,), device="cuda")
+    (X, Y), targets = ll.transform_inputs(x, y, 10)
+    emb, out1, loss = m(X, Y)
+    assert emb.shape == (16, 64) and out1.shape == (16, 10) and loss.shape == (16, 1) and targets["labelembed_loss"].shape == (16, 1)
+    assert torch.equal(m.labelembeddings.weight, torch.eye(10, device="cuda"))
+    out = m.embedding_bn(torch.relu(emb.float()))
+    want = lo.labelembed_loss(out1.detach().cpu().numpy(), m.out2(out).detach().cpu().numpy(), torch.eye(10)[y.cpu()].numpy(), y.cpu().numpy())
+    assert np.abs(loss.detach().cpu().numpy().ravel() - want).max() <= 1e-4
+    loss.mean().backward()
+    g = {n: p.grad for n, p in m.named_parameters()}
+    assert g["prob.weight"].abs().sum() > 0 and g["out2.weight"].abs().sum() > 0 and g["labelembeddings.weight"].abs().sum() >= 0
+    assert all(torch.isfinite(v).all() for v in g.values() if v is not None)
+
+
+def test_bench_line_schema_on_a_small_problem():
+    """bench.py end to end at a reduced size (so that a broken bench cannot reach the driver): one JSON line with the contract's
+    keys, the roofline / kernels objects, the post-run oracle verification and the sharded-gallery leg."""
+    import json
+    import subprocess
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--n", "4096", "--steps", "2", "--warmup", "1", "--no-train",
+                          "--shard-rows", "3000", "--shard-queries", "500", "--shard-dim", "64", "--shard-k", "17", "--cpu-sample-queries", "256"],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1
+    d = json.loads(line[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline", "kernels", "verified", "sharded_gallery"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["verified"] is True and d["value"] > 0
+    assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])
+    assert d["kernels"]["pairwise_dist"]["flops_executed"] < d["kernels"]["pairwise_dist"]["flops_full_matrix"]
+    sg = d["sharded_gallery"]
+    assert "error" not in sg and sg["merged_lists_sorted_with_index_tiebreak"] and sg["merged_indices_in_range"]
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
