@@ -14,14 +14,15 @@ tail -5 $OUT/pytest_gpu.log
 cat $OUT/bench.json
 for what in pdist rank topk loss hprec; do timeout 300 python tools/bench_kernels.py $what; done > $OUT/kernels.log 2>&1
 cat $OUT/kernels.log
+TUNING=$PWD/semantic-embeddings_amd/sehip/libsehip_tuning.so     # the product library ignores every tuning / ablation switch
 if [ "${ABLATE:-0}" = "1" ]; then
-  for ab in 1 2 3; do echo "SE_PD_ABLATE=$ab"; SE_PD_ABLATE=$ab timeout 300 python tools/bench_kernels.py pdist; done > $OUT/ablate.log 2>&1
-  SE_PD_NOSTAGGER=1 timeout 300 python tools/bench_kernels.py pdist >> $OUT/ablate.log 2>&1
+  for ab in 1 2 3; do echo "SE_PD_ABLATE=$ab"; SEHIP_LIB=$TUNING SE_PD_ABLATE=$ab timeout 300 python tools/bench_kernels.py pdist; done > $OUT/ablate.log 2>&1
+  SEHIP_LIB=$TUNING SE_PD_NOSTAGGER=1 timeout 300 python tools/bench_kernels.py pdist >> $OUT/ablate.log 2>&1
   cat $OUT/ablate.log
   hipcc --offload-arch=gfx950 -O3 tools/probes/store_patterns.hip -o /tmp/store_patterns && timeout 120 /tmp/store_patterns > $OUT/store_patterns.log 2>&1
   cat $OUT/store_patterns.log
 fi
-SE_RR_PROFILE=1 timeout 200 python tools/bench_kernels.py rank --reps 2 2>&1 | grep profile | tail -2 > $OUT/rank_phase_profile.txt; cat $OUT/rank_phase_profile.txt
+SEHIP_LIB=$TUNING SE_RR_PROFILE=1 timeout 200 python tools/bench_kernels.py rank --reps 2 2>&1 | grep profile | tail -2 > $OUT/rank_phase_profile.txt; cat $OUT/rank_phase_profile.txt
 rocprofv3 --kernel-trace --stats -d $OUT/prof -o r1 -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-train > $OUT/prof.log 2>&1
 DB=$(find $OUT/prof -name "*.db" | head -1)
 [ -n "$DB" ] && python tools/rocprof_summary.py $DB "python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-train" > $OUT/prof_summary.txt && cat $OUT/prof_summary.txt
