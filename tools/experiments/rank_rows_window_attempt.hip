@@ -1,0 +1,1083 @@
+// rank_rows.hip -- full ranking of every row of a distance matrix.
+//
+// Replaces `ranking = np.argsort(pdist, axis = -1)` (evaluate_retrieval.py:67) with the canonical
+// tie rule: ascending (distance, index), NaN last, -0 == +0.
+//
+// One workgroup sorts one row (a segment of N keys) with a stable LSD radix sort (8-bit digits, 4
+// passes) on the order-preserving uint32 image of the float keys; stability + initial index order
+// give the index tiebreak for free.  Structure per row:
+//   H. one streaming read of the row builds the digit histograms of ALL four passes (LDS atomics);
+//      their exclusive scans are the running output cursors gbase[pass][digit].
+//   P. each pass walks the row in tiles of RK_TILE keys held in registers (wave w owns a contiguous
+//      sub-chunk of the tile, 64 keys per step, coalesced loads):
+//        1. per-wave digit counts of the tile (LDS atomics) -> digit-major / wave-minor scan;
+//        2. stable rank inside the tile: lanes holding equal digits find each other with 8 ballots
+//           (wave multisplit), one LDS cursor read+write per digit group; keys/indices are written
+//           to their tile-sorted slot IN LDS;
+//        3. the tile is read back in sorted order and written to global memory at
+//           gbase[digit] + offset: consecutive lanes write consecutive addresses inside each digit
+//           run, so HBM/L2 see coalesced runs (~RK_TILE/256 keys) instead of 4-byte scatters.
+// Keys/indices ping-pong between two scratch rows per resident workgroup in the caller's workspace;
+// the last pass writes the index matrix only.
+// HBM-side algorithmic traffic: 4 N bytes in (distances) + 4 N bytes out (int32 ranks) per row.
+#include "se_common.h"
+#include <stdlib.h>
+#include <atomic>
+
+namespace se {
+
+constexpr int RK_THREADS = 512;
+constexpr int RK_WAVES = RK_THREADS / WAVE;
+constexpr int RK_ITEMS = 16;                       // keys per thread per tile
+constexpr int RK_TILE = RK_THREADS * RK_ITEMS;     // 8192
+constexpr int RK_WCHUNK = RK_TILE / RK_WAVES;      // 1024 keys per wave per tile
+constexpr int RK_NB = 256;
+
+struct RankLds {
+    uint32_t gbase[4][RK_NB];        // running global cursors per pass
+    uint32_t wcnt[RK_WAVES][RK_NB];  // per-wave cursors inside the current tile
+    uint32_t tile_start[RK_NB];      // first tile-sorted slot of each digit
+    uint32_t wave_tot[RK_WAVES];
+    uint32_t tkeys[RK_TILE];
+    uint32_t tidx[RK_TILE];
+};
+
+__device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t &total)
+{
+    const int lane = lane_id();
+    uint32_t incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
+    }
+    total = __shfl(incl, 63, 64);
+    return incl - v;
+}
+
+template <bool IDX64>
+__global__ __launch_bounds__(RK_THREADS) void rank_rows_kernel(const float *__restrict__ pdist, int64_t ldp,
+                                                               int64_t Q, int N, void *rank, int64_t ldr,
+                                                               uint32_t *ws, int64_t n_pad)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char rk_raw[];
+    RankLds &L = *reinterpret_cast<RankLds *>(rk_raw);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+
+    uint32_t *kA = ws + (int64_t)blockIdx.x * 4 * n_pad;
+    uint32_t *iA = kA + n_pad, *kB = iA + n_pad, *iB = kB + n_pad;
+    const int ntiles = (N + RK_TILE - 1) / RK_TILE;
+
+    for (int64_t row = blockIdx.x; row < Q; row += gridDim.x) {
+        const float *drow = pdist + row * ldp;
+
+        // ---------------- H: histograms of all four digits, one read of the row ----------------
+        __syncthreads();
+        for (int i = tid; i < 4 * RK_NB; i += RK_THREADS) (&L.gbase[0][0])[i] = 0;
+        __syncthreads();
+        for (int i = tid; i < N; i += RK_THREADS) {
+            const uint32_t key = canon_key(drow[i]);
+            atomicAdd(&L.gbase[0][key & 0xFF], 1u);
+            atomicAdd(&L.gbase[1][(key >> 8) & 0xFF], 1u);
+            atomicAdd(&L.gbase[2][(key >> 16) & 0xFF], 1u);
+            atomicAdd(&L.gbase[3][key >> 24], 1u);
+        }
+        __syncthreads();
+        if (wave < 4) {  // wave p scans histogram p (4 digits per lane)
+            uint32_t c[4], s = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) { c[j] = L.gbase[wave][lane * 4 + j]; s += c[j]; }
+            uint32_t tot;
+            uint32_t run = wave_excl_scan(s, tot);
+#pragma unroll
+            for (int j = 0; j < 4; j++) { L.gbase[wave][lane * 4 + j] = run; run += c[j]; }
+        }
+        __syncthreads();
+
+        // ---------------- P: four stable counting passes ----------------
+#pragma unroll 1
+        for (int p = 0; p < 4; p++) {
+            const int shift = p * 8;
+            const uint32_t *sk = (p & 1) ? kA : kB;
+            const uint32_t *si = (p & 1) ? iA : iB;
+            uint32_t *dk = (p & 1) ? kB : kA;
+            uint32_t *di = (p & 1) ? iB : iA;
+            const bool last = (p == 3);
+#pragma unroll 1
+            for (int t = 0; t < ntiles; t++) {
+                const int tbase = t * RK_TILE;
+                const int tcount = (N - tbase < RK_TILE) ? (N - tbase) : RK_TILE;
+                const int wbeg = wave * RK_WCHUNK;   // tile-local first element of this wave
+
+                // 1a. load the wave's sub-chunk (coalesced), zero own counters.  Loads are unconditional
+                //     (clamped index + select): branching around each load would serialise them.
+                uint32_t key[RK_ITEMS], idx[RK_ITEMS];
+                if (p == 0) {
+#pragma unroll
+                    for (int s = 0; s < RK_ITEMS; s++) {
+                        const int li = wbeg + s * WAVE + lane;
+                        const int gi = tbase + li;
+                        const float f = drow[gi < N ? gi : N - 1];
+                        key[s] = (li < tcount) ? canon_key(f) : 0xFFFFFFFFu;
+                        idx[s] = (uint32_t)gi;
+                    }
+                } else {
+#pragma unroll
+                    for (int s = 0; s < RK_ITEMS; s++) {
+                        const int li = wbeg + s * WAVE + lane;
+                        const int gi = tbase + li;
+                        const int gc = gi < N ? gi : N - 1;
+                        const uint32_t k = sk[gc], i2 = si[gc];
+                        key[s] = (li < tcount) ? k : 0xFFFFFFFFu;
+                        idx[s] = i2;
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < RK_NB / WAVE; j++) L.wcnt[wave][j * WAVE + lane] = 0;
+                // 1b. per-wave digit counts
+#pragma unroll
+                for (int s = 0; s < RK_ITEMS; s++) {
+                    const int li = wbeg + s * WAVE + lane;
+                    if (li < tcount) atomicAdd(&L.wcnt[wave][(key[s] >> shift) & 0xFF], 1u);
+                }
+                __syncthreads();
+                // 1c. digit-major / wave-minor exclusive scan (threads 0..255 own one digit each)
+                uint32_t my_total = 0;
+                if (tid < RK_NB) {
+                    uint32_t run = 0;
+#pragma unroll
+                    for (int w = 0; w < RK_WAVES; w++) {
+                        const uint32_t c = L.wcnt[w][tid];
+                        L.wcnt[w][tid] = run;
+                        run += c;
+                    }
+                    my_total = run;
+                    uint32_t wtot;
+                    const uint32_t ex = wave_excl_scan(my_total, wtot);
+                    if (lane == 63) L.wave_tot[wave] = wtot;
+                    L.tile_start[tid] = ex;  // still missing the totals of the lower waves
+                }
+                __syncthreads();
+                if (tid < RK_NB) {
+                    uint32_t add = 0;
+                    for (int w = 0; w < wave; w++) add += L.wave_tot[w];
+                    const uint32_t st = L.tile_start[tid] + add;
+                    L.tile_start[tid] = st;
+#pragma unroll
+                    for (int w = 0; w < RK_WAVES; w++) L.wcnt[w][tid] += st;
+                }
+                __syncthreads();
+
+                // 2. stable rank inside the tile, place into LDS in tile-sorted order
+                volatile uint32_t *cur = L.wcnt[wave];
+#pragma unroll
+                for (int s = 0; s < RK_ITEMS; s++) {
+                    const int li = wbeg + s * WAVE + lane;
+                    const bool valid = li < tcount;
+                    const uint32_t dgt = (key[s] >> shift) & 0xFF;
+                    uint64_t peers = __ballot(valid);
+#pragma unroll
+                    for (int bb = 0; bb < 8; bb++) {
+                        const bool bit = (dgt >> bb) & 1u;
+                        const uint64_t m = __ballot(bit && valid);
+                        peers &= bit ? m : ~m;
+                    }
+                    if (valid) {
+                        const int rnk = __popcll(peers & lt_mask);
+                        const int npeers = __popcll(peers);
+                        const uint32_t base = cur[dgt];
+                        if (rnk == npeers - 1) cur[dgt] = base + (uint32_t)npeers;
+                        L.tkeys[base + rnk] = key[s];
+                        L.tidx[base + rnk] = idx[s];
+                    }
+                }
+                __syncthreads();
+
+                // 3. coalesced write-out of the tile-sorted keys
+#pragma unroll
+                for (int j = 0; j < RK_ITEMS; j++) {
+                    const int i = j * RK_THREADS + tid;
+                    if (i < tcount) {
+                        const uint32_t k = L.tkeys[i];
+                        const uint32_t id = L.tidx[i];
+                        const uint32_t d = (k >> shift) & 0xFF;
+                        const uint32_t gpos = L.gbase[p][d] + ((uint32_t)i - L.tile_start[d]);
+                        if (last) {
+                            if (IDX64) ((int64_t *)rank)[row * ldr + gpos] = (int64_t)id;
+                            else ((int32_t *)rank)[row * ldr + gpos] = (int32_t)id;
+                        } else {
+                            dk[gpos] = k;
+                            di[gpos] = id;
+                        }
+                    }
+                }
+                __syncthreads();
+                if (tid < RK_NB) L.gbase[p][tid] += my_total;
+                // (next tile's first barrier orders this update before its use)
+            }
+        }
+    }
+}
+
+
+// =================================================================================================
+// Register-resident variant (the fast path, N <= RR_MAX_N): one 512-thread workgroup holds a whole
+// row in registers (ITEMS keys per thread), so a row costs ONE HBM read of the distances and ONE HBM
+// write of the ranks -- the algorithmic minimum -- and no global round trip sits between the passes.
+//   * position p of the current arrangement lives in wave p / (64 ITEMS), step (p / 64) % ITEMS,
+//     lane p % 64; positions >= N hold padding keys 0xFFFFFFFF whose initial position is behind
+//     every real key, so stability keeps them last and they are never written out;
+//   * per pass: (R) stable within-wave rank of every key on the wave's private LDS counters -- ONE returning add per key
+//     (hardware-ordered build: 3 passes of 11 + 11 + 10 or 10 + 10 + 12 bits) or an 8-ballot wave multisplit + one add per
+//     digit group (guaranteed-order build: 4 passes of 8 bits); (S) digit-major / wave-minor scan of the counters;
+//     (X) in-place exchange through a 2-byte-per-key LDS buffer (160 KB of LDS cannot hold 4 B x 50k keys): the 16-bit
+//     index, then the key halves that later passes still need -- 6 (8) two-byte exchanges per key instead of 9 (12);
+//   * indices travel as 16 bits (N <= 65536 by construction) packed with the 16-bit destination;
+//   * after the last pass the exchange buffer IS the ranking: it is streamed to HBM with 16-byte
+//     stores.
+#ifndef SE_RR_THREADS
+#define SE_RR_THREADS 512   // 512 (8 waves, 2 per SIMD, <= 256 VGPRs) or 768 (12 waves, 3 per SIMD, <= 168 VGPRs)
+#endif
+constexpr int RR_THREADS = SE_RR_THREADS;
+constexpr int RR_WAVES = RR_THREADS / WAVE;
+constexpr int RR_SCAN_THREADS = 512;                  // threads that scan the packed counters (2 words each of the 1024 per wave)
+constexpr int RR_SCAN_WAVES = RR_SCAN_THREADS / WAVE;
+static_assert((53248 + RR_THREADS - 1) / RR_THREADS <= 104, "rows of up to 53,248 columns: 104 keys per thread (512 threads) / 70 (768 threads)");
+constexpr int RR_G = 8;                               // steps ranked together (latency overlap vs live registers)
+constexpr int RR_MAX_N = 53248;
+
+// Wave multisplit on an 8-bit digit: bit mask of the lanes whose digit DIFFERS from this lane's, as
+// OR_b (ballot_b ^ own_bit_b): per bit one v_bfe_i32, one v_cmp (the ballot) and one v_bitop3 per mask half.
+__device__ __forceinline__ void differ_mask(uint32_t d, uint32_t &lo, uint32_t &hi)
+{
+    lo = 0;
+    hi = 0;
+#pragma unroll
+    for (int bb = 0; bb < 8; bb += 2) {
+        uint32_t s0 = (uint32_t)__builtin_amdgcn_sbfe((int)d, bb, 1);       // 0 or ~0
+        uint32_t s1 = (uint32_t)__builtin_amdgcn_sbfe((int)d, bb + 1, 1);
+        asm volatile("" : "+v"(s0), "+v"(s1));   // keep the ballot a plain compare of the extracted bit
+        const uint64_t m0 = __ballot(s0 != 0), m1 = __ballot(s1 != 0);
+        // acc | (ballot ^ own): v_bitop3_b32, truth table of a | (b ^ c) with a = 0xF0, b = 0xCC, c = 0xAA
+        lo = __builtin_amdgcn_bitop3_b32(lo, (uint32_t)m0, s0, 0xF6);
+        hi = __builtin_amdgcn_bitop3_b32(hi, (uint32_t)(m0 >> 32), s0, 0xF6);
+        lo = __builtin_amdgcn_bitop3_b32(lo, (uint32_t)m1, s1, 0xF6);
+        hi = __builtin_amdgcn_bitop3_b32(hi, (uint32_t)(m1 >> 32), s1, 0xF6);
+    }
+}
+
+// Sort key of the register-resident kernel: the canonical order of canon_key() in 6 VALU instead of ~13 (the canonicalisation
+// of a 50k row is 98 keys x 2 waves per SIMD: 6k of a row's 115k cycles with canon_key).  Negative values map to ~u + 1, so
+// that -0.0 lands ON +0.0's key 0x80000000 without a compare (the keys never leave the kernel; order and ties are those of
+// canon_key: ascending value, -0.0 == +0.0, every NaN and every padding slot 0xFFFFFFFF).
+__device__ __forceinline__ uint32_t rr_key(uint32_t u, bool pad)
+{
+    const uint32_t sx = (uint32_t)((int32_t)u >> 31);                                   // 0 or ~0
+    uint32_t k = __builtin_amdgcn_bitop3_b32(u, sx, 0x80000000u, 0x1E);                 // u ^ (sx | 0x80000000): ~u or u | 0x80000000
+    k -= sx;                                                                            // negative: + 1
+    const float f = __uint_as_float(u);
+    return (f != f || pad) ? 0xFFFFFFFFu : k;
+}
+
+template <typename T>
+__device__ __forceinline__ void opaque(T &x) { asm volatile("" : "+v"(x)); }   // value barrier: no CSE / hoisting across it
+
+__device__ __forceinline__ uint32_t lds_off(const void *p) { return (uint32_t)(uintptr_t)p; }   // LDS byte address of a __shared__ pointer
+// The exchange is written with explicit DS instructions: the 16-bit loads land IN PLACE in one half of a
+// live register (no temporaries, no merge VALU) and hipcc cannot cache 2 x ITEMS destination addresses.
+// hipcc does not count these toward its own s_waitcnt bookkeeping, hence the explicit lds_wait().
+__device__ __forceinline__ void lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void lds_st16_lo(uint32_t addr, uint32_t v) { asm volatile("ds_write_b16 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
+__device__ __forceinline__ void lds_st16_hi(uint32_t addr, uint32_t v) { asm volatile("ds_write_b16_d16_hi %0, %1" ::"v"(addr), "v"(v) : "memory"); }
+// (gfx950 runs with SRAM-ECC: a d16 load ZEROES the other register half, so the 16-bit loads go to a
+// small ring of temporaries and one v_perm_b32 merges each into the live register.)
+template <int OFF>
+__device__ __forceinline__ void lds_ld16(uint32_t &dst, uint32_t addr) { asm volatile("ds_read_u16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF) : "memory"); }
+// wait until at most K DS operations are outstanding; `landed` is the register the awaited load writes -- naming
+// it as an in/out operand is what orders its consumers after the wait (the asm statements carry no other dependency)
+template <int K>
+__device__ __forceinline__ void lds_wait_le(uint32_t &landed) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(landed) : "n"(K) : "memory"); }
+
+#ifndef SE_RR_RING
+#define SE_RR_RING 12
+#endif
+constexpr int RR_RING = SE_RR_RING;   // 16-bit loads in flight per lane (lgkmcnt counts to 15)
+// Software-pipelined read of this lane's ITEMS new 16-bit values (read slot of step s = addr + 128 s)
+// into the HIGH (HI = true) or LOW half of a[s]: read i is issued RR_RING - 1 reads ahead of its merge.
+template <int ITEMS, bool HI, int I = 0>
+struct RRRead {
+    static __device__ __forceinline__ void run(uint32_t (&a)[ITEMS], uint32_t (&t)[RR_RING], uint32_t addr)
+    {
+        constexpr int D = RR_RING - 1;
+        if constexpr (I < ITEMS) lds_ld16<I * WAVE * 2>(t[I % RR_RING], addr);
+        if constexpr (I >= D) {
+            constexpr int J = I - D;
+            constexpr int newest = (I < ITEMS ? I : ITEMS - 1);
+            lds_wait_le<newest - J>(t[J % RR_RING]);
+            // HI: (t << 16) | (a & 0xFFFF)      LO: (a & 0xFFFF0000) | (t & 0xFFFF)
+            a[J] = __builtin_amdgcn_perm(t[J % RR_RING], a[J], HI ? 0x05040100u : 0x03020504u);
+        }
+        if constexpr (I + 1 < ITEMS + D) RRRead<ITEMS, HI, I + 1>::run(a, t, addr);
+    }
+};
+
+// ---- R phase, one group of V <= RR_G consecutive steps starting at step S0 -------------------------------
+// Per step: every lane READS its digit's counter (equal digits: one broadcast read), then the first lane of
+// each digit group ADDS the group size (no return value).  DS operations of one wave execute in program
+// order, so the read sees exactly the keys of earlier steps; nothing waits on the add, and the V reads of
+// the group are in flight together.  Explicit DS instructions: a volatile / atomic C++ access to the
+// counters would be emitted as a FLAT operation.
+template <int ITEMS, int V, int S0, int I = 0>
+struct RRRankFinish {   // read I of the group is followed by 2 (V-1-I) + 1 younger DS operations (every step issues both)
+    static __device__ __forceinline__ void run(uint32_t (&ir)[ITEMS], uint32_t (&key)[ITEMS], uint32_t (&rnk)[V], uint32_t (&base)[V])
+    {
+        lds_wait_le<2 * (V - 1 - I) + 1>(base[I]);
+        ir[S0 + I] = (ir[S0 + I] & 0xFFFF0000u) | (base[I] + rnk[I]);
+        opaque(ir[S0 + I]);    // materialise now: nothing but key/ir stays live per key
+        opaque(key[S0 + I]);   // (and no cached counter address either)
+        if constexpr (I + 1 < V) RRRankFinish<ITEMS, V, S0, I + 1>::run(ir, key, rnk, base);
+    }
+};
+
+template <int ITEMS, int S0 = 0>
+struct RRRank {
+    static __device__ __forceinline__ void run(uint32_t (&ir)[ITEMS], uint32_t (&key)[ITEMS], int shift, int lane, uint32_t cb)
+    {
+        constexpr int V = (ITEMS - S0 < RR_G) ? (ITEMS - S0) : RR_G;
+        static_assert(2 * V - 1 <= 15, "lgkmcnt counts to 15");
+        uint32_t rnk[V], base[V];
+#pragma unroll
+        for (int g = 0; g < V; g++) {
+            const uint32_t d = (key[S0 + g] >> shift) & 0xFFu;
+            uint32_t dlo, dhi;
+            differ_mask(d, dlo, dhi);
+            // lower lanes with the same digit = lower lanes - lower lanes that differ
+            rnk[g] = (uint32_t)lane - __builtin_amdgcn_mbcnt_hi(dhi, __builtin_amdgcn_mbcnt_lo(dlo, 0u));
+            const uint32_t ca = cb + (d << 2);
+            asm volatile("ds_read_b32 %0, %1" : "=v"(base[g]) : "v"(ca) : "memory");
+            if (rnk[g] == 0) {   // (lane 0 always leads a group, so the add is issued in every step)
+                const uint32_t np = 64u - (uint32_t)(__popc(dlo) + __popc(dhi));
+                asm volatile("ds_add_u32 %0, %1" ::"v"(ca), "v"(np) : "memory");
+            }
+        }
+        RRRankFinish<ITEMS, V, S0>::run(ir, key, rnk, base);
+        // the scheduling fence between groups keeps hipcc from hoisting all ITEMS steps' ballots at once
+        // (hundreds of live SGPR pairs -> spills)
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (S0 + V < ITEMS) RRRank<ITEMS, S0 + V>::run(ir, key, shift, lane, cb);
+    }
+};
+
+// ---- R phase, hardware-ordered variant -------------------------------------------------------------------
+// One RETURNING add per key on the wave's digit counter: the returned value is the within-wave rank directly,
+// PROVIDED the LDS serves the lanes of one ds_add_rtn that hit the same address in ascending lane order.
+// gfx950 does (tools/probes/lds_atomic_order.hip: 84 M returns under every conflict pattern, 8 waves per
+// workgroup hammering the LDS), but the ISA does not promise it, so this variant is only selected after the
+// same property has been re-verified on the device at first use (se_rank_rows: probe kernel) and can be
+// switched off with SE_RANK_SAFE=1.  ~5 VALU per key and pass instead of ~41.
+#ifndef SE_RR_NT
+#define SE_RR_NT 0   // 1: nontemporal rank stores (build-time tuning aid)
+#endif
+typedef int rr_i32x4 __attribute__((ext_vector_type(4)));
+typedef long long rr_i64x2 __attribute__((ext_vector_type(2)));
+#ifndef SE_RR_PF
+#define SE_RR_PF 1
+#endif
+#ifndef SE_RR_GH
+#define SE_RR_GH 8
+#endif
+constexpr int RR_GH = SE_RR_GH;    // returning adds in flight per lane
+constexpr int RR_HW_BITS = 11;   // digit width of the hardware-ordered variant: 3 passes (11 + 11 + 10 bits; rows of >= 32,768 columns: 10 + 10 + 12) instead of 4
+constexpr int RR_WIDE_WORDS = 2048;   // counter words per wave of the 12-bit pass (4096 packed 16-bit counters)
+// Counters are 16 bits wide, two per LDS word (8 waves x 2048 digits x 2 B = 32 KB next to the 100 KB exchange
+// buffer): a wave holds at most 64 x 104 keys and a destination is < 53,248, so neither half can carry into the
+// other.  The returning add is done on the word with the increment shifted into the digit's half.
+// PEEL (used for the most significant digit): the lanes that share lane 0's digit are ranked by one ballot and ONE
+// add of the group size issued by lane 0; only the other lanes issue their own returning add.  The top digit of
+// real distance rows is heavily skewed -- all-positive Euclidean distances put every key of a wave step on one
+// counter, i.e. a 64-way same-address conflict per instruction (16.9 ms instead of 11 ms on the CLI-default branch).
+// Digit d of a pass = key bits [shift, shift + wlo + whi): its low wlo = 10 bits select the counter WORD, bit 10 (whi = 1;
+// the 10-bit last pass has whi = 0) the 16-bit HALF -- both straight v_bfe_u32 of the key, and the S phase can scan the
+// packed words without unpacking them (digits 0..1023 are the low halves, 1024..2047 the high halves).
+// The adds are software-pipelined one by one -- "retire step S - RR_GH, issue step S" -- so every lane keeps RR_GH - 1 or
+// RR_GH returning adds in flight from the first step to the last (tools/probes/lds_throughput.hip: the LDS sustains one
+// random-word returning add per 6.4 cycles and CU; batches of 8 that drain before the next batch is issued reached 21).
+template <int ITEMS, bool PEEL, int S = 0>
+struct RRRankHW {
+    // `peel` is wave-uniform (one code instance for all passes: two instances of this unrolled body make hipcc spill)
+    static __device__ __forceinline__ void run(uint32_t (&ir)[ITEMS], uint32_t (&key)[ITEMS], uint32_t (&r)[RR_GH], uint32_t (&sh)[RR_GH],
+                                               uint32_t (&grp)[RR_GH], uint32_t shift, uint32_t hshift, uint32_t wlo, uint32_t whi, uint32_t cb,
+                                               int lane, bool peel)
+    {
+        constexpr int SLOT = S % RR_GH;
+        uint32_t ca = 0, inc = 0, shv = 0, g = 0xFFFFFFFFu;
+        uint64_t part = ~0ull;
+        if constexpr (S < ITEMS) {
+            const uint32_t w = __builtin_amdgcn_ubfe(key[S], shift, wlo);
+            const uint32_t h = __builtin_amdgcn_ubfe(key[S], hshift, whi);   // width 0 -> 0
+            ca = cb + (w << 2);
+            if constexpr (PEEL) {
+                shv = h << 4;
+                inc = 1u << shv;
+            } else {
+                // no shift amounts: the increment is 1 + 0xFFFF h, and `shv` holds the v_perm_b32 selector that drops the returned
+                // half straight into the low half of ir (bytes [ir3, ir2, r(1 + 2h), r(2h)]): 6 VALU per key instead of 7
+                inc = __umul24(h, 0xFFFFu) + 1u;
+                shv = __umul24(h, 0x0202u) + 0x07060100u;
+            }
+            if constexpr (PEEL) {
+                if (peel) {                          // wave-uniform branch: the other passes skip the group bookkeeping
+                    // lanes sharing lane 0's digit (most significant pass only) are ranked by one ballot and ONE add of the group size
+                    const uint32_t d = w | (h << 11);   // (w < 2048)
+                    const bool in = (d == (uint32_t)__builtin_amdgcn_readfirstlane((int)d));
+                    const uint64_t m = __ballot(in);
+                    if (in) g = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    if (lane == 0) inc = (uint32_t)__popcll(m) << shv;
+                    part = ~m | 1ull;                // only lane 0 and the lanes outside its group issue the add
+                }
+            }
+        }
+        if constexpr (S >= RR_GH) {                  // retire step J: wait until only the adds issued after it are outstanding
+            constexpr int J = S - RR_GH;
+            constexpr int younger = ((S < ITEMS ? S : ITEMS) - 1) - J;
+            lds_wait_le<younger>(r[SLOT]);
+            if constexpr (PEEL) {
+                const uint32_t lead = (uint32_t)__builtin_amdgcn_readfirstlane((int)r[SLOT]);   // lane 0's counter word before its add
+                const uint32_t own = (grp[SLOT] != 0xFFFFFFFFu) ? lead : r[SLOT];                 // group members use lane 0's word (same digit => same half)
+                const uint32_t rank = __builtin_amdgcn_ubfe(own, sh[SLOT], 16u) + (grp[SLOT] != 0xFFFFFFFFu ? grp[SLOT] : 0u);
+                ir[J] = (ir[J] & 0xFFFF0000u) | rank;
+            } else {
+                ir[J] = __builtin_amdgcn_perm(ir[J], r[SLOT], sh[SLOT]);
+            }
+            opaque(ir[J]);    // materialise now: nothing but key/ir stays live per key
+            opaque(key[J]);   // (and no cached counter address either)
+        }
+        if constexpr (S < ITEMS) {
+            sh[SLOT] = shv;
+            grp[SLOT] = g;
+            if constexpr (PEEL) {
+                // The exec mask is narrowed INSIDE the asm statement: a C++ `if` around an asynchronous DS return lets hipcc copy the
+                // (not yet landed) result register at the join.  Lane 0 always takes part: exactly one DS operation per step.
+                uint64_t saved;
+                r[SLOT] = 0;
+                asm volatile("s_and_saveexec_b64 %0, %4\n\tds_add_rtn_u32 %1, %2, %3\n\ts_mov_b64 exec, %0"
+                             : "=&s"(saved), "+v"(r[SLOT])
+                             : "v"(ca), "v"(inc), "s"(part)
+                             : "memory");
+            } else {
+                asm volatile("ds_add_rtn_u32 %0, %1, %2" : "=v"(r[SLOT]) : "v"(ca), "v"(inc) : "memory");
+            }
+        }
+        // the scheduling fence keeps hipcc from hoisting the address arithmetic of all ITEMS steps (live registers -> spills)
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (S + 1 < ITEMS + RR_GH) RRRankHW<ITEMS, PEEL, S + 1>::run(ir, key, r, sh, grp, shift, hshift, wlo, whi, cb, lane, peel);
+    }
+};
+
+// Windowed most significant digit (SE_RR_WIN, long rows of the hardware-ordered build).  The last pass is the expensive one: its
+// digit -- sign, exponent, 3 mantissa bits -- takes few distinct values on real distance rows, several lanes of every wave step hit
+// the same counter, and same-address returning adds serialise (32k cycles per row in its rank phase vs 8k in the other passes,
+// profiles/r02_d_phase_profiles.txt).  Half of that digit's 4096 values can never occur when every value of the row has magnitude
+// below 2 -- always true for cosine distances: keys then lie in [0x40000000, 0xC0000000).  Such rows (detected per row while the
+// keys are canonicalised: no float pattern has bit 30 set) are sorted with digits of 10 + 9 + 13 bits, the 13-bit digit
+// minus 2048 being a 12-bit value: one more mantissa bit = half the lanes per counter, same 64 KB of aliased counters.  Rows with
+// larger values, Inf or NaN keep 10 + 10 + 12.
+#ifndef SE_RR_WIN
+#define SE_RR_WIN 1
+#endif
+template <int ITEMS, bool PROF, bool HWORD, bool PEEL>
+__global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_kernel(const float *__restrict__ pdist, int64_t ldp, int64_t Q,
+                                                                    int N, void *rank, int64_t ldr, int idx64, int vec_ok,
+                                                                    unsigned long long *prof, const uint32_t *skew_flag)
+{
+    // two launches per call when the detector is used: the variant that does not match the flag leaves at once
+    if (skew_flag && ((*skew_flag != 0) != PEEL)) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char rr_raw[];
+    constexpr int BITS = HWORD ? RR_HW_BITS : 8;                        // digit width (narrow passes)
+    constexpr int NB = 1 << BITS;
+    constexpr int NPASS = (32 + BITS - 1) / BITS;                       // 3 or 4
+    constexpr int CNT_WORDS = HWORD ? NB / 2 : NB;                      // LDS words per wave: packed 16-bit or 32-bit counters
+    // WIDE: digits of 10 + 10 + 12 bits instead of 11 + 11 + 10.  The most significant digit of real distance rows is skewed (sign,
+    // exponent, 1-2 mantissa bits: ~20 values, 8 lanes of a wave step on the same counter = 29 instead of 8 cycles per returning add);
+    // two more mantissa bits quarter the multiplicity.  Its 8 x 4096 16-bit counters (64 KB) do not fit next to the exchange buffer, so
+    // they ALIAS it: the buffer is idle from the last exchange read of the previous pass to the first scatter of this one (two extra
+    // barriers per row keep the other waves' reads / counter look-ups on the right side of that reuse).
+    constexpr bool WIDE = HWORD && ((size_t)RR_THREADS * ITEMS * sizeof(uint16_t) >= (size_t)RR_WAVES * RR_WIDE_WORDS * sizeof(uint32_t));
+    uint32_t *wcnt = reinterpret_cast<uint32_t *>(rr_raw);              // [RR_WAVES][CNT_WORDS]
+    uint32_t *wave_tot = wcnt + RR_WAVES * CNT_WORDS;                   // [8] (+pad)
+    uint16_t *xbuf = reinterpret_cast<uint16_t *>(wave_tot + 32);       // [RR_THREADS * ITEMS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wpos0 = wave * (ITEMS * WAVE) + lane;                     // position of (step s) = wpos0 + 64 s
+    const uint32_t xb = lds_off(xbuf);                                  // exchange buffer, byte address
+    const uint32_t rb = xb + 2u * (uint32_t)wpos0;                      // this lane's read slot of step 0
+#define RR_DST(IR) (xb + (((IR) & 0xFFFFu) << 1))
+    // tuning aid (SE_RR_PROFILE=1): shader-clock cycles per phase, summed over every workgroup's wave 0
+    uint64_t t_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_pp[24] = {}, t_last = PROF ? __builtin_amdgcn_s_memtime() : 0;
+#define RR_T(i) if constexpr (PROF) { lds_wait(); __syncthreads(); /* phase times are workgroup-wide: include the skew between the waves */ const uint64_t now = __builtin_amdgcn_s_memtime(); t_acc[i] += now - t_last; if (rr_pass >= 0) t_pp[(i) * 3 + rr_pass] += now - t_last; t_last = now; } else { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
+
+    // The row loop is software-pipelined over HBM: the NEXT row is prefetched into L2 during the last pass (one dword per 128-byte
+    // line), loaded into the key registers right after it -- BEFORE this row's rank stores are issued, so the memory pipeline serves
+    // the loads first -- and canonicalised after the write-out, which covers most of their latency.  (With the loads issued after
+    // the stores, as in the first version, every row first waited for HBM to absorb its 200-400 KB: 29 % of the kernel.)
+    uint32_t key[ITEMS], ir[ITEMS];   // ir = (index << 16) | (within-wave rank, then destination)
+    uint32_t ring[RR_RING];
+#define RR_LOAD_ONE(DROW, WPOS, S)                                                                                   \
+    {                                                                                                                 \
+        /* unconditional load (clamped index; the padding is applied in RR_CANON): a branch around a load makes      \
+           hipcc wait for each load before issuing the next */                                                        \
+        const int pos = (WPOS) + (S) * WAVE;                                                                          \
+        uint32_t gi = (uint32_t)(pos < N ? pos : N - 1);   /* unsigned: scalar base + 32-bit lane offset addressing */ \
+        opaque(gi);                                                                                                   \
+        key[S] = __float_as_uint((DROW)[gi]);                                                                         \
+    }
+#define RR_CANON()                                                                                                    \
+    {                                                                                                                 \
+        int wpos_ = wpos0;                                                                                            \
+        opaque(wpos_);                                                                                                \
+        uint32_t any_ = 0;                                                                                            \
+        _Pragma("unroll") for (int s = 0; s < ITEMS; s++) {                                                           \
+            const int pos = wpos_ + s * WAVE;                                                                         \
+            if constexpr (WIDE && SE_RR_WIN) any_ |= key[s]; /* bit 30 of the float pattern: |value| >= 2, Inf or NaN */ \
+            key[s] = rr_key(key[s], pos >= N); /* pos >= N: all ones */                                               \
+        }                                                                                                             \
+        if constexpr (WIDE && SE_RR_WIN) win = !__syncthreads_or((int)((any_ >> 30) & 1u));                           \
+    }
+#define RR_PREFETCH_NEXT_ROW() \
+    if (p == NPASS - 1 && more) { \
+                const char *nrow = (const char *)(pdist + (row + gridDim.x) * ldp); \
+                const uint32_t row_bytes = (uint32_t)N * 4u; \
+                for (uint32_t off = (uint32_t)tid * 128u; off < row_bytes; off += RR_THREADS * 128u) \
+                    asm volatile("global_load_dword %0, %1, off" : "=v"(pf_sink) : "v"(nrow + off) : "memory"); \
+            }
+    [[maybe_unused]] bool win = false;   // the row held in key[] has all magnitudes below 2 (windowed most significant digit)
+    if ((int64_t)blockIdx.x < Q) {
+        const float *drow = pdist + (int64_t)blockIdx.x * ldp;
+        int wpos = wpos0;
+        opaque(wpos);
+#pragma unroll
+        for (int s = 0; s < ITEMS; s++) RR_LOAD_ONE(drow, wpos, s)
+        RR_CANON()
+    }
+    uint32_t pf_sink = 0;
+    [[maybe_unused]] int rr_pass = -1;   // profile build: pass index for the per-pass phase times
+    for (int64_t row = blockIdx.x; row < Q; row += gridDim.x) {
+        const bool more = row + gridDim.x < Q;
+        {
+            int wpos = wpos0;
+            opaque(wpos);
+#pragma unroll
+            for (int s = 0; s < ITEMS; s++) ir[s] = (uint32_t)(wpos + s * WAVE) << 16;
+        }
+#pragma unroll 1
+        for (int p = 0; p < NPASS; p++) {
+            // digit of this pass = key bits [shift, shift + nbits); windowed rows: 10 + 9 + (13 - offset = 12), else 10 + 10 + 12
+            const int shift = WIDE ? (win ? (p == 0 ? 0 : (p == 1 ? 10 : 19)) : p * 10) : p * BITS;
+            const int nbits = WIDE ? (p == 2 ? 12 : ((win && p == 1) ? 9 : 10)) : ((shift + BITS < 32) ? BITS : 32 - shift);
+            rr_pass = p;
+            const int end = (p == NPASS - 1) ? 32 : shift + nbits;           // bits [0, end) are sorted after this pass
+            const bool wide = WIDE && p == 2;                               // 12-bit digit, counters aliased onto the exchange buffer
+            if constexpr (WIDE && SE_RR_WIN) {
+                if (win && p == 2) {   // keys -> keys - 0x40000000 (real keys then < 2^31; padding saturates to the largest digit)
+#pragma unroll
+                    for (int s = 0; s < ITEMS; s++) {
+                        const uint32_t t = key[s] - 0x40000000u;
+                        key[s] = t < 0x7FFFFFFFu ? t : 0x7FFFFFFFu;
+                    }
+                }
+            }
+            // ---- R: stable rank inside the wave ----
+            // counters of this pass: the wave's slice of the dedicated region, or (wide pass) of the idle exchange buffer
+            uint32_t *pcnt = wcnt;              // [RR_WAVES][pcw]
+            int pcw = CNT_WORDS;
+            if (wide) {
+                __syncthreads();                // every wave has finished reading the exchange buffer (previous pass's key exchange)
+                pcnt = reinterpret_cast<uint32_t *>(xbuf);
+                pcw = RR_WIDE_WORDS;
+            }
+            uint32_t *mycnt = pcnt + wave * pcw;
+            const uint32_t cb = lds_off(mycnt);                             // this wave's digit counters, byte address
+#pragma unroll
+            for (int j = 0; j < CNT_WORDS / WAVE; j++) mycnt[j * WAVE + lane] = 0;
+            if (wide) {
+#pragma unroll
+                for (int j = CNT_WORDS / WAVE; j < RR_WIDE_WORDS / WAVE; j++) mycnt[j * WAVE + lane] = 0;
+            }
+            // HWORD digit split: low wlo bits = counter word, the rest (0 or 1 bit) = half
+            [[maybe_unused]] const uint32_t wcap = wide ? 11u : 10u, wlo = (uint32_t)nbits < wcap ? (uint32_t)nbits : wcap,
+                                            whi = (uint32_t)nbits - wlo, hshift = (uint32_t)(shift + (int)wlo) & 31u;
+            if constexpr (HWORD) {
+                uint32_t hr[RR_GH], hs[RR_GH], hg[RR_GH];
+                RRRankHW<ITEMS, PEEL>::run(ir, key, hr, hs, hg, (uint32_t)shift, hshift, wlo, whi, cb, lane, p == NPASS - 1);
+            }
+            else RRRank<ITEMS>::run(ir, key, shift, lane, cb);
+            lds_wait();
+            RR_T(1)
+            __syncthreads();
+            if (SE_RR_PF == 3) { RR_PREFETCH_NEXT_ROW() }
+            // ---- S: counters -> first destination of every (wave, digit) ----
+            if constexpr (!HWORD) {
+            uint32_t ex = 0;
+            if (tid < RK_NB) {
+                uint32_t run = 0;
+#pragma unroll
+                for (int w = 0; w < RR_WAVES; w++) run += wcnt[w * RK_NB + tid];
+                uint32_t wtot;
+                ex = wave_excl_scan(run, wtot);
+                if (lane == 63) wave_tot[wave] = wtot;
+            }
+            __syncthreads();
+            if (tid < RK_NB) {   // (the per-wave counts are re-read rather than kept in 8 registers across the barrier)
+                for (int w = 0; w < wave; w++) ex += wave_tot[w];
+#pragma unroll
+                for (int w = 0; w < RR_WAVES; w++) {
+                    const uint32_t c = wcnt[w * RK_NB + tid];
+                    wcnt[w * RK_NB + tid] = ex;
+                    ex += c;
+                }
+            }
+            } else {
+                // 8 waves x pcw words of 16-bit counts, two per word (low half: digit w, high half: digit pcw + w).  Thread t owns the
+                // words 2t and 2t+1 of every wave (one 8-byte LDS access each; the 12-bit pass: also 1024 + 2t and 1025 + 2t) and all
+                // arithmetic stays PACKED: a half never exceeds the 53,248 keys of a row, so the low halves cannot carry into the high ones.
+                const bool scanner = tid < RR_SCAN_THREADS;   // (with 768 threads the last 4 waves only take part in the barriers)
+                const int st = scanner ? tid : 0;
+                uint32_t T0 = 0, T1 = 0, U0 = 0, U1 = 0;   // per-word totals over the waves (U: second word group of the wide pass)
+#pragma unroll
+                for (int w = 0; w < RR_WAVES; w++) {
+                    const uint2 v = *reinterpret_cast<const uint2 *>(pcnt + w * pcw + 2 * st);
+                    T0 += v.x; T1 += v.y;
+                }
+                if (wide) {
+                    __builtin_amdgcn_sched_barrier(0);   // one word group at a time: 2 x ITEMS registers are live across the scan
+#pragma unroll
+                    for (int w = 0; w < RR_WAVES; w++) {
+                        const uint2 v = *reinterpret_cast<const uint2 *>(pcnt + w * pcw + CNT_WORDS + 2 * st);
+                        U0 += v.x; U1 += v.y;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                uint32_t wtot, wtot2 = 0, ex2 = 0;
+                uint32_t ex = wave_excl_scan(T0 + T1, wtot);   // both halves scanned at once
+                if (wide) ex2 = wave_excl_scan(U0 + U1, wtot2);
+                if (scanner && lane == 63) { wave_tot[wave] = wtot; wave_tot[RR_SCAN_WAVES + wave] = wtot2; }
+                __syncthreads();
+                uint32_t all = 0, all2 = 0;
+#pragma unroll
+                for (int w = 0; w < RR_SCAN_WAVES; w++) {
+                    const uint32_t wt = wave_tot[w], wt2 = wave_tot[RR_SCAN_WAVES + w];
+                    all += wt; all2 += wt2;
+                    ex += (w < wave) ? wt : 0u;
+                    ex2 += (w < wave) ? wt2 : 0u;
+                }
+                ex2 += all;                        // the second word group follows the whole first group
+                const uint32_t hi = (all + all2) << 16;   // the high-half digits follow ALL low-half digits
+                ex += hi; ex2 += hi;
+                // digit-major / wave-minor: counts -> first destination of (wave, digit), written back in place
+                if (scanner) {
+                uint32_t s0 = ex, s1 = ex + T0;
+#pragma unroll
+                for (int w = 0; w < RR_WAVES; w++) {
+                    uint2 *wp = reinterpret_cast<uint2 *>(pcnt + w * pcw + 2 * tid);
+                    const uint2 v = *wp;
+                    *wp = make_uint2(s0, s1);
+                    s0 += v.x; s1 += v.y;
+                }
+                if (wide) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    s0 = ex2; s1 = ex2 + U0;
+#pragma unroll
+                    for (int w = 0; w < RR_WAVES; w++) {
+                        uint2 *wp = reinterpret_cast<uint2 *>(pcnt + w * pcw + CNT_WORDS + 2 * tid);
+                        const uint2 v = *wp;
+                        *wp = make_uint2(s0, s1);
+                        s0 += v.x; s1 += v.y;
+                    }
+                }
+                }
+            }
+            __syncthreads();
+            RR_T(2)
+            // L2 prefetch of this workgroup's NEXT row (one workgroup per CU: nothing else hides its 200 KB of HBM latency): one dword
+            // per 128-byte line, all into one sink register that stays reserved until the loads after the pass loop have been waited for.
+            // SE_RR_PF (build-time tuning aid): 0 = no prefetch, 1 = before the destination phase of the last pass (default), 2 = after it, 3 = before its scan
+            if (SE_RR_PF == 1) { RR_PREFETCH_NEXT_ROW() }
+            // ---- X: destinations, then the 2-byte exchanges ----
+#pragma unroll
+            for (int s0 = 0; s0 < ITEMS; s0 += 8) {
+                uint32_t first[8];
+#pragma unroll
+                for (int g = 0; g < 8; g++)
+                    if (s0 + g < ITEMS) {
+                        if constexpr (HWORD) first[g] = reinterpret_cast<const uint16_t *>(mycnt)[(__builtin_amdgcn_ubfe(key[s0 + g], (uint32_t)shift, wlo) << 1) | __builtin_amdgcn_ubfe(key[s0 + g], hshift, whi)];
+                        else first[g] = mycnt[(key[s0 + g] >> shift) & 0xFFu];
+                    }
+#pragma unroll
+                for (int g = 0; g < 8; g++)
+                    if (s0 + g < ITEMS) {
+                        ir[s0 + g] += first[g];   // low half: rank -> destination (< 65536)
+                        opaque(ir[s0 + g]);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (SE_RR_PF == 2) { RR_PREFETCH_NEXT_ROW() }
+            if (wide) __syncthreads();   // the scatter below overwrites the (aliased) counters other waves may still be looking up
+            RR_T(3)
+#pragma unroll
+            for (int s = 0; s < ITEMS; s++) { opaque(ir[s]); lds_st16_hi(RR_DST(ir[s]), ir[s]); }           // index
+            lds_wait();
+            __syncthreads();
+            RR_T(4)
+            if (end >= 32) break;   // last pass: the index buffer is the ranking
+            RRRead<ITEMS, true>::run(ir, ring, rb);
+            lds_wait();
+            __syncthreads();
+            RR_T(5)
+#pragma unroll
+            for (int s = 0; s < ITEMS; s++) { opaque(ir[s]); lds_st16_hi(RR_DST(ir[s]), key[s]); }          // key bits 16-31  (opaque: no cached addresses)
+            lds_wait();
+            __syncthreads();
+            RRRead<ITEMS, true>::run(key, ring, rb);
+            lds_wait();
+            if (end < 16) {                                                              // key bits 0-15: still needed by a later pass
+                __syncthreads();
+#pragma unroll
+                for (int s = 0; s < ITEMS; s++) { opaque(ir[s]); lds_st16_lo(RR_DST(ir[s]), key[s]); }      // (low half is still the old key's)
+                lds_wait();
+                __syncthreads();
+                RRRead<ITEMS, false>::run(key, ring, rb);
+                lds_wait();
+            }
+            RR_T(6)
+            // (the next pass's barriers order these reads before its first exchange write)
+        }
+#undef RR_DST
+        rr_pass = -1;
+        // ---- the exchange buffer now holds the ranking: canonicalise the next row's keys (waits for its loads), then stream the ranks out ----
+        // (the loads sit after the pass loop, not inside its last iteration: a re-definition of the key registers on the `break` path makes
+        // hipcc copy all ITEMS index registers there, and a separate straight-line instance of the last pass -- measured, DESIGN.md 5.2 --
+        // pushes the 98-key build into scratch; the row was prefetched into L2 during the last pass.  They are issued BEFORE the rank
+        // stores and waited for after them: the memory pipeline serves them first and the write-out covers most of their latency.)
+        {
+            const float *drow = pdist + (more ? row + gridDim.x : row) * ldp;
+            int wpos = wpos0;
+            opaque(wpos);   // per-row opaque: otherwise hipcc hoists ITEMS row-invariant clamps out of the row loop and keeps them live
+#pragma unroll
+            for (int s = 0; s < ITEMS; s++) RR_LOAD_ONE(drow, wpos, s)
+        }
+        int wt = tid;
+        opaque(wt);   // per-row opaque: the write-out offsets are recomputed here instead of living (spilled) across the whole row loop
+        if (idx64) {
+            int64_t *o = (int64_t *)rank + row * ldr;
+            // (the next row's keys are live: no unrolling, the LDS read of the next step is issued before this step's stores instead)
+            uint2 nv = *reinterpret_cast<const uint2 *>(xbuf + (wt * 4 < N ? wt * 4 : 0));
+            _Pragma("unroll 1") for (int j = wt * 4; j < N; j += RR_THREADS * 4) {
+                const uint2 v = nv;
+                const int jn = j + RR_THREADS * 4;
+                nv = *reinterpret_cast<const uint2 *>(xbuf + (jn < N ? jn : 0));
+                const int64_t e0 = v.x & 0xFFFFu, e1 = v.x >> 16, e2 = v.y & 0xFFFFu, e3 = v.y >> 16;
+                if (vec_ok && j + 3 < N) {
+                    if (SE_RR_NT) {
+                        __builtin_nontemporal_store((rr_i64x2){e0, e1}, reinterpret_cast<rr_i64x2 *>(o + j));
+                        __builtin_nontemporal_store((rr_i64x2){e2, e3}, reinterpret_cast<rr_i64x2 *>(o + j + 2));
+                    } else {
+                        *reinterpret_cast<longlong2 *>(o + j) = make_longlong2(e0, e1);
+                        *reinterpret_cast<longlong2 *>(o + j + 2) = make_longlong2(e2, e3);
+                    }
+                } else {
+                    o[j] = e0;
+                    if (j + 1 < N) o[j + 1] = e1;
+                    if (j + 2 < N) o[j + 2] = e2;
+                    if (j + 3 < N) o[j + 3] = e3;
+                }
+            }
+        } else {
+            int32_t *o = (int32_t *)rank + row * ldr;
+            uint2 nv = *reinterpret_cast<const uint2 *>(xbuf + (wt * 4 < N ? wt * 4 : 0));
+            _Pragma("unroll 1") for (int j = wt * 4; j < N; j += RR_THREADS * 4) {
+                const uint2 v = nv;
+                const int jn = j + RR_THREADS * 4;
+                nv = *reinterpret_cast<const uint2 *>(xbuf + (jn < N ? jn : 0));
+                const int e0 = v.x & 0xFFFFu, e1 = v.x >> 16, e2 = v.y & 0xFFFFu, e3 = v.y >> 16;
+                if (vec_ok && j + 3 < N) {
+                    if (SE_RR_NT) __builtin_nontemporal_store((rr_i32x4){e0, e1, e2, e3}, reinterpret_cast<rr_i32x4 *>(o + j));
+                    else *reinterpret_cast<int4 *>(o + j) = make_int4(e0, e1, e2, e3);
+                } else {
+                    o[j] = e0;
+                    if (j + 1 < N) o[j + 1] = e1;
+                    if (j + 2 < N) o[j + 2] = e2;
+                    if (j + 3 < N) o[j + 3] = e3;
+                }
+            }
+        }
+        RR_T(7)
+        RR_CANON()
+        if constexpr (PROF) {   // keep the canonicalisation (and with it the wait for the loads) inside the 'load' interval of the phase profile
+            _Pragma("unroll") for (int s = 0; s < ITEMS; s++) opaque(key[s]);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf_sink) : : "memory");   // prefetch dwords landed too: the sink register is free again, nothing is outstanding
+        RR_T(0)
+        // (the next row's pass-0 barriers order these reads before its first exchange write)
+    }
+    if (PROF && tid == 0)
+    {
+        for (int i = 0; i < 12; i++) atomicAdd(&prof[i], (unsigned long long)t_acc[i]);
+        for (int i = 0; i < 24; i++) atomicAdd(&prof[12 + i], (unsigned long long)t_pp[i]);
+    }
+#undef RR_T
+}
+
+}  // namespace se
+
+using namespace se;
+
+static int rank_grid(int64_t q)
+{
+    // resident workgroups of the tiled kernel: 256 CUs x 2 (512 threads, ~78 KB LDS each)
+    const int64_t g = 512;
+    return (int)(q < g ? q : g);
+}
+
+static int64_t rank_npad(int64_t n) { return (n + 63) / 64 * 64; }
+
+static bool rank_use_tiled(int64_t n)
+{
+    static const bool force = tuning_env("SE_RANK_TILED") != nullptr;   // -DSE_TUNING build only: always take the general kernel
+    return force || n > RR_MAX_N;
+}
+
+// Skew detector for the hardware-ordered variant: do the keys share their most significant 10-bit digit (e.g.
+// all-positive Euclidean distances: every lane of a wave step would hit ONE or two counters)?  Histogram of that
+// digit over 3 rows x 1024 evenly spaced columns; flag = 1 when one value holds >= 30 % of them.  The two kernel variants launched
+// behind it read the flag and the one it does not select returns immediately -- no host round trip.
+__global__ __launch_bounds__(256) void rank_skew_detect_kernel(const float *__restrict__ pdist, int64_t ldp, int64_t Q, int N,
+                                                               int shift, uint32_t *__restrict__ flag)
+{
+    constexpr int NBIN = 4096;   // values of the most significant digit: 1024 (10 bits, shift 22) or 4096 (12 bits, shift 20)
+    __shared__ uint32_t hist[NBIN];
+    __shared__ uint32_t best;
+    for (int i = threadIdx.x; i < NBIN; i += 256) hist[i] = 0;
+    if (threadIdx.x == 0) best = 0;
+    __syncthreads();
+    const int cols = N < 1024 ? N : 1024;
+    for (int r = 0; r < 3; r++) {
+        const int64_t row = (r == 0) ? 0 : (r == 1 ? Q / 2 : Q - 1);
+        const float *drow = pdist + row * ldp;
+        for (int i = threadIdx.x; i < cols; i += 256) atomicAdd(&hist[canon_key(drow[(int64_t)i * N / cols]) >> shift], 1u);
+    }
+    __syncthreads();
+    uint32_t mine = 0;
+    for (int i = threadIdx.x; i < NBIN; i += 256) mine = hist[i] > mine ? hist[i] : mine;
+    atomicMax(&best, mine);
+    __syncthreads();
+    // peeling pays from roughly a 30 % share of one digit (two-valued Euclidean rows: ~50 %; mixed-sign cosine rows: ~10 %)
+    if (threadIdx.x == 0) *flag = (10u * best >= 3u * 3u * (uint32_t)cols) ? 1u : 0u;
+}
+
+template <int ITEMS, bool HW, bool PEEL>
+static int launch_rank_reg_variant(const float *pdist, int64_t ldp, int64_t q, int n, void *rank, int idx64, int64_t ldr,
+                                   const uint32_t *skew_flag, hipStream_t s)
+{
+    const size_t cnt_words = HW ? (size_t)(1 << RR_HW_BITS) / 2 : (size_t)RK_NB;   // per wave (packed 16-bit vs 32-bit counters)
+    const size_t lds = (RR_WAVES * cnt_words + 32) * sizeof(uint32_t) + (size_t)RR_THREADS * ITEMS * sizeof(uint16_t);
+    static const bool profile = tuning_env("SE_RR_PROFILE") != nullptr;   // -DSE_TUNING build only: allocates, synchronises, prints
+    auto kern = (kTuning && profile) ? rank_rows_reg_kernel<ITEMS, kTuning && (ITEMS == 98), HW, PEEL> : rank_rows_reg_kernel<ITEMS, false, HW, PEEL>;
+    // per instantiation, computed once (thread-safe static initialisation): resident workgroups = CUs x occupancy
+    struct Resident { hipError_t err; int64_t grid; };
+    static const Resident res = [&]() -> Resident {
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        int dev = 0, occ = 0;
+        hipDeviceProp_t prop;
+        if (e == hipSuccess) e = hipGetDevice(&dev);
+        if (e == hipSuccess) e = hipGetDeviceProperties(&prop, dev);
+        if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)kern, RR_THREADS, lds);
+        if (e != hipSuccess) return {e, 0};
+        return {hipSuccess, (int64_t)(prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256) * (occ > 0 ? occ : 1)};
+    }();
+    if (res.err != hipSuccess) return fail(SE_ERR_HIP, "se_rank_rows: kernel set-up failed: %s", hipGetErrorString(res.err));
+    int64_t grid = res.grid;
+    if (grid > q) grid = q;
+    const size_t esz = idx64 ? 8 : 4;
+    const int vec_ok = ((((uintptr_t)rank) & 15) == 0) && ((ldr * esz) % 16 == 0);
+    unsigned long long *prof = nullptr;
+    if (profile && ITEMS == 98) {
+        SE_HIP_CHECK(hipMalloc((void **)&prof, 36 * sizeof(unsigned long long)));
+        SE_HIP_CHECK(hipMemsetAsync(prof, 0, 36 * sizeof(unsigned long long), s));
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(RR_THREADS), lds, s, pdist, ldp, q, n, rank, ldr, idx64, vec_ok, prof, skew_flag);
+    SE_LAUNCH_CHECK();
+    if (prof) {
+        unsigned long long h[36];
+        SE_HIP_CHECK(hipStreamSynchronize(s));
+        SE_HIP_CHECK(hipMemcpy(h, prof, sizeof(h), hipMemcpyDeviceToHost));
+        SE_HIP_CHECK(hipFree(prof));
+        static const char *names[8] = {"load", "rank", "scan", "dest", "idx-write", "idx-read", "key-exchange", "write-out"};
+        double tot = 0;
+        for (int i = 0; i < 8; i++) tot += (double)h[i];
+        if (tot > 0) {
+            fprintf(stderr, "[se_rank_rows profile] ITEMS=%d hw=%d peel=%d grid=%lld:", ITEMS, (int)HW, (int)PEEL, (long long)grid);
+            for (int i = 0; i < 8; i++) fprintf(stderr, " %s %.1f%%", names[i], 100.0 * (double)h[i] / tot);
+            fprintf(stderr, "  (%.0f cycles per row)\n[se_rank_rows profile] cycles per row by phase and pass:", tot / (double)q);
+            for (int i = 1; i < 7; i++) fprintf(stderr, " %s %.0f/%.0f/%.0f", names[i], (double)h[12 + 3 * i] / (double)q, (double)h[13 + 3 * i] / (double)q, (double)h[14 + 3 * i] / (double)q);
+            fprintf(stderr, "\n");
+        }
+    }
+    return SE_OK;
+}
+
+// hw: hardware-ordered variant allowed (capability probe passed).  scratch: >= 256 bytes of caller workspace or NULL;
+// with scratch the skew detector picks between the plain and the group-peeling hardware-ordered kernels.
+template <int ITEMS>
+static int launch_rank_reg(const float *pdist, int64_t ldp, int64_t q, int n, void *rank, int idx64, int64_t ldr, bool hw, void *scratch,
+                           hipStream_t s)
+{
+    if (!hw) return launch_rank_reg_variant<ITEMS, false, false>(pdist, ldp, q, n, rank, idx64, ldr, nullptr, s);
+    static const char *force = tuning_env("SE_RANK_PEEL");   // -DSE_TUNING build only: "0" / "1" pins the variant
+    if (force || !scratch) {
+        if (force && force[0] == '1') return launch_rank_reg_variant<ITEMS, true, true>(pdist, ldp, q, n, rank, idx64, ldr, nullptr, s);
+        return launch_rank_reg_variant<ITEMS, true, false>(pdist, ldp, q, n, rank, idx64, ldr, nullptr, s);
+    }
+    uint32_t *flag = (uint32_t *)scratch + 16;   // (words 0-1 belong to the capability probe)
+    // first bit of the most significant digit: 20 for the instantiations whose last pass is 12 bits wide (see WIDE in the kernel), else 22
+    const int top_shift = ((size_t)RR_THREADS * ITEMS * sizeof(uint16_t) >= (size_t)RR_WAVES * RR_WIDE_WORDS * sizeof(uint32_t)) ? 20 : 2 * RR_HW_BITS;
+    hipLaunchKernelGGL(rank_skew_detect_kernel, dim3(1), dim3(256), 0, s, pdist, ldp, q, n, top_shift, flag);
+    SE_LAUNCH_CHECK();
+    int rc = launch_rank_reg_variant<ITEMS, true, false>(pdist, ldp, q, n, rank, idx64, ldr, flag, s);
+    if (rc != SE_OK) return rc;
+    return launch_rank_reg_variant<ITEMS, true, true>(pdist, ldp, q, n, rank, idx64, ldr, flag, s);
+}
+
+// ---- capability probe for the hardware-ordered ranking --------------------------------------------------
+// Every wave of 64 workgroups issues returning LDS adds under four conflict patterns (one address, 4, 16,
+// 256 addresses) while its 7 sibling waves do the same, and compares each returned value with the stable rank
+// computed by the ballot multisplit -- first with 32-bit counters and one add at a time, then the way the production kernel
+// uses them: packed 16-bit halves of a shared word and eight adds in flight per lane.  res[0] = mismatches, res[1] = waves that reported.
+constexpr int RR_PROBE_BLOCKS = 64, RR_PROBE_STEPS = 48;
+__global__ __launch_bounds__(RR_THREADS) void rank_order_probe_kernel(uint32_t *res)
+{
+    __shared__ uint32_t cnt[RR_WAVES][RK_NB], ref[RR_WAVES][RK_NB];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = lane; i < RK_NB; i += WAVE) { cnt[wave][i] = 0; ref[wave][i] = 0; }
+    __syncthreads();
+    const uint32_t cb = lds_off(&cnt[wave][0]);
+    uint32_t bad = 0, seed = (blockIdx.x * RR_THREADS + threadIdx.x) * 2654435761u + 12345u;
+    const int mode = blockIdx.x & 3;
+    for (int s = 0; s < RR_PROBE_STEPS; s++) {
+        seed = seed * 1664525u + 1013904223u;
+        const uint32_t rnd = seed >> 24;
+        const uint32_t d = mode == 0 ? 7u : mode == 1 ? (rnd & 3u) : mode == 2 ? (rnd & 15u) * 16u : rnd;
+        uint32_t got;
+        const uint32_t ca = cb + (d << 2), one = 1u;
+        asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(got) : "v"(ca), "v"(one) : "memory");
+        uint32_t dlo, dhi;
+        differ_mask(d, dlo, dhi);
+        const uint32_t rnk = (uint32_t)lane - __builtin_amdgcn_mbcnt_hi(dhi, __builtin_amdgcn_mbcnt_lo(dlo, 0u));
+        const uint32_t want = ref[wave][d] + rnk;
+        if (rnk == 0) ref[wave][d] += 64u - (uint32_t)(__popc(dlo) + __popc(dhi));   // one lane per digit group
+        bad += (got != want);
+    }
+    // ---- the same property under PRODUCTION conditions: packed 16-bit counter halves (increment 1 or 1 << 16 on the shared word),
+    // eight returning adds in flight per lane before the first result is looked at, all eight waves hammering their tables ----
+    __syncthreads();
+    for (int i = lane; i < RK_NB; i += WAVE) { cnt[wave][i] = 0; ref[wave][i] = 0; }   // ref: low half = expected count of (word, half 0), high half = of half 1
+    __syncthreads();
+    for (int batch = 0; batch < 6; batch++) {
+        uint32_t got[8], dw[8], dh[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            seed = seed * 1664525u + 1013904223u;
+            const uint32_t rnd = seed >> 23;
+            dw[j] = mode == 0 ? 7u : mode == 1 ? (rnd & 3u) : mode == 2 ? (rnd & 15u) * 16u : (rnd & 255u);
+            dh[j] = (rnd >> 8) & 1u;
+            const uint32_t ca = cb + (dw[j] << 2), inc = dh[j] ? 0x10000u : 1u;
+            asm volatile("ds_add_rtn_u32 %0, %1, %2" : "=v"(got[j]) : "v"(ca), "v"(inc) : "memory");   // no wait: 8 in flight
+        }
+        lds_wait_le<0>(got[0]);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            opaque(got[j]);
+            uint32_t dlo, dhi;
+            differ_mask(dw[j], dlo, dhi);
+            const uint64_t hb = __ballot(dh[j] != 0);
+            const uint64_t hdiff = dh[j] ? ~hb : hb;                                  // lanes whose half differs from mine
+            dlo |= (uint32_t)hdiff; dhi |= (uint32_t)(hdiff >> 32);
+            const uint32_t rnk = (uint32_t)lane - __builtin_amdgcn_mbcnt_hi(dhi, __builtin_amdgcn_mbcnt_lo(dlo, 0u));
+            const uint32_t packed = ref[wave][dw[j]];
+            const uint32_t want = (dh[j] ? (packed >> 16) : (packed & 0xFFFFu)) + rnk;
+            const uint32_t mine = dh[j] ? (got[j] >> 16) : (got[j] & 0xFFFFu);
+            bad += (mine != want);
+            __builtin_amdgcn_s_barrier();   // (every lane has read ref before the group leaders update it; whole workgroup in lockstep)
+            if (rnk == 0) atomicAdd(&ref[wave][dw[j]], (64u - (uint32_t)(__popc(dlo) + __popc(dhi))) << (dh[j] ? 16 : 0));
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) bad += __shfl_xor(bad, off, 64);
+    if (lane == 0) { atomicAdd(&res[0], bad); atomicAdd(&res[1], 1u); }
+}
+
+// 1 = the hardware-ordered kernel may be used on the current device, 0 = it may not.  The first call per device
+// runs the probe (needs 256 bytes of caller workspace, synchronises the stream once); SE_RANK_SAFE=1 forces 0.
+static int rank_hw_order_ok(void *workspace, int64_t workspace_bytes, hipStream_t s)
+{
+    static const bool forced_safe = getenv("SE_RANK_SAFE") != nullptr;
+    if (forced_safe) return 0;
+    static std::atomic<int> state[64];   // per device: 0 unknown, 1 verified, -1 refuted (zero-initialised; two threads racing here
+                                         // both run the probe on their own workspace and store the same verdict)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    if (state[dev].load(std::memory_order_acquire) == 0) {
+        if (!workspace || workspace_bytes < 256) return 0;   // cannot probe without scratch: stay on the safe kernel
+        uint32_t *res = (uint32_t *)workspace, h[2] = {1u, 0u};
+        if (hipMemsetAsync(res, 0, 8, s) != hipSuccess) return 0;
+        hipLaunchKernelGGL(rank_order_probe_kernel, dim3(RR_PROBE_BLOCKS), dim3(RR_THREADS), 0, s, res);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(s) != hipSuccess ||
+            hipMemcpy(h, res, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess)
+            return 0;
+        const int verdict = (h[0] == 0u && h[1] == (uint32_t)(RR_PROBE_BLOCKS * RR_WAVES)) ? 1 : -1;
+        state[dev].store(verdict, std::memory_order_release);
+        if (getenv("SE_RANK_VERBOSE"))
+            fprintf(stderr, "[se_rank_rows] LDS returning-add order probe on device %d: %u mismatches, %u waves -> %s kernel\n", dev,
+                    h[0], h[1], verdict == 1 ? "hardware-ordered" : "ballot");
+    }
+    return state[dev].load(std::memory_order_acquire) == 1;
+}
+
+extern "C" int64_t se_rank_rows_workspace_bytes(int64_t q, int64_t n)
+{
+    if (q <= 0 || n <= 0) return 0;
+    if (!rank_use_tiled(n)) return 256;   // register-resident kernel: only the first-use capability probe writes here
+    return (int64_t)rank_grid(q) * 4 * rank_npad(n) * (int64_t)sizeof(uint32_t);
+}
+
+extern "C" int se_rank_rows(const float *pdist, int64_t ldp, int64_t q, int64_t n, void *rank, int idx64,
+                            int64_t ldr, void *workspace, int64_t workspace_bytes, se_stream_t stream)
+{
+    if (q < 0 || n < 0 || n > 0x7FFFFFFFll) return fail(SE_ERR_INVALID, "se_rank_rows: bad shape q=%lld n=%lld", (long long)q, (long long)n);
+    if (q == 0 || n == 0) return SE_OK;
+    if (!pdist || !rank || ldp < n || ldr < n) return fail(SE_ERR_INVALID, "se_rank_rows: bad argument");
+    hipStream_t s = (hipStream_t)stream;
+    if (!rank_use_tiled(n)) {
+        const int items = (int)((n + RR_THREADS - 1) / RR_THREADS);
+        const bool hw = rank_hw_order_ok(workspace, workspace_bytes, s) != 0;
+        void *scratch = (workspace && workspace_bytes >= 256) ? workspace : nullptr;
+#define SE_RR_CASE(I) if (items <= I) return launch_rank_reg<I>(pdist, ldp, q, (int)n, rank, idx64, ldr, hw, scratch, s);
+#if SE_RR_THREADS == 512
+        SE_RR_CASE(2) SE_RR_CASE(8) SE_RR_CASE(20) SE_RR_CASE(40) SE_RR_CASE(64) SE_RR_CASE(80) SE_RR_CASE(98) SE_RR_CASE(104)
+#else
+        SE_RR_CASE(2) SE_RR_CASE(6) SE_RR_CASE(14) SE_RR_CASE(28) SE_RR_CASE(44) SE_RR_CASE(56) SE_RR_CASE(66) SE_RR_CASE(70)
+#endif
+#undef SE_RR_CASE
+    }
+    const int64_t need = (int64_t)rank_grid(q) * 4 * rank_npad(n) * (int64_t)sizeof(uint32_t);
+    if (!workspace || workspace_bytes < need) return fail(SE_ERR_WORKSPACE, "se_rank_rows: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)need);
+    const size_t lds = sizeof(RankLds);
+    if (idx64) {
+        SE_HIP_CHECK(hipFuncSetAttribute((const void *)rank_rows_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(rank_rows_kernel<true>, dim3((unsigned)rank_grid(q)), dim3(RK_THREADS), lds, s, pdist, ldp, q, (int)n, rank, ldr, (uint32_t *)workspace, rank_npad(n));
+    } else {
+        SE_HIP_CHECK(hipFuncSetAttribute((const void *)rank_rows_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(rank_rows_kernel<false>, dim3((unsigned)rank_grid(q)), dim3(RK_THREADS), lds, s, pdist, ldp, q, (int)n, rank, ldr, (uint32_t *)workspace, rank_npad(n));
+    }
+    SE_LAUNCH_CHECK();
+    return SE_OK;
+}

@@ -3,7 +3,7 @@
 set -u
 OUT=gpurun_out/${1:-rrab}
 mkdir -p $OUT
-for v in 768 default; do
+for v in default; do
   if [ "$v" = "default" ]; then unset SEHIP_LIB; else export SEHIP_LIB=$PWD/semantic-embeddings_amd/sehip/libsehip_rr_$v.so; fi
   echo "=== variant $v" | tee -a $OUT/ab.log
   ( timeout 600 python -m pytest tests/test_gpu_retrieval.py -q -x -k "rank or full_size or benchmarked or golden" 2>&1 | tail -3 ) | tee -a $OUT/ab.log
