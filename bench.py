@@ -61,7 +61,7 @@ def parse(argv=None):
     ap.add_argument("--d", type=int, default=100, help="feature dimension (retrieval)")
     ap.add_argument("--metric", default="cosine", choices=["cosine", "euclid"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-queries", type=int, default=24576, help="query rows of the timed CPU sample (~10-20 s of host work)")
+    ap.add_argument("--cpu-sample-queries", type=int, default=16384, help="query rows of the timed CPU sample (~13 s of host work, ~10 GB of host memory)")
     ap.add_argument("--with-train", dest="with_train", action="store_true", default=True,
                     help="also time the ResNet-110-fc and ResNet-50 training steps (adds 'train' / 'train_r50' objects; default on)")
     ap.add_argument("--no-train", dest="with_train", action="store_false")
