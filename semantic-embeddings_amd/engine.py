@@ -216,13 +216,15 @@ class Trainer(object):
             mean = li.mean()
             total = mean * weight if total is None else total + mean * weight
             key = 'loss' if len(self.losses) == 1 else name + '_loss'
-            logs[key] = logs.get(key, 0) + mean.detach()
+            nrows = int(li.shape[0])          # logs accumulate SUMS over samples (Keras weights every batch by its size); '_n' counts them
+            logs[key] = logs.get(key, 0) + mean.detach() * nrows
             for m in self.metrics.get(name, ()):
                 mname = m.name if len(self.losses) == 1 else '{}_{}'.format(name, m.name)
                 with torch.no_grad():
-                    logs[mname] = logs.get(mname, 0) + m(yt, m_in).float().mean()
+                    logs[mname] = logs.get(mname, 0) + m(yt, m_in).float().sum()
         if len(self.losses) > 1:
-            logs['loss'] = logs.get('loss', 0) + total.detach()
+            logs['loss'] = logs.get('loss', 0) + total.detach() * nrows
+        logs['_n'] = logs.get('_n', 0) + nrows
         return total
 
     def train_step(self, X, y, logs):
@@ -296,7 +298,7 @@ class Trainer(object):
                 self._eager_core(self._sX, sy, eager_logs)
                 ref_norm = float(torch.linalg.vector_norm(ref))
                 noise = float(torch.linalg.vector_norm(self.flat.flat_g - ref)) / max(ref_norm, 1e-30)
-                eager_loss = float(eager_logs.get('loss', self._g_loss))
+                eager_loss = float(eager_logs['loss']) / max(float(eager_logs.get('_n', 1)), 1.0) if 'loss' in eager_logs else float(self._g_loss)
                 self.graph_validation = {'eager_noise': noise, 'replay_error': []}
                 for r in range(validate):
                     ga.replay()
@@ -383,8 +385,8 @@ class Trainer(object):
         gb.replay()
         self.iterations += 1
         self._graph_steps += 1
-        for k, v in self._g_logs.items():      # static device scalars written by graph A
-            logs[k] = logs.get(k, 0) + v.clone()
+        for k, v in self._g_logs.items():      # static device scalars written by graph A (sums over the batch) and its row count
+            logs[k] = logs.get(k, 0) + (v.clone() if torch.is_tensor(v) else v)
         if self._graph_steps % 256 == 0 and not bool(torch.isfinite(self._g_loss)):     # one host sync per 256 steps
             raise FloatingPointError('non-finite loss in HIP-graph replay %d (diverged training, or a replay fault: '
                                      'rerun with SE_TRAIN_GRAPHS=0 to tell)' % self._graph_steps)
@@ -422,17 +424,32 @@ class Trainer(object):
 
     # ---------------------------------------------------------------- loops
 
-    def _reduce_logs(self, logs, n):
+    def regularization_loss(self):
+        """Sum of the L2 kernel penalties (``lam * |w|^2``) at the current weights -- Keras adds them to every reported ``loss`` /
+        ``val_loss`` (what ReduceLROnPlateau and --snapshot_best observe)."""
+        flat = self.flat
+        if not flat.has_l2:
+            return 0.0
+        return float(0.5 * torch.dot(flat.flat_l2, flat.flat_p * flat.flat_p))     # flat_l2 holds 2 lam
+
+    def _reduce_logs(self, logs, n=None):
+        """Per-sample means of the accumulated sums (``logs['_n']`` samples on this rank), summed over the ranks: every sample
+        counts once whatever the batch / shard sizes.  ``loss`` gets the L2 penalties of the current weights added like Keras
+        reports it (for the training loss of an epoch this is the penalty at the epoch's end, not its running average)."""
         out = {}
-        if not logs:
+        keys = sorted(k for k in logs if k != '_n')
+        if not keys:
             return out
-        keys = sorted(logs)
-        vec = torch.stack([torch.as_tensor(logs[k], dtype=torch.float32, device=self.flat.flat_p.device) for k in keys]) / max(n, 1)
+        dev = self.flat.flat_p.device
+        vec = torch.stack([torch.as_tensor(logs[k], dtype=torch.float32, device=dev) for k in keys]
+                          + [torch.as_tensor(float(logs.get('_n', 0)), dtype=torch.float32, device=dev)])
         if self.world > 1:
             dist.all_reduce(vec, op=dist.ReduceOp.SUM)
-            vec /= self.world
-        for k, v in zip(keys, vec.tolist()):
+        count = max(float(vec[-1].item()), 1.0)
+        for k, v in zip(keys, (vec[:-1] / count).tolist()):
             out[k] = v
+        if 'loss' in out:
+            out['loss'] += self.regularization_loss()
         return out
 
     def evaluate(self, seq):
@@ -444,7 +461,7 @@ class Trainer(object):
                 self._loss_and_metrics(self._forward(X), y, logs)
                 n += 1
         self.model.train()
-        return self._reduce_logs(logs, n)
+        return self._reduce_logs(logs)
 
     def predict(self, seq, steps=None, to_host=True):
         """Model outputs for every batch of ``seq`` (rank-local rows), concatenated: NumPy arrays on the host (``to_host``, what
@@ -491,7 +508,7 @@ class Trainer(object):
                     print('\rEpoch {}/{} - batch {}/{} - {:.1f} img/s'.format(
                         epoch + 1, epochs, b + 1, nb, (b + 1) * train_seq.batch_size / (time.time() - t0)), end='', flush=True)
             train_seq.on_epoch_end()
-            ep_logs = self._reduce_logs(logs, nb)
+            ep_logs = self._reduce_logs(logs)
             if validation_data is not None:
                 ep_logs.update({'val_' + k: v for k, v in self.evaluate(validation_data).items()})
             for cb in callbacks:

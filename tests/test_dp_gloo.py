@@ -44,9 +44,9 @@ def _dp_worker(rank, world, port, out):
     logs = {}
     for _ in range(4):
         tr.train_step(X[rank::world], Y[rank::world], logs)
-    red = tr._reduce_logs(logs, 4)
-    if rank == 0:
-        torch.save({"state": model.state_dict(), "loss": red["loss"]}, out)
+    red = tr._reduce_logs(logs)
+    if rank == 0:     # (the reported loss carries the L2 penalty of the current weights, like Keras' does)
+        torch.save({"state": model.state_dict(), "loss": red["loss"] - tr.regularization_loss(), "reg": tr.regularization_loss()}, out)
     dist.destroy_process_group()
 
 
@@ -65,7 +65,8 @@ def test_dp_matches_single_process_on_the_concatenated_batch(tmp_path):
         tr.train_step(X, Y, logs)
     for k, v in model.state_dict().items():
         assert torch.allclose(v, got["state"][k], atol=1e-6), k
-    assert float(logs["loss"]) / 4 == pytest.approx(got["loss"], rel=1e-5)
+    assert float(logs["loss"]) / float(logs["_n"]) == pytest.approx(got["loss"], rel=1e-5)
+    assert got["reg"] == pytest.approx(1e-3 * float((model[0].weight ** 2).sum()), rel=1e-5) and got["reg"] > 0
 
 
 def _topk_worker(rank, world, port, out):
@@ -242,3 +243,55 @@ def test_evaluate_retrieval_main_is_rank_aware(monkeypatch):
     assert er.init_distributed() == (0, 1)
     src = open(er.__file__).read()
     assert "distributed=world > 1" in src and "if rank != 0:" in src
+
+
+def _two_trainers_worker(rank, world, port, out):
+    """The --finetune flow (learn_image_embeddings.py:183-207): a first trainer on the new layers only, then a second one on the whole
+    model.  The first one's gradient hooks must be gone (Trainer.close) -- otherwise they all-reduce a dead buffer on every backward
+    of the second -- and uneven shards (3 + 2 rows) must be averaged per SAMPLE."""
+    _setup(rank, world, port)
+    import engine
+    model = _make_model()
+    g = torch.Generator().manual_seed(2)
+    X, Y = torch.randn(5, 6, generator=g), torch.randn(5, 4, generator=g)
+    pre = engine.Trainer(model, {"o": (_loss, 1.0)}, {}, lr=0.05, momentum=0.0, autocast_dtype=None, trainable=lambda n: n.startswith("2."))
+    pre.train_step(X[rank::world], Y[rank::world], {})
+    pre.close()
+    assert pre.reducer.hook_handles == [] and not pre.reducer.enabled
+    for p in model.parameters():
+        p.requires_grad_(True)
+    calls = []
+    orig = dist.all_reduce
+    dist.all_reduce = lambda t, *a, **k: (calls.append(t.data_ptr()), orig(t, *a, **k))[1]
+    tr = engine.Trainer(model, {"o": (_loss, 1.0)}, {}, lr=0.05, momentum=0.0, autocast_dtype=None)
+    logs = {}
+    tr.train_step(X[rank::world], Y[rank::world], logs)
+    dist.all_reduce = orig
+    lo_, hi_ = tr.flat.flat_g.data_ptr(), tr.flat.flat_g.data_ptr() + tr.flat.total * 4
+    assert calls and all(lo_ <= c < hi_ for c in calls), "an all-reduce touched a buffer of the closed trainer"
+    red = tr._reduce_logs(logs)
+    if rank == 0:
+        torch.save({"loss": red["loss"], "n": float(logs["_n"])}, out)
+    dist.destroy_process_group()
+
+
+def test_second_trainer_after_close_and_per_sample_log_weighting(tmp_path):
+    out = str(tmp_path / "two.pt")
+    mp.spawn(_two_trainers_worker, args=(2, 29619, out), nprocs=2, join=True)
+    got = torch.load(out)
+    import engine
+    model = _make_model()
+    g = torch.Generator().manual_seed(2)
+    X, Y = torch.randn(5, 6, generator=g), torch.randn(5, 4, generator=g)
+    pre = engine.Trainer(model, {"o": (_loss, 1.0)}, {}, lr=0.05, momentum=0.0, autocast_dtype=None, trainable=lambda n: n.startswith("2."))
+    # the data-parallel pre-step averages the two shard MEANS (3 and 2 rows), like every DP step does; reproduce that weighting here
+    o = model(X)
+    per = _loss(Y, o)
+    (0.5 * (per[0::2].mean() + per[1::2].mean())).backward()
+    with torch.no_grad():
+        for n_, p in model.named_parameters():
+            if n_.startswith("2."):
+                p -= 0.05 * p.grad
+            p.grad = None
+    want = float(_loss(Y, model(X)).mean())            # per-SAMPLE mean over all five rows
+    assert got["n"] == 3.0 and got["loss"] == pytest.approx(want, rel=1e-5)
