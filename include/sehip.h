@@ -237,15 +237,35 @@ int se_retrieve_topk(const float *queries, int64_t ldq, const float *gallery, in
  *   wup, lcs  [C, C] f64 class similarity tables (Wu-Palmer, 1 - LCS height / max height)
  *   best_*    [C, ldb] f64: for query class c, cumulative sum of the descending-sorted similarities of the
  *             WHOLE gallery to c (class_hierarchy.py:266,275) -- host-side, once per gallery
+ *   rcp       the same curves pre-divided for the kernel, from se_hprec_reciprocal_curves (once per gallery):
+ *             1 / (best[i] - 1) of both similarities -- the divisor of every rank behind the query, whose removal
+ *             shifts the curve and subtracts its self-similarity (class_hierarchy.py:280-290); rcp_len = the
+ *             list_len it was built for (>= this call's list_len).  Ranks ahead of the query divide by best_*.
  *   ks        [nk] int32 cut-offs; ahp_len: -1 no AHP, 0 whole list, K > 0 clipped AHP@K; want_ap: 0 / 1
  *   out       [q, 2 nk + 3] f64: P@k WUP x nk, P@k LCS x nk, AHP WUP, AHP LCS, AP (ldo elements between rows)
+ *   order_ws  NULL, or se_hprec_order_workspace_bytes(q) bytes of device scratch: the queries are then visited in
+ *             class order (one contiguous part of it per XCD), which keeps the best curve being streamed in L2.
+ *             The results do not depend on it.
  */
+int64_t se_hprec_order_workspace_bytes(int64_t q);
 int se_hierarchical_precision(const int32_t *rank, int64_t ldr, int64_t q, int64_t list_len,
                               const int32_t *cls, const int32_t *qcls, const int32_t *qidx,
                               const double *wup, const double *lcs, int num_classes,
                               const double *best_wup, const double *best_lcs, int64_t ldb,
+                              const double *rcp, int64_t rcp_len,
                               const int32_t *ks, int nk, int64_t ahp_len, int want_ap, double *out,
-                              int64_t ldo, se_stream_t stream);
+                              int64_t ldo, void *order_ws, se_stream_t stream);
+
+/*
+ * The best-possible curves of se_hierarchical_precision, pre-divided and laid out for its loads.
+ *   best_*    [num_classes, ldb] f64 as above; list_len positions of every row are used
+ *   rcp       [num_classes, se_hprec_curve_len(list_len), 2] f64 out: (1 / (best_wup[c][i] - 1), 1 / (best_lcs[c][i] - 1))
+ *             stored chunk-transposed (2048-position chunks, position 8 t + e of a chunk at slot 256 e + t) so that
+ *             the 256 threads of the metric kernel, each owning 8 consecutive ranks, read contiguous 16-byte pairs.
+ */
+int64_t se_hprec_curve_len(int64_t list_len);
+int se_hprec_reciprocal_curves(const double *best_wup, const double *best_lcs, int64_t ldb,
+                               int num_classes, int64_t list_len, double *rcp, se_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -296,6 +296,7 @@ class ClassHierarchy(object):
         import torch
         from sharded_retrieval import shard_bounds, sharded_topk
         kernels = dict(kernels or {})
+        native_metrics = 'hierarchical_precision' not in kernels
         if 'ranking_tiles' not in kernels or 'hierarchical_precision' not in kernels:
             import sehip
             from evaluate_retrieval import ranking_tiles
@@ -337,6 +338,13 @@ class ClassHierarchy(object):
         q0, q1 = shard_bounds(n, world)[rank] if world > 1 else (0, n)
         ncol = 2 * len(ks) + 3
         outs = []
+
+        def curves(args_d):     # the best curves pre-divided for se_hierarchical_precision (the CPU stand-ins of the tests divide themselves)
+            if not native_metrics:
+                return {}
+            import sehip
+            return {'curves': sehip.hprec_reciprocal_curves(args_d[2], args_d[3])}
+
         if world > 1 and head_only:
             # ---- sharded gallery: top-L lists are enough for every requested metric ----
             L = min(n, max(ks + [ahp_clip or 0]) + 1)
@@ -354,13 +362,15 @@ class ClassHierarchy(object):
                                     local_topk=kernels.get('local_topk'), merge=kernels.get('merge'))
             if q1 > q0:
                 outs.append(kernels['hierarchical_precision'](top_i[q0:q1].contiguous(), cls_d, cls_d[q0:q1].contiguous(),
-                                                             qidx_d[q0:q1].contiguous(), *args_d, ks_d, ahp_len=ahp_len, want_ap=False))
+                                                             qidx_d[q0:q1].contiguous(), *args_d, ks_d, ahp_len=ahp_len, want_ap=False,
+                                                             **curves(args_d)))
         else:
             args_d = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (wup_t, lcs_t, best_w, best_l)]
+            extra = curves(args_d)      # once per gallery, shared by every tile
             for r0, tile in kernels['ranking_tiles'](feats, normalize, tile_rows=tile_rows, queries=(q0, q1), kblocks=kblocks):
                 rows = tile.shape[0]
                 outs.append(kernels['hierarchical_precision'](tile, cls_d, cls_d[r0:r0 + rows].contiguous(), qidx_d[r0:r0 + rows].contiguous(),
-                                                             *args_d, ks_d, ahp_len=ahp_len, want_ap=compute_ap))
+                                                             *args_d, ks_d, ahp_len=ahp_len, want_ap=compute_ap, **extra))
         res_d = torch.cat(outs) if outs else torch.zeros((0, ncol), dtype=torch.float64, device=dev)
         sums = None
         if world > 1:

@@ -7,12 +7,21 @@
 // the descending-sorted similarities of the whole gallery, cumulated) are computed once on the host and passed in;
 // the 0.6 h the reference spends here at N = 50k is the gather + prefix sums over Q x N ranks, which is this kernel.
 //
-// One 256-thread workgroup per query walks its ranking in blocked chunks (thread t owns 8 consecutive ranks):
-// gather class -> similarity row (LDS), float64 running sums by a workgroup scan with a carry between chunks.
+// One 256-thread workgroup per query walks its ranking in 2048-rank chunks (thread t owns 8 consecutive ranks):
+// gather class -> similarity pair (LDS), float64 running sums by a DPP wave scan + one barrier per chunk (wave totals
+// double-buffered in LDS, the carry replicated in every thread), per-thread accumulation of the trapezoid / AP terms
+// (reduced once per query).  What the memory system sees, per rank: 4 B of the ranking (HBM, streamed), a 4-byte class
+// gather (L2) and 16 B of the query class's best curve.  The best curve enters as the pre-divided, chunk-transposed table
+// of `se_hprec_reciprocal_curves` -- 1 / (best[i] - 1) for both similarities, laid out so that a wave's loads are
+// contiguous -- which turns two float64 divisions per rank into two multiplications; and the queries are visited in class
+// order (`order_ws`: a counting sort of `qcls`, one contiguous segment of that order per XCD, handed out by per-XCD
+// atomic counters) so that the workgroups resident on an XCD stream the SAME 16 N-byte curve and it stays in that XCD's
+// 4 MB L2 instead of coming from HBM once per query.
 // Bookkeeping kept from the reference: the query itself is dropped from its ranking (position q_pos), which shifts
 // the best curve left there and subtracts its self-similarity 1.0 (class_hierarchy.py:280-290); AHP is numpy's
 // trapz of cum / best with dx = 1 / length; AP is the mean over the relevant ranks of precision at that rank.
-// float64 throughout; sums are associated differently from numpy's sequential cumsum (last-bits differences).
+// float64 throughout; sums are associated differently from numpy's sequential cumsum and cum / best is cum * (1 / best)
+// (last-bits differences; the tests hold the outputs to 1e-10 of the reference's).
 #include "se_common.h"
 
 namespace se {
@@ -22,33 +31,39 @@ constexpr int HP_WAVES = HP_THREADS / WAVE;
 constexpr int HP_ITEMS = 8;
 constexpr int HP_CHUNK = HP_THREADS * HP_ITEMS;
 constexpr int HP_MAX_KS = 512;
+constexpr int HP_WS_HEAD = 16;      // order_ws: [0, 8) per-XCD cursors, [16, 16 + q) the queries in class order
+constexpr int HP_ORDER_THREADS = 1024;
 
-struct HpCarry {
-    double cw, cl;       // running similarity sums (effective sequence, query skipped)
-    double yw, yl;       // running sum of cum / best (for the trapezoid)
-    double ap;           // running sum of precision at relevant ranks
-    long long rel;       // relevant items so far
-};
+// ---- DPP wave scans (no LDS traffic): Kogge-Stone inside the 16-lane rows, then the row totals by row_bcast ----
+template <int CTRL, int ROWS>
+__device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, ROWS, 0xf, true); }
+
+template <int CTRL, int ROWS>
+__device__ __forceinline__ double dpp_f64(double v)
+{
+    const int lo = dpp_i32<CTRL, ROWS>(__double2loint(v)), hi = dpp_i32<CTRL, ROWS>(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
 
 __device__ __forceinline__ double wave_incl_scan_f64(double v)
 {
-    const int lane = lane_id();
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const double t = __shfl_up(v, off, 64);
-        if (lane >= off) v += t;
-    }
+    v += dpp_f64<0x111, 0xf>(v);   // row_shr:1
+    v += dpp_f64<0x112, 0xf>(v);   // row_shr:2
+    v += dpp_f64<0x114, 0xf>(v);   // row_shr:4
+    v += dpp_f64<0x118, 0xf>(v);   // row_shr:8
+    v += dpp_f64<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
+    v += dpp_f64<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3
     return v;
 }
 
-__device__ __forceinline__ long long wave_incl_scan_i64(long long v)
+__device__ __forceinline__ int wave_incl_scan_i32(int v)
 {
-    const int lane = lane_id();
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const long long t = __shfl_up(v, off, 64);
-        if (lane >= off) v += t;
-    }
+    v += dpp_i32<0x111, 0xf>(v);
+    v += dpp_i32<0x112, 0xf>(v);
+    v += dpp_i32<0x114, 0xf>(v);
+    v += dpp_i32<0x118, 0xf>(v);
+    v += dpp_i32<0x142, 0xa>(v);
+    v += dpp_i32<0x143, 0xc>(v);
     return v;
 }
 
@@ -59,30 +74,113 @@ __device__ __forceinline__ double wave_sum_f64(double v)
     return v;
 }
 
+// 1 / x for x = 1 .. 2^31 (AP: precision at a relevant rank): v_rcp_f64 + two Newton steps instead of the IEEE division sequence
+__device__ __forceinline__ double fast_rcp_f64(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(r, fma(-x, r, 1.0), r);
+    r = fma(r, fma(-x, r, 1.0), r);
+    return r;
+}
+
+// slot of original position i inside a class row of the reciprocal table: chunk k = i / 2048, thread t = (i % 2048) / 8,
+// element e = i % 8  ->  (k * 8 + e) * 256 + t   (for a fixed e the 256 threads of a chunk read 256 consecutive double2)
+__device__ __host__ __forceinline__ int64_t hp_slot(int64_t i)
+{
+    const int64_t k = i / HP_CHUNK, p = i % HP_CHUNK;
+    return (k * HP_ITEMS + (p % HP_ITEMS)) * HP_THREADS + p / HP_ITEMS;
+}
+
+__global__ __launch_bounds__(HP_THREADS) void hprec_rcp_kernel(const double *__restrict__ bw, const double *__restrict__ bl, int64_t ldb,
+                                                               int64_t len, int64_t lp, double2 *__restrict__ out)
+{
+    const int64_t c = blockIdx.y;
+    for (int64_t i = (int64_t)blockIdx.x * HP_THREADS + threadIdx.x; i < lp; i += (int64_t)gridDim.x * HP_THREADS) {
+        double2 v = make_double2(0.0, 0.0);
+        if (i < len) v = make_double2(1.0 / (bw[c * ldb + i] - 1.0), 1.0 / (bl[c * ldb + i] - 1.0));
+        out[c * lp + hp_slot(i)] = v;
+    }
+}
+
+// Counting sort of the queries by class (any order inside a class) + the per-XCD cursors of hprec_kernel.
+__global__ __launch_bounds__(HP_ORDER_THREADS) void hprec_order_kernel(const int32_t *__restrict__ qcls, int64_t Q, int C, int32_t *__restrict__ ws)
+{
+    extern __shared__ int hp_hist[];            // [C] class counts -> cursors, then [16] wave totals
+    int *s_wt = hp_hist + C;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int c = tid; c < C; c += HP_ORDER_THREADS) hp_hist[c] = 0;
+    if (tid < HP_WS_HEAD) ws[tid] = 0;
+    __syncthreads();
+    for (int64_t i = tid; i < Q; i += HP_ORDER_THREADS) atomicAdd(&hp_hist[qcls[i]], 1);
+    __syncthreads();
+    const int per = (C + HP_ORDER_THREADS - 1) / HP_ORDER_THREADS, lo = tid * per, hi = (lo + per < C) ? lo + per : C;
+    int mine = 0;
+    for (int c = lo; c < hi; c++) mine += hp_hist[c];
+    const int incl = wave_incl_scan_i32(mine);
+    if (lane == 63) s_wt[wave] = incl;
+    __syncthreads();
+    int run = incl - mine;
+    for (int w = 0; w < wave; w++) run += s_wt[w];
+    for (int c = lo; c < hi; c++) { const int t = hp_hist[c]; hp_hist[c] = run; run += t; }
+    __syncthreads();
+    for (int64_t i = tid; i < Q; i += HP_ORDER_THREADS) ws[HP_WS_HEAD + atomicAdd(&hp_hist[qcls[i]], 1)] = (int32_t)i;
+}
+
 // out row layout: [P@k WUP x nk][P@k LCS x nk][AHP WUP][AHP LCS][AP]
 __global__ __launch_bounds__(HP_THREADS) void hprec_kernel(const int32_t *__restrict__ rank, int64_t ldr, int64_t Q, int64_t L,
                                                            const int32_t *__restrict__ cls, const int32_t *__restrict__ qcls,
                                                            const int32_t *__restrict__ qidx, const double *__restrict__ wup,
                                                            const double *__restrict__ lcs, int C, const double *__restrict__ best_wup,
                                                            const double *__restrict__ best_lcs, int64_t ldb,
+                                                           const double2 *__restrict__ rcp, int64_t ldc,
                                                            const int32_t *__restrict__ ks, int nk, int64_t ahp_len, int want_ap,
-                                                           double *__restrict__ out, int64_t ldo)
+                                                           double *__restrict__ out, int64_t ldo, int32_t *__restrict__ order_ws, int vec_ok)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char hp_raw[];
-    double *s_wup = reinterpret_cast<double *>(hp_raw);   // [C] similarity row of the query class
-    double *s_lcs = s_wup + C;                            // [C]
-    double *s_part = s_lcs + C;                           // [HP_WAVES][6] wave totals
-    int *s_qpos = reinterpret_cast<int *>(s_part + HP_WAVES * 6);
+    double2 *s_sim = reinterpret_cast<double2 *>(hp_raw);          // [C] (wup, lcs) similarity of the query class to every class
+    double2 *s_y = s_sim + C;                                      // [HP_CHUNK] cum / best of one chunk (only where a cut-off may fall)
+    double *s_part = reinterpret_cast<double *>(s_y + HP_CHUNK);   // [2][HP_WAVES][3] wave totals of the scans, double-buffered
+    double *s_fin = s_part + 2 * HP_WAVES * 3;                     // [HP_WAVES][7] end-of-query reduction
+    int *s_qpos = reinterpret_cast<int *>(s_fin + HP_WAVES * 7);
+    int *s_next = s_qpos + 1;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
-    for (int64_t q = blockIdx.x; q < Q; q += gridDim.x) {
+    // ---- which queries this workgroup takes: class order, one segment of it per XCD (blockIdx round-robins the XCDs), stealing
+    //      from the next segments once its own is empty; or every gridDim-th query when no workspace was given ----
+    const int xcd = blockIdx.x & 7;
+    const int64_t seg_len = (Q + 7) / 8;
+    int seg = 0;
+    int64_t q_static = blockIdx.x;
+    for (;;) {
+        int64_t q;
+        if (order_ws) {
+            __syncthreads();
+            if (tid == 0) {
+                int got = -1;
+                for (; seg < 8; seg++) {
+                    const int xs = (xcd + seg) & 7;
+                    const int64_t lo = xs * seg_len, hi = (lo + seg_len < Q) ? lo + seg_len : Q;
+                    const int64_t at = lo + atomicAdd(&order_ws[xs], 1);
+                    if (at < hi) { got = order_ws[HP_WS_HEAD + at]; break; }
+                }
+                *s_next = got;
+            }
+            __syncthreads();
+            q = *s_next;
+            if (q < 0) break;
+        } else {
+            q = q_static;
+            if (q >= Q) break;
+            q_static += gridDim.x;
+        }
         const int32_t *rrow = rank + q * ldr;
         const int qc = qcls[q];
         const int32_t self = qidx ? qidx[q] : -1;
         const double *bw = best_wup + (int64_t)qc * ldb, *bl = best_lcs + (int64_t)qc * ldb;
+        const double2 *rc = rcp + (int64_t)qc * ldc;
         double *orow = out + q * ldo;
         __syncthreads();
-        for (int c = tid; c < C; c += HP_THREADS) { s_wup[c] = wup[(int64_t)qc * C + c]; s_lcs[c] = lcs[(int64_t)qc * C + c]; }
+        for (int c = tid; c < C; c += HP_THREADS) s_sim[c] = make_double2(wup[(int64_t)qc * C + c], lcs[(int64_t)qc * C + c]);
         if (tid == 0) *s_qpos = 0x7FFFFFFF;
         __syncthreads();
         // ---- position of the query in its own ranking (first hit; L if absent) ----
@@ -100,93 +198,128 @@ __global__ __launch_bounds__(HP_THREADS) void hprec_kernel(const int32_t *__rest
             }
         }
         __syncthreads();
-        const int64_t qpos = (*s_qpos == 0x7FFFFFFF) ? L : (int64_t)*s_qpos;
-        const int64_t eff_len = (qpos < L) ? L - 1 : L;                         // len(wup) after `del wup[qid_ind]`
-        const int64_t alen = (ahp_len > 0) ? (ahp_len < eff_len ? ahp_len : eff_len) : eff_len;   // AHP window (effective ranks)
+        // positions are int32 from here on (list_len < 2^31 is checked at the entry point)
+        const int Li = (int)L;
+        const int qpos = (*s_qpos == 0x7FFFFFFF) ? Li : *s_qpos;
+        const int eff_len = (qpos < Li) ? Li - 1 : Li;                          // len(wup) after `del wup[qid_ind]`
+        const int alen = (ahp_len > 0) ? (ahp_len < eff_len ? (int)ahp_len : eff_len) : eff_len;   // AHP window (effective ranks)
         // effective rank j -> original position: j if j < qpos else j + 1.  AHP / AP need positions up to:
-        int64_t need = 0;
+        int need = 0;
         for (int i = 0; i < nk; i++) need = (ks[i] > need) ? ks[i] : need;
-        const int64_t kmax = need;
+        const int kmax = need;                                                  // cut-offs live at original positions <= kmax
         if (ahp_len >= 0) need = (alen > need) ? alen : need;
         if (want_ap) need = eff_len;
-        int64_t last_pos = need + 1;                                            // original positions [0, last_pos) cover `need` effective ranks
-        if (last_pos > L) last_pos = L;
+        const int last_pos = (need < Li) ? need + 1 : Li;                       // original positions [0, last_pos) cover `need` effective ranks
 
-        HpCarry carry = {0.0, 0.0, 0.0, 0.0, 0.0, 0};
+        double car_w = 0.0, car_l = 0.0;      // running similarity sums up to the current chunk (the same value in every thread)
+        int car_r = 0;                        // relevant items so far
+        double acc_w = 0.0, acc_l = 0.0, acc_ap = 0.0;                          // this thread's share of sum(cum / best) and of the AP terms
         double y_first_w = 0.0, y_first_l = 0.0, y_last_w = 0.0, y_last_l = 0.0;   // trapezoid end points (valid on the owning thread)
-        for (int64_t base = 0; base < last_pos; base += HP_CHUNK) {
-            // ---- this thread's 8 consecutive positions ----
-            double vw[HP_ITEMS], vl[HP_ITEMS];
-            int rl[HP_ITEMS];
-            double tw = 0.0, tl = 0.0;
-            long long tr = 0;
+        int par = 0;
+        const double2 *rct = rc + tid;
+        for (int base = 0; base < last_pos; base += HP_CHUNK, par ^= 1, rct += HP_CHUNK) {
+            const int i0 = base + tid * HP_ITEMS;
+            // ---- this thread's 8 consecutive positions: rank -> class -> similarity pair ----
+            int r[HP_ITEMS];
+            if (vec_ok && i0 + HP_ITEMS <= last_pos) {
+                const int4 a = *reinterpret_cast<const int4 *>(rrow + i0), b = *reinterpret_cast<const int4 *>(rrow + i0 + 4);
+                r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = a.w; r[4] = b.x; r[5] = b.y; r[6] = b.z; r[7] = b.w;
+            } else {
 #pragma unroll
-            for (int e = 0; e < HP_ITEMS; e++) {
-                const int64_t i = base + (int64_t)tid * HP_ITEMS + e;
-                const bool live = (i < last_pos) && (i != qpos);
-                int c = 0;
-                if (live) c = cls[rrow[i]];
-                vw[e] = live ? s_wup[c] : 0.0;
-                vl[e] = live ? s_lcs[c] : 0.0;
-                rl[e] = (live && c == qc) ? 1 : 0;
-                tw += vw[e]; tl += vl[e]; tr += rl[e];
+                for (int e = 0; e < HP_ITEMS; e++) r[e] = (i0 + e < last_pos) ? rrow[i0 + e] : 0;
             }
-            // ---- workgroup exclusive scan of the thread totals ----
-            const double iw = wave_incl_scan_f64(tw), il = wave_incl_scan_f64(tl);
-            const long long ir = wave_incl_scan_i64(tr);
-            if (lane == 63) { s_part[wave * 6 + 0] = iw; s_part[wave * 6 + 1] = il; s_part[wave * 6 + 2] = (double)ir; }
-            __syncthreads();
-            double ow = carry.cw, ol = carry.cl;
-            long long orl = carry.rel;
-            for (int w = 0; w < wave; w++) { ow += s_part[w * 6 + 0]; ol += s_part[w * 6 + 1]; orl += (long long)s_part[w * 6 + 2]; }
-            double cw = ow + (iw - tw), cl = ol + (il - tl);     // sums BEFORE this thread's first element
-            long long cr = orl + (ir - tr);
-            // ---- walk the 8 positions: cumulative sums, P@k, trapezoid terms, AP terms ----
-            double syw = 0.0, syl = 0.0, sap = 0.0;
+            double2 t[HP_ITEMS];                  // 1 / (best - 1) of these positions: contiguous across the wave for every e
+#pragma unroll
+            for (int e = 0; e < HP_ITEMS; e++) t[e] = rct[e * HP_THREADS];
+            double vw[HP_ITEMS], vl[HP_ITEMS];
+            unsigned rel = 0;                     // bit e: position e is of the query's class
+            double tw = 0.0, tl = 0.0;
 #pragma unroll
             for (int e = 0; e < HP_ITEMS; e++) {
-                const int64_t i = base + (int64_t)tid * HP_ITEMS + e;
-                cw += vw[e]; cl += vl[e]; cr += rl[e];
+                const int i = i0 + e;
+                const bool live = (i < last_pos) && (i != qpos);
+                const int c = live ? cls[r[e]] : 0;
+                const double2 s = s_sim[c];
+                vw[e] = live ? s.x : 0.0;
+                vl[e] = live ? s.y : 0.0;
+                rel |= (live && c == qc) ? (1u << e) : 0u;
+                tw += vw[e]; tl += vl[e];
+            }
+            const int tr = __popc(rel);
+            // ---- workgroup exclusive scan of the thread totals: DPP inside the wave, wave totals through LDS ----
+            const double iw = wave_incl_scan_f64(tw), il = wave_incl_scan_f64(tl);
+            const int ir = wave_incl_scan_i32(tr);
+            double *part = s_part + par * (HP_WAVES * 3);
+            if (lane == 63) { part[wave * 3 + 0] = iw; part[wave * 3 + 1] = il; part[wave * 3 + 2] = (double)ir; }
+            __syncthreads();   // the only barrier of a chunk: the other half of s_part is written next time
+            double cw = car_w + (iw - tw), cl = car_l + (il - tl);     // sums BEFORE this thread's first element
+            int cr = car_r + (ir - tr);
+#pragma unroll
+            for (int w = 0; w < HP_WAVES; w++) {
+                const double pw = part[w * 3 + 0], pl = part[w * 3 + 1];
+                const int pr = (int)part[w * 3 + 2];
+                if (w < wave) { cw += pw; cl += pl; cr += pr; }
+                car_w += pw; car_l += pl; car_r += pr;
+            }
+            if (base < qpos) {   // uniform and rare (the query is normally its own nearest neighbour): ranks AHEAD of the query divide
+#pragma unroll           // by the unshifted curve
+                for (int e = 0; e < HP_ITEMS; e++)
+                    if (i0 + e < qpos && i0 + e < last_pos) t[e] = make_double2(1.0 / bw[i0 + e], 1.0 / bl[i0 + e]);
+            }
+            // ---- walk the 8 positions: cumulative sums, cum / best, trapezoid and AP terms ----
+            const bool stage = (nk > 0) && (base <= kmax);              // uniform: a cut-off may fall into this chunk
+#pragma unroll
+            for (int e = 0; e < HP_ITEMS; e++) {
+                const int i = i0 + e;
+                const bool hit = (rel >> e) & 1u;
+                cw += vw[e]; cl += vl[e]; cr += hit ? 1 : 0;
+                double yw = 0.0, yl = 0.0;
                 if (i < last_pos && i != qpos) {
-                    const int64_t j = (i < qpos) ? i : i - 1;                  // effective rank
-                    const double sub = (i > qpos) ? 1.0 : 0.0;                 // best curve shifted left at the query, minus its self-similarity
-                    const double yw = cw / (bw[i] - sub), yl = cl / (bl[i] - sub);
-                    if (j < kmax)
-                        for (int t = 0; t < nk; t++)
-                            if ((int64_t)ks[t] - 1 == j) { orow[t] = yw; orow[nk + t] = yl; }
+                    yw = cw * t[e].x; yl = cl * t[e].y;
+                    const int j = (i < qpos) ? i : i - 1;                       // effective rank
                     if (ahp_len >= 0 && j < alen) {
-                        syw += yw; syl += yl;
+                        acc_w += yw; acc_l += yl;
                         if (j == 0) { y_first_w = yw; y_first_l = yl; }
                         if (j == alen - 1) { y_last_w = yw; y_last_l = yl; }
                     }
-                    if (want_ap && rl[e]) sap += (double)cr / (double)(j + 1);
+                    if (want_ap && hit) acc_ap += (double)cr * fast_rcp_f64((double)(j + 1));
                 }
+                if (stage) s_y[e * HP_THREADS + tid] = make_double2(yw, yl);
             }
-            syw = wave_sum_f64(syw); syl = wave_sum_f64(syl); sap = wave_sum_f64(sap);
-            __syncthreads();   // everyone has read the wave totals of the scan
-            if (lane == 0) { s_part[wave * 6 + 3] = syw; s_part[wave * 6 + 4] = syl; s_part[wave * 6 + 5] = sap; }
-            __syncthreads();
-            for (int w = 0; w < HP_WAVES; w++) {
-                carry.cw += s_part[w * 6 + 0]; carry.cl += s_part[w * 6 + 1]; carry.rel += (long long)s_part[w * 6 + 2];
-                carry.yw += s_part[w * 6 + 3]; carry.yl += s_part[w * 6 + 4]; carry.ap += s_part[w * 6 + 5];
+            if (stage) {   // hierarchical precision at the cut-offs that fall into this chunk
+                __syncthreads();
+                for (int s = tid; s < nk; s += HP_THREADS) {
+                    const int j = ks[s] - 1;
+                    if (j < 0 || j >= eff_len) continue;
+                    const int i = (j < qpos) ? j : j + 1;
+                    if (i < base || i >= base + HP_CHUNK || i >= last_pos) continue;
+                    const int p = i - base;
+                    const double2 y = s_y[(p % HP_ITEMS) * HP_THREADS + p / HP_ITEMS];
+                    orow[s] = y.x; orow[nk + s] = y.y;
+                }
+                __syncthreads();
             }
-            __syncthreads();
         }
         // ---- finish: trapezoid and AP (end points live on whichever thread owned ranks 0 and alen - 1) ----
         {
-            double e0 = wave_sum_f64(y_first_w) , e1 = wave_sum_f64(y_first_l), e2 = wave_sum_f64(y_last_w), e3 = wave_sum_f64(y_last_l);
-            if (lane == 0) { s_part[wave * 6 + 0] = e0; s_part[wave * 6 + 1] = e1; s_part[wave * 6 + 2] = e2; s_part[wave * 6 + 3] = e3; }
+            double f[7] = {acc_w, acc_l, acc_ap, y_first_w, y_first_l, y_last_w, y_last_l};
+#pragma unroll
+            for (int v = 0; v < 7; v++) f[v] = wave_sum_f64(f[v]);
+            if (lane == 0)
+#pragma unroll
+                for (int v = 0; v < 7; v++) s_fin[wave * 7 + v] = f[v];
             __syncthreads();
             if (tid == 0) {
-                double f_w = 0, f_l = 0, l_w = 0, l_l = 0;
-                for (int w = 0; w < HP_WAVES; w++) { f_w += s_part[w * 6 + 0]; f_l += s_part[w * 6 + 1]; l_w += s_part[w * 6 + 2]; l_l += s_part[w * 6 + 3]; }
+                double g[7] = {0, 0, 0, 0, 0, 0, 0};
+                for (int w = 0; w < HP_WAVES; w++)
+                    for (int v = 0; v < 7; v++) g[v] += s_fin[w * 7 + v];
                 if (ahp_len >= 0) {
                     // np.trapz(y, dx) = dx * (sum(y) - (y[0] + y[-1]) / 2), dx = 1 / len(wup) (whole list) or 1 / clip
                     const double dx = 1.0 / (double)((ahp_len > 0) ? ahp_len : eff_len);
-                    orow[2 * nk] = dx * (carry.yw - 0.5 * (f_w + l_w));
-                    orow[2 * nk + 1] = dx * (carry.yl - 0.5 * (f_l + l_l));
+                    orow[2 * nk] = dx * (g[0] - 0.5 * (g[3] + g[5]));
+                    orow[2 * nk + 1] = dx * (g[1] - 0.5 * (g[4] + g[6]));
                 }
-                if (want_ap) orow[2 * nk + 2] = carry.rel > 0 ? carry.ap / (double)carry.rel : 0.0;
+                if (want_ap) orow[2 * nk + 2] = car_r > 0 ? g[2] / (double)car_r : 0.0;
             }
         }
     }
@@ -196,25 +329,57 @@ __global__ __launch_bounds__(HP_THREADS) void hprec_kernel(const int32_t *__rest
 
 using namespace se;
 
+extern "C" int64_t se_hprec_curve_len(int64_t list_len)
+{
+    return list_len <= 0 ? 0 : (list_len + HP_CHUNK - 1) / HP_CHUNK * HP_CHUNK;
+}
+
+extern "C" int se_hprec_reciprocal_curves(const double *best_wup, const double *best_lcs, int64_t ldb, int num_classes, int64_t list_len,
+                                          double *rcp, se_stream_t stream)
+{
+    if (num_classes <= 0 || list_len <= 0 || ldb < list_len) return fail(SE_ERR_INVALID, "se_hprec_reciprocal_curves: bad shape classes=%d len=%lld ldb=%lld", num_classes, (long long)list_len, (long long)ldb);
+    if (!best_wup || !best_lcs || !rcp) return fail(SE_ERR_INVALID, "se_hprec_reciprocal_curves: null pointer");
+    const int64_t lp = se_hprec_curve_len(list_len);
+    int64_t gx = lp / HP_THREADS;
+    if (gx > 1024) gx = 1024;
+    hipLaunchKernelGGL(hprec_rcp_kernel, dim3((unsigned)gx, (unsigned)num_classes), dim3(HP_THREADS), 0, (hipStream_t)stream, best_wup, best_lcs, ldb,
+                       list_len, lp, reinterpret_cast<double2 *>(rcp));
+    SE_LAUNCH_CHECK();
+    return SE_OK;
+}
+
+extern "C" int64_t se_hprec_order_workspace_bytes(int64_t q) { return q < 0 ? 0 : (int64_t)sizeof(int32_t) * (HP_WS_HEAD + q); }
+
 extern "C" int se_hierarchical_precision(const int32_t *rank, int64_t ldr, int64_t q, int64_t list_len, const int32_t *cls,
                                          const int32_t *qcls, const int32_t *qidx, const double *wup, const double *lcs,
                                          int num_classes, const double *best_wup, const double *best_lcs, int64_t ldb,
-                                         const int32_t *ks, int nk, int64_t ahp_len, int want_ap, double *out, int64_t ldo,
-                                         se_stream_t stream)
+                                         const double *rcp, int64_t rcp_len, const int32_t *ks, int nk, int64_t ahp_len, int want_ap,
+                                         double *out, int64_t ldo, void *order_ws, se_stream_t stream)
 {
-    if (q < 0 || list_len <= 0 || num_classes <= 0 || nk < 0 || nk > HP_MAX_KS)
+    if (q < 0 || list_len <= 0 || num_classes <= 0 || nk < 0 || nk > HP_MAX_KS || q > 0x7FFFFFFF || list_len > 0x7FFFFFFF)
         return fail(SE_ERR_INVALID, "se_hierarchical_precision: bad shape q=%lld len=%lld classes=%d nk=%d", (long long)q, (long long)list_len, num_classes, nk);
     if (q == 0) return SE_OK;
-    if (!rank || !cls || !qcls || !wup || !lcs || !best_wup || !best_lcs || !out || (nk > 0 && !ks))
+    if (!rank || !cls || !qcls || !wup || !lcs || !best_wup || !best_lcs || !rcp || !out || (nk > 0 && !ks))
         return fail(SE_ERR_INVALID, "se_hierarchical_precision: null pointer");
     if (ldr < list_len || ldb < list_len || ldo < 2 * nk + 3) return fail(SE_ERR_INVALID, "se_hierarchical_precision: leading dimension too small");
-    const size_t lds = (size_t)(2 * num_classes + HP_WAVES * 6) * sizeof(double) + 16;
+    if (rcp_len < list_len) return fail(SE_ERR_INVALID, "se_hierarchical_precision: the reciprocal curves cover %lld positions, the rankings have %lld", (long long)rcp_len, (long long)list_len);
+    const size_t lds = (size_t)num_classes * sizeof(double2) + (size_t)HP_CHUNK * sizeof(double2) + (size_t)(2 * HP_WAVES * 3 + HP_WAVES * 7) * sizeof(double) + 16;
     if (lds > 160 * 1024) return fail(SE_ERR_UNSUPPORTED, "se_hierarchical_precision: %d classes exceed the LDS similarity rows", num_classes);
     hipStream_t s = (hipStream_t)stream;
     SE_HIP_CHECK(hipFuncSetAttribute((const void *)hprec_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const int64_t grid = q < 2048 ? q : 2048;
+    int32_t *ws = static_cast<int32_t *>(order_ws);
+    const size_t order_lds = (size_t)(num_classes + HP_ORDER_THREADS / WAVE) * sizeof(int);
+    if (ws) {
+        SE_HIP_CHECK(hipFuncSetAttribute((const void *)hprec_order_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)order_lds));
+        hipLaunchKernelGGL(hprec_order_kernel, dim3(1), dim3(HP_ORDER_THREADS), order_lds, s, qcls, q, num_classes, ws);
+        SE_LAUNCH_CHECK();
+    }
+    const int64_t cap = ws ? 1024 : 2048;       // with a workspace the workgroups pull queries until none are left
+    const int64_t grid = q < cap ? q : cap;
+    const int vec_ok = (ldr % 4 == 0) && (reinterpret_cast<uintptr_t>(rank) % 16 == 0);
     hipLaunchKernelGGL(hprec_kernel, dim3((unsigned)grid), dim3(HP_THREADS), lds, s, rank, ldr, q, list_len, cls, qcls, qidx, wup, lcs,
-                       num_classes, best_wup, best_lcs, ldb, ks, nk, ahp_len, want_ap, out, ldo);
+                       num_classes, best_wup, best_lcs, ldb, reinterpret_cast<const double2 *>(rcp), se_hprec_curve_len(rcp_len), ks, nk,
+                       ahp_len, want_ap, out, ldo, ws, vec_ok);
     SE_LAUNCH_CHECK();
     return SE_OK;
 }

@@ -28,6 +28,7 @@ EXPORTS = (
     "se_rank_rows_workspace_bytes", "se_rank_rows",
     "se_topk_rows", "se_topk_merge",
     "se_retrieve_topk_workspace_bytes", "se_retrieve_topk", "se_hierarchical_precision",
+    "se_hprec_order_workspace_bytes", "se_hprec_curve_len", "se_hprec_reciprocal_curves",
 )
 
 
@@ -88,8 +89,13 @@ def lib():
     L.se_normalize_rows.argtypes = [vp, c_i64, c_i64, c_i64, vp]
     L.se_pairwise_dist.argtypes = [vp, c_i64, vp, c_i64, vp, vp, c_i64, c_i64, c_i64, c_int,
                                    ctypes.POINTER(ctypes.c_int32), c_int, vp, c_i64, vp]
-    L.se_hierarchical_precision.argtypes = [vp, c_i64, c_i64, c_i64, vp, vp, vp, vp, vp, c_int, vp, vp, c_i64, vp, c_int, c_i64, c_int,
-                                            vp, c_i64, vp]
+    L.se_hierarchical_precision.argtypes = [vp, c_i64, c_i64, c_i64, vp, vp, vp, vp, vp, c_int, vp, vp, c_i64, vp, c_i64, vp, c_int, c_i64,
+                                            c_int, vp, c_i64, vp, vp]
+    L.se_hprec_order_workspace_bytes.argtypes = [c_i64]
+    L.se_hprec_order_workspace_bytes.restype = c_i64
+    L.se_hprec_curve_len.argtypes = [c_i64]
+    L.se_hprec_curve_len.restype = c_i64
+    L.se_hprec_reciprocal_curves.argtypes = [vp, vp, c_i64, c_int, c_i64, vp, vp]
     L.se_rank_rows_workspace_bytes.argtypes = [c_i64, c_i64]
     L.se_rank_rows_workspace_bytes.restype = c_i64
     L.se_rank_rows.argtypes = [vp, c_i64, c_i64, c_i64, vp, c_int, c_i64, vp, c_i64, vp]

@@ -123,6 +123,42 @@ def test_training_step_resnet110_fc_uses_hip_loss_and_learns():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("n,q,class_order,with_qidx", [(3001, 37, True, True), (3001, 37, False, True), (4096, 64, True, False),
+                                                       (2048, 9, True, True), (700, 300, True, True)])
+def test_se_hierarchical_precision_general_rankings(n, q, class_order, with_qidx):
+    """se_hierarchical_precision on rankings where the query sits ANYWHERE in its list (ranks ahead of it divide by the unshifted
+    best curve, class_hierarchy.py:280-290), rows that are not 16-byte aligned (n = 3001), no query ids at all, cut-offs in several
+    chunks, with and without the class-ordered visit: equal to the NumPy statement of the reference's per-query loop (1e-10)."""
+    import sehip
+    from test_dp_gloo import _hprec_standin
+    rng = np.random.default_rng(n + q)
+    C = 23
+    cls = rng.integers(0, C, size=n).astype(np.int32)
+    tab_w = rng.random((C, C)) * 0.8 + 0.1; tab_w = (tab_w + tab_w.T) / 2; np.fill_diagonal(tab_w, 1.0)
+    tab_l = rng.random((C, C)) * 0.8 + 0.1; tab_l = (tab_l + tab_l.T) / 2; np.fill_diagonal(tab_l, 1.0)
+    counts = np.bincount(cls, minlength=C)
+
+    def best(tab):
+        return np.stack([np.cumsum(np.repeat(tab[c][np.argsort(-tab[c], kind="stable")], counts[np.argsort(-tab[c], kind="stable")]))
+                         for c in range(C)])
+    best_w, best_l = best(tab_w), best(tab_l)
+    rk = np.stack([rng.permutation(n) for _ in range(q)]).astype(np.int32)
+    rk[0, 0], rk[0, np.flatnonzero(rk[0] == 0)[0]] = 0, rk[0, 0]                      # query 0 is its own nearest neighbour
+    last = np.flatnonzero(rk[1] == 1)[0]
+    rk[1, last], rk[1, n - 1] = rk[1, n - 1], 1                                        # query 1 comes last in its list
+    qidx = np.arange(q, dtype=np.int32)
+    ks = np.array([1, 2, 10, 250, min(n - 1, 2047), min(n - 1, 2049), n - 1], dtype=np.int32)
+    args = [torch.from_numpy(a) for a in (rk, cls, cls[:q].copy(), qidx if with_qidx else np.full(q, -1, np.int32), tab_w, tab_l, best_w, best_l, ks)]
+    dev = [a.cuda() for a in args]
+    if not with_qidx:
+        dev[3] = None
+    for ahp, ap in ((0, True), (50, False), (2500, True), (-1, False)):
+        want = _hprec_standin(*args, ahp_len=ahp, want_ap=ap).numpy()
+        got = sehip.hierarchical_precision(*dev, ahp_len=ahp, want_ap=ap, class_order=class_order).cpu().numpy()
+        assert np.abs(got - want).max() <= 1e-10, (ahp, ap, np.abs(got - want).max())
+
+
+@pytest.mark.gpu
 def test_training_graph_replay_matches_eager_steps_and_keeps_state():
     """Trainer.enable_graphs (fp32 NCHW backbone_mode of the CIFAR ResNets): capture must leave parameters, velocity and
     BatchNorm buffers untouched, replayed steps must follow the eager trajectory, a short batch runs eagerly."""

@@ -75,11 +75,16 @@ def main():
         rk = sehip.rank_rows(pd)
         ks = torch.arange(1, 251, dtype=torch.int32, device="cuda")
         qidx = torch.arange(qq, dtype=torch.int32, device="cuda")
+        curves = sehip.hprec_reciprocal_curves(best_d, best_d)
+        qcls = cls[:qq].contiguous()
         for name, ahp in (("whole-list AHP + AP", 0), ("AHP@250, no AP", 250)):
-            med, mn = timeit(lambda: sehip.hierarchical_precision(rk, cls, cls[:qq].contiguous(), qidx, tab_d, tab_d, best_d, best_d, ks,
-                                                                  ahp_len=ahp, want_ap=(ahp == 0)), args.reps)
-            print("hprec %-22s q=%d n=%d: median %.3f ms (min %.3f)  %.1f GB/s of ranks, %.1f Mranks/s" %
-                  (name, qq, n, med, mn, 4.0 * qq * n / med / 1e6, qq * n / med / 1e3))
+            for order in (True, False):
+                med, mn = timeit(lambda: sehip.hierarchical_precision(rk, cls, qcls, qidx, tab_d, tab_d, best_d, best_d, ks, ahp_len=ahp,
+                                                                      want_ap=(ahp == 0), curves=curves, class_order=order), args.reps)
+                print("hprec %-22s %-14s q=%d n=%d: median %.3f ms (min %.3f)  %.1f GB/s of ranks, %.1f Mranks/s" %
+                      (name, "class order" if order else "query order", qq, n, med, mn, 4.0 * qq * n / med / 1e6, qq * n / med / 1e3))
+        med, mn = timeit(lambda: sehip.hprec_reciprocal_curves(best_d, best_d), args.reps)
+        print("hprec reciprocal curves C=%d n=%d: median %.3f ms" % (C, n, med))
     elif args.what == "shard":
         # BASELINE.json configs[4], one rank's share: 50,000 queries x (1,281,167 / 8) gallery rows, D = 1000, top-251, then the
         # merge of the 8 all-gathered lists (synthetic: 8 copies with shifted indices)
