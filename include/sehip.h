@@ -232,15 +232,13 @@ int se_retrieve_topk(const float *queries, int64_t ldq, const float *gallery, in
  *           P@k (WUP / LCS_HEIGHT), AHP or AHP@K (np.trapz of cum / best, :303-309), AP (:310-314), with the
  *           reference's handling of the query inside its own ranking (:280-290).
  *   rank      [q, list_len] int32 gallery indices, best first (ldr elements between rows)
- *   cls       [gallery] int32 class index of every gallery item;  qcls [q] class index of every query
+ *   cls       [gallery] int32 class index of every gallery item (the kernel keeps a byte / 16-bit copy in LDS when
+ *             num_classes and gallery allow);  qcls [q] class index of every query
  *   qidx      [q] int32 gallery index of the query itself (dropped from its ranking), NULL = keep everything
  *   wup, lcs  [C, C] f64 class similarity tables (Wu-Palmer, 1 - LCS height / max height)
- *   best_*    [C, ldb] f64: for query class c, cumulative sum of the descending-sorted similarities of the
- *             WHOLE gallery to c (class_hierarchy.py:266,275) -- host-side, once per gallery
- *   rcp       the same curves pre-divided for the kernel, from se_hprec_reciprocal_curves (once per gallery):
- *             1 / (best[i] - 1) of both similarities -- the divisor of every rank behind the query, whose removal
- *             shifts the curve and subtracts its self-similarity (class_hierarchy.py:280-290); rcp_len = the
- *             list_len it was built for (>= this call's list_len).  Ranks ahead of the query divide by best_*.
+ *   rcp       the best-possible cumulative similarity per query class (class_hierarchy.py:266,275), pre-divided
+ *             for the kernel by se_hprec_reciprocal_curves (once per gallery); rcp_len = the list_len it was built
+ *             for (>= this call's list_len)
  *   ks        [nk] int32 cut-offs; ahp_len: -1 no AHP, 0 whole list, K > 0 clipped AHP@K; want_ap: 0 / 1
  *   out       [q, 2 nk + 3] f64: P@k WUP x nk, P@k LCS x nk, AHP WUP, AHP LCS, AP (ldo elements between rows)
  *   order_ws  NULL, or se_hprec_order_workspace_bytes(q) bytes of device scratch: the queries are then visited in
@@ -249,19 +247,22 @@ int se_retrieve_topk(const float *queries, int64_t ldq, const float *gallery, in
  */
 int64_t se_hprec_order_workspace_bytes(int64_t q);
 int se_hierarchical_precision(const int32_t *rank, int64_t ldr, int64_t q, int64_t list_len,
-                              const int32_t *cls, const int32_t *qcls, const int32_t *qidx,
+                              const int32_t *cls, int64_t gallery, const int32_t *qcls, const int32_t *qidx,
                               const double *wup, const double *lcs, int num_classes,
-                              const double *best_wup, const double *best_lcs, int64_t ldb,
                               const double *rcp, int64_t rcp_len,
                               const int32_t *ks, int nk, int64_t ahp_len, int want_ap, double *out,
                               int64_t ldo, void *order_ws, se_stream_t stream);
 
 /*
  * The best-possible curves of se_hierarchical_precision, pre-divided and laid out for its loads.
- *   best_*    [num_classes, ldb] f64 as above; list_len positions of every row are used
- *   rcp       [num_classes, se_hprec_curve_len(list_len), 2] f64 out: (1 / (best_wup[c][i] - 1), 1 / (best_lcs[c][i] - 1))
- *             stored chunk-transposed (2048-position chunks, position 8 t + e of a chunk at slot 256 e + t) so that
- *             the 256 threads of the metric kernel, each owning 8 consecutive ranks, read contiguous 16-byte pairs.
+ *   best_*    [num_classes, ldb] f64: for query class c, the cumulative sum of the descending-sorted similarities of
+ *             the WHOLE gallery to c (class_hierarchy.py:266,275) -- host-side, once per gallery; list_len positions used
+ *   rcp       [num_classes, 2, se_hprec_curve_len(list_len), 2] f64 out, per class: the divisors of the ranks BEHIND the
+ *             query, (1 / (best_wup[i] - 1), 1 / (best_lcs[i] - 1)) -- dropping the query from its ranking shifts the
+ *             curve and subtracts its self-similarity (class_hierarchy.py:280-290) -- then those of the ranks AHEAD of
+ *             it, (1 / best_wup[i], 1 / best_lcs[i]).  Both chunk-transposed (4096-position chunks, position 16 t + e of
+ *             a chunk at slot 256 e + t) so that the 256 threads of the metric kernel, each owning 16 consecutive ranks,
+ *             read contiguous 16-byte pairs.
  */
 int64_t se_hprec_curve_len(int64_t list_len);
 int se_hprec_reciprocal_curves(const double *best_wup, const double *best_lcs, int64_t ldb,

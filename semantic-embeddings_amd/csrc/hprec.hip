@@ -24,11 +24,18 @@
 // (last-bits differences; the tests hold the outputs to 1e-10 of the reference's).
 #include "se_common.h"
 
+#include <type_traits>
+
 namespace se {
 
-constexpr int HP_THREADS = 256;
+#ifndef SE_HP_THREADS           // geometry of a chunk: threads x consecutive ranks per thread, and the occupancy the registers are
+#define SE_HP_THREADS 256       // bounded for (waves per SIMD); tools/experiments/README.md has the measured alternatives
+#define SE_HP_ITEMS 16
+#define SE_HP_WAVES_PER_SIMD 2
+#endif
+constexpr int HP_THREADS = SE_HP_THREADS;
 constexpr int HP_WAVES = HP_THREADS / WAVE;
-constexpr int HP_ITEMS = 8;
+constexpr int HP_ITEMS = SE_HP_ITEMS;
 constexpr int HP_CHUNK = HP_THREADS * HP_ITEMS;
 constexpr int HP_MAX_KS = 512;
 constexpr int HP_WS_HEAD = 16;      // order_ws: [0, 8) per-XCD cursors, [16, 16 + q) the queries in class order
@@ -96,9 +103,14 @@ __global__ __launch_bounds__(HP_THREADS) void hprec_rcp_kernel(const double *__r
 {
     const int64_t c = blockIdx.y;
     for (int64_t i = (int64_t)blockIdx.x * HP_THREADS + threadIdx.x; i < lp; i += (int64_t)gridDim.x * HP_THREADS) {
-        double2 v = make_double2(0.0, 0.0);
-        if (i < len) v = make_double2(1.0 / (bw[c * ldb + i] - 1.0), 1.0 / (bl[c * ldb + i] - 1.0));
-        out[c * lp + hp_slot(i)] = v;
+        double2 behind = make_double2(0.0, 0.0), ahead = behind;
+        if (i < len) {
+            const double w = bw[c * ldb + i], l = bl[c * ldb + i];
+            behind = make_double2(1.0 / (w - 1.0), 1.0 / (l - 1.0));     // ranks behind the query: curve shifted, self-similarity removed
+            ahead = make_double2(1.0 / w, 1.0 / l);                      // ranks ahead of it: the curve as it is
+        }
+        out[c * 2 * lp + hp_slot(i)] = behind;
+        out[(c * 2 + 1) * lp + hp_slot(i)] = ahead;
     }
 }
 
@@ -127,23 +139,53 @@ __global__ __launch_bounds__(HP_ORDER_THREADS) void hprec_order_kernel(const int
 }
 
 // out row layout: [P@k WUP x nk][P@k LCS x nk][AHP WUP][AHP LCS][AP]
-__global__ __launch_bounds__(HP_THREADS) void hprec_kernel(const int32_t *__restrict__ rank, int64_t ldr, int64_t Q, int64_t L,
-                                                           const int32_t *__restrict__ cls, const int32_t *__restrict__ qcls,
-                                                           const int32_t *__restrict__ qidx, const double *__restrict__ wup,
-                                                           const double *__restrict__ lcs, int C, const double *__restrict__ best_wup,
-                                                           const double *__restrict__ best_lcs, int64_t ldb,
-                                                           const double2 *__restrict__ rcp, int64_t ldc,
-                                                           const int32_t *__restrict__ ks, int nk, int64_t ahp_len, int want_ap,
-                                                           double *__restrict__ out, int64_t ldo, int32_t *__restrict__ order_ws, int vec_ok)
+// CLSW: where the class of a ranked gallery item comes from -- 1 / 2: a byte / 16-bit copy of `cls` in LDS, filled once per
+// (persistent) workgroup; 0: gathered from global memory (galleries too large for LDS).  The random 4-byte gather costs a
+// 128-byte L2 -> L1 line per rank, 32x the ranking itself, and was what bounded the kernel before the LDS copy.
+template <int CLSW>
+__global__ __launch_bounds__(HP_THREADS, SE_HP_WAVES_PER_SIMD) void hprec_kernel(const int32_t *__restrict__ rank, int64_t ldr, int64_t Q, int64_t L,
+                                                              const int32_t *__restrict__ cls, int64_t gallery,
+                                                              const int32_t *__restrict__ qcls, const int32_t *__restrict__ qidx,
+                                                              const double *__restrict__ wup, const double *__restrict__ lcs, int C,
+                                                              const double2 *__restrict__ rcp, int64_t ldc,
+                                                              const int32_t *__restrict__ ks, int nk, int64_t ahp_len, int want_ap,
+                                                              double *__restrict__ out, int64_t ldo, int32_t *__restrict__ order_ws, int vec_ok)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char hp_raw[];
     double2 *s_sim = reinterpret_cast<double2 *>(hp_raw);          // [C] (wup, lcs) similarity of the query class to every class
-    double2 *s_y = s_sim + C;                                      // [HP_CHUNK] cum / best of one chunk (only where a cut-off may fall)
-    double *s_part = reinterpret_cast<double *>(s_y + HP_CHUNK);   // [2][HP_WAVES][3] wave totals of the scans, double-buffered
-    double *s_fin = s_part + 2 * HP_WAVES * 3;                     // [HP_WAVES][7] end-of-query reduction
-    int *s_qpos = reinterpret_cast<int *>(s_fin + HP_WAVES * 7);
+    double *s_part = reinterpret_cast<double *>(s_sim + C);        // [2][HP_WAVES][3] wave totals of the scans, double-buffered
+    double *s_fin = s_part + 2 * HP_WAVES * 3;                     // [HP_WAVES][3] end-of-query reduction, then [4] trapezoid end points
+    double *s_ends = s_fin + HP_WAVES * 3;
+    int *s_ks = reinterpret_cast<int *>(s_ends + 4);     // [nk] the cut-offs, ascending
+    int *s_perm = s_ks + nk;                                       // [nk] their slots in the output row
+    int *s_qpos = s_perm + nk;
     int *s_next = s_qpos + 1;
+    unsigned char *s_cls8 = reinterpret_cast<unsigned char *>(s_qpos + 4);   // [gallery] class of every gallery item (CLSW 1 / 2)
+    unsigned short *s_cls16 = reinterpret_cast<unsigned short *>(s_cls8);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+
+    // ---- once per workgroup: the gallery's classes into LDS, the cut-offs sorted (rank by counting; ties keep their order) ----
+    if (CLSW == 1) {
+        unsigned *w = reinterpret_cast<unsigned *>(s_cls8);
+        for (int64_t i = (int64_t)tid * 4; i < gallery; i += HP_THREADS * 4) {
+            unsigned v = 0;
+#pragma unroll
+            for (int e = 0; e < 4; e++) v |= (i + e < gallery ? (unsigned)cls[i + e] & 0xFFu : 0u) << (8 * e);
+            w[i >> 2] = v;
+        }
+    } else if (CLSW == 2) {
+        unsigned *w = reinterpret_cast<unsigned *>(s_cls16);
+        for (int64_t i = (int64_t)tid * 2; i < gallery; i += HP_THREADS * 2)
+            w[i >> 1] = ((unsigned)cls[i] & 0xFFFFu) | ((i + 1 < gallery ? (unsigned)cls[i + 1] & 0xFFFFu : 0u) << 16);
+    }
+    for (int s = tid; s < nk; s += HP_THREADS) {
+        const int k = ks[s];
+        int r = 0;
+        for (int u = 0; u < nk; u++) { const int ku = ks[u]; r += (ku < k || (ku == k && u < s)) ? 1 : 0; }
+        s_ks[r] = k; s_perm[r] = s;
+    }
+    __syncthreads();
+    const int kmax = nk > 0 ? s_ks[nk - 1] : 0;                    // cut-offs live at original positions <= kmax
 
     // ---- which queries this workgroup takes: class order, one segment of it per XCD (blockIdx round-robins the XCDs), stealing
     //      from the next segments once its own is empty; or every gridDim-th query when no workspace was given ----
@@ -176,12 +218,12 @@ __global__ __launch_bounds__(HP_THREADS) void hprec_kernel(const int32_t *__rest
         const int32_t *rrow = rank + q * ldr;
         const int qc = qcls[q];
         const int32_t self = qidx ? qidx[q] : -1;
-        const double *bw = best_wup + (int64_t)qc * ldb, *bl = best_lcs + (int64_t)qc * ldb;
         const double2 *rc = rcp + (int64_t)qc * ldc;
         double *orow = out + q * ldo;
         __syncthreads();
         for (int c = tid; c < C; c += HP_THREADS) s_sim[c] = make_double2(wup[(int64_t)qc * C + c], lcs[(int64_t)qc * C + c]);
         if (tid == 0) *s_qpos = 0x7FFFFFFF;
+        if (tid < 4) s_ends[tid] = 0.0;
         __syncthreads();
         // ---- position of the query in its own ranking (first hit; L if absent) ----
         if (self >= 0) {   // chunk by chunk with a uniform early exit: the query is normally its own nearest neighbour
@@ -198,15 +240,13 @@ __global__ __launch_bounds__(HP_THREADS) void hprec_kernel(const int32_t *__rest
             }
         }
         __syncthreads();
-        // positions are int32 from here on (list_len < 2^31 is checked at the entry point)
+        // positions are int32 from here on (list_len < 2^31 - 4096 is checked at the entry point)
         const int Li = (int)L;
         const int qpos = (*s_qpos == 0x7FFFFFFF) ? Li : *s_qpos;
         const int eff_len = (qpos < Li) ? Li - 1 : Li;                          // len(wup) after `del wup[qid_ind]`
         const int alen = (ahp_len > 0) ? (ahp_len < eff_len ? (int)ahp_len : eff_len) : eff_len;   // AHP window (effective ranks)
         // effective rank j -> original position: j if j < qpos else j + 1.  AHP / AP need positions up to:
-        int need = 0;
-        for (int i = 0; i < nk; i++) need = (ks[i] > need) ? ks[i] : need;
-        const int kmax = need;                                                  // cut-offs live at original positions <= kmax
+        int need = kmax;
         if (ahp_len >= 0) need = (alen > need) ? alen : need;
         if (want_ap) need = eff_len;
         const int last_pos = (need < Li) ? need + 1 : Li;                       // original positions [0, last_pos) cover `need` effective ranks
@@ -214,112 +254,130 @@ __global__ __launch_bounds__(HP_THREADS) void hprec_kernel(const int32_t *__rest
         double car_w = 0.0, car_l = 0.0;      // running similarity sums up to the current chunk (the same value in every thread)
         int car_r = 0;                        // relevant items so far
         double acc_w = 0.0, acc_l = 0.0, acc_ap = 0.0;                          // this thread's share of sum(cum / best) and of the AP terms
-        double y_first_w = 0.0, y_first_l = 0.0, y_last_w = 0.0, y_last_l = 0.0;   // trapezoid end points (valid on the owning thread)
         int par = 0;
         const double2 *rct = rc + tid;
-        for (int base = 0; base < last_pos; base += HP_CHUNK, par ^= 1, rct += HP_CHUNK) {
-            const int i0 = base + tid * HP_ITEMS;
-            // ---- this thread's 8 consecutive positions: rank -> class -> similarity pair ----
-            int r[HP_ITEMS];
-            if (vec_ok && i0 + HP_ITEMS <= last_pos) {
-                const int4 a = *reinterpret_cast<const int4 *>(rrow + i0), b = *reinterpret_cast<const int4 *>(rrow + i0 + 4);
-                r[0] = a.x; r[1] = a.y; r[2] = a.z; r[3] = a.w; r[4] = b.x; r[5] = b.y; r[6] = b.z; r[7] = b.w;
+        const int64_t half = ldc / 2;
+        // the 16 ranks a thread owns in a chunk; the next chunk's are requested right after the barrier of the current one, so that
+        // HBM latency runs under the walk (two workgroups of four waves per CU do not hide it by themselves)
+        int r[HP_ITEMS];
+        auto load_ranks = [&](int at) {
+            if (vec_ok && at + HP_ITEMS <= last_pos) {
+#pragma unroll
+                for (int v = 0; v < HP_ITEMS / 4; v++) {
+                    const int4 a = *reinterpret_cast<const int4 *>(rrow + at + 4 * v);
+                    r[4 * v] = a.x; r[4 * v + 1] = a.y; r[4 * v + 2] = a.z; r[4 * v + 3] = a.w;
+                }
             } else {
 #pragma unroll
-                for (int e = 0; e < HP_ITEMS; e++) r[e] = (i0 + e < last_pos) ? rrow[i0 + e] : 0;
+                for (int e = 0; e < HP_ITEMS; e++) r[e] = (at + e < last_pos) ? rrow[at + e] : 0;
             }
-            double2 t[HP_ITEMS];                  // 1 / (best - 1) of these positions: contiguous across the wave for every e
+        };
+        load_ranks(tid * HP_ITEMS);
+        for (int base = 0; base < last_pos; base += HP_CHUNK, par ^= 1, rct += HP_CHUNK) {
+            const int i0 = base + tid * HP_ITEMS;
+            const bool cuts = (nk > 0) && (base <= kmax);               // uniform: a cut-off may fall into this chunk
+            // One chunk.  FAST = an interior chunk (uniform test below): every position is live, behind the query, inside the AHP
+            // window and away from its end points and from the cut-offs -- nothing to mask or test per rank.
+            auto chunk = [&](auto fast_c) {
+                constexpr bool FAST = decltype(fast_c)::value;
+                double2 t[HP_ITEMS];              // 1 / (best - 1) of these positions: contiguous across the wave for every e
+#pragma unroll                                    // (1 / best for the ranks ahead of the query: the second half of the class row)
+                for (int e = 0; e < HP_ITEMS; e++) t[e] = rct[e * HP_THREADS + ((!FAST && i0 + e < qpos) ? half : 0)];
+                double2 sv[HP_ITEMS];             // rank -> class -> similarity pair
+                unsigned rel = 0;                 // bit e: position e is of the query's class
+                double tw = 0.0, tl = 0.0;
 #pragma unroll
-            for (int e = 0; e < HP_ITEMS; e++) t[e] = rct[e * HP_THREADS];
-            double vw[HP_ITEMS], vl[HP_ITEMS];
-            unsigned rel = 0;                     // bit e: position e is of the query's class
-            double tw = 0.0, tl = 0.0;
+                for (int e = 0; e < HP_ITEMS; e++) {
+                    const int i = i0 + e;
+                    const bool live = FAST || ((i < last_pos) && (i != qpos));
+                    int c = 0;
+                    if (CLSW == 1) c = s_cls8[r[e]];
+                    else if (CLSW == 2) c = s_cls16[r[e]];
+                    else if (live) c = cls[r[e]];
+                    double2 v = s_sim[c];
+                    if (!FAST) { v.x = live ? v.x : 0.0; v.y = live ? v.y : 0.0; }
+                    sv[e] = v;
+                    rel |= (live && c == qc) ? (1u << e) : 0u;
+                    tw += v.x; tl += v.y;
+                }
+                const int tr = __popc(rel);
+                // ---- workgroup exclusive scan of the thread totals: DPP inside the wave, wave totals through LDS ----
+                const double iw = wave_incl_scan_f64(tw), il = wave_incl_scan_f64(tl);
+                const int ir = wave_incl_scan_i32(tr);
+                double *part = s_part + par * (HP_WAVES * 3);
+                if (lane == 63) { part[wave * 3 + 0] = iw; part[wave * 3 + 1] = il; part[wave * 3 + 2] = (double)ir; }
+                __syncthreads();   // the only barrier of a chunk: the other half of s_part is written next time
+                load_ranks(i0 + HP_CHUNK);
+                double cw = car_w + (iw - tw), cl = car_l + (il - tl);     // sums BEFORE this thread's first element
+                int cr = car_r + (ir - tr);
 #pragma unroll
-            for (int e = 0; e < HP_ITEMS; e++) {
-                const int i = i0 + e;
-                const bool live = (i < last_pos) && (i != qpos);
-                const int c = live ? cls[r[e]] : 0;
-                const double2 s = s_sim[c];
-                vw[e] = live ? s.x : 0.0;
-                vl[e] = live ? s.y : 0.0;
-                rel |= (live && c == qc) ? (1u << e) : 0u;
-                tw += vw[e]; tl += vl[e];
-            }
-            const int tr = __popc(rel);
-            // ---- workgroup exclusive scan of the thread totals: DPP inside the wave, wave totals through LDS ----
-            const double iw = wave_incl_scan_f64(tw), il = wave_incl_scan_f64(tl);
-            const int ir = wave_incl_scan_i32(tr);
-            double *part = s_part + par * (HP_WAVES * 3);
-            if (lane == 63) { part[wave * 3 + 0] = iw; part[wave * 3 + 1] = il; part[wave * 3 + 2] = (double)ir; }
-            __syncthreads();   // the only barrier of a chunk: the other half of s_part is written next time
-            double cw = car_w + (iw - tw), cl = car_l + (il - tl);     // sums BEFORE this thread's first element
-            int cr = car_r + (ir - tr);
-#pragma unroll
-            for (int w = 0; w < HP_WAVES; w++) {
-                const double pw = part[w * 3 + 0], pl = part[w * 3 + 1];
-                const int pr = (int)part[w * 3 + 2];
-                if (w < wave) { cw += pw; cl += pl; cr += pr; }
-                car_w += pw; car_l += pl; car_r += pr;
-            }
-            if (base < qpos) {   // uniform and rare (the query is normally its own nearest neighbour): ranks AHEAD of the query divide
-#pragma unroll           // by the unshifted curve
-                for (int e = 0; e < HP_ITEMS; e++)
-                    if (i0 + e < qpos && i0 + e < last_pos) t[e] = make_double2(1.0 / bw[i0 + e], 1.0 / bl[i0 + e]);
-            }
-            // ---- walk the 8 positions: cumulative sums, cum / best, trapezoid and AP terms ----
-            const bool stage = (nk > 0) && (base <= kmax);              // uniform: a cut-off may fall into this chunk
-#pragma unroll
-            for (int e = 0; e < HP_ITEMS; e++) {
-                const int i = i0 + e;
-                const bool hit = (rel >> e) & 1u;
-                cw += vw[e]; cl += vl[e]; cr += hit ? 1 : 0;
-                double yw = 0.0, yl = 0.0;
-                if (i < last_pos && i != qpos) {
-                    yw = cw * t[e].x; yl = cl * t[e].y;
-                    const int j = (i < qpos) ? i : i - 1;                       // effective rank
-                    if (ahp_len >= 0 && j < alen) {
-                        acc_w += yw; acc_l += yl;
-                        if (j == 0) { y_first_w = yw; y_first_l = yl; }
-                        if (j == alen - 1) { y_last_w = yw; y_last_l = yl; }
+                for (int w = 0; w < HP_WAVES; w++) {
+                    const double pw = part[w * 3 + 0], pl = part[w * 3 + 1];
+                    const int pr = (int)part[w * 3 + 2];
+                    if (w < wave) { cw += pw; cl += pl; cr += pr; }
+                    car_w += pw; car_l += pl; car_r += pr;
+                }
+                // ---- walk the 16 positions: cumulative sums, cum / best, trapezoid terms, the cut-offs ----
+                int kat = 0, knext = 0x7FFFFFFF;
+                if (!FAST && cuts) {            // lower bound of this thread's first effective rank + 1 among the sorted cut-offs
+                    const int k0 = (i0 <= qpos) ? i0 + 1 : i0;
+                    int hi = nk;
+                    while (kat < hi) {
+                        const int mid = (kat + hi) >> 1;
+                        if (s_ks[mid] < k0) kat = mid + 1; else hi = mid;
                     }
-                    if (want_ap && hit) acc_ap += (double)cr * fast_rcp_f64((double)(j + 1));
+                    if (kat < nk) knext = s_ks[kat];
                 }
-                if (stage) s_y[e * HP_THREADS + tid] = make_double2(yw, yl);
-            }
-            if (stage) {   // hierarchical precision at the cut-offs that fall into this chunk
-                __syncthreads();
-                for (int s = tid; s < nk; s += HP_THREADS) {
-                    const int j = ks[s] - 1;
-                    if (j < 0 || j >= eff_len) continue;
-                    const int i = (j < qpos) ? j : j + 1;
-                    if (i < base || i >= base + HP_CHUNK || i >= last_pos) continue;
-                    const int p = i - base;
-                    const double2 y = s_y[(p % HP_ITEMS) * HP_THREADS + p / HP_ITEMS];
-                    orow[s] = y.x; orow[nk + s] = y.y;
+#pragma unroll
+                for (int e = 0; e < HP_ITEMS; e++) {
+                    const int i = i0 + e;
+                    cw += sv[e].x; cl += sv[e].y;
+                    if (FAST) {
+                        acc_w += cw * t[e].x; acc_l += cl * t[e].y;
+                    } else if (i < last_pos && i != qpos) {
+                        const double yw = cw * t[e].x, yl = cl * t[e].y;
+                        const int j = (i < qpos) ? i : i - 1;                   // effective rank
+                        if (ahp_len >= 0 && j < alen) {
+                            acc_w += yw; acc_l += yl;
+                            if (j == 0) { s_ends[0] = yw; s_ends[1] = yl; }
+                            if (j == alen - 1) { s_ends[2] = yw; s_ends[3] = yl; }
+                        }
+                        if (cuts && j < kmax) {   // hierarchical precision at k = j + 1, if that is a cut-off: the thread's ranks are
+                            while (knext < j + 1) knext = (++kat < nk) ? s_ks[kat] : 0x7FFFFFFF;   // consecutive, so it merges them with
+                            while (knext == j + 1) {                                            // the sorted cut-offs from its lower bound
+                                orow[s_perm[kat]] = yw; orow[nk + s_perm[kat]] = yl;
+                                knext = (++kat < nk) ? s_ks[kat] : 0x7FFFFFFF;
+                            }
+                        }
+                    }
                 }
-                __syncthreads();
-            }
+                // ---- AP: precision at the relevant ranks (about one in C ranks: a loop over the set bits, not a test per rank) ----
+                if (want_ap) {
+                    for (unsigned m = rel; m; m &= m - 1) {
+                        const int e = __ffs(m) - 1, i = i0 + e;
+                        const int j1 = (i < qpos) ? i + 1 : i;                  // effective rank + 1
+                        acc_ap += (double)(cr + __popc(rel & ((2u << e) - 1u))) * fast_rcp_f64((double)j1);
+                    }
+                }
+            };
+            const bool interior = vec_ok && ahp_len >= 0 && !cuts && base > qpos && base + HP_CHUNK <= last_pos && base + HP_CHUNK - 2 < alen - 1;
+            if (interior) chunk(std::true_type{}); else chunk(std::false_type{});
         }
-        // ---- finish: trapezoid and AP (end points live on whichever thread owned ranks 0 and alen - 1) ----
+        // ---- finish: trapezoid and AP (the end points were left in LDS by whichever thread owned ranks 0 and alen - 1) ----
         {
-            double f[7] = {acc_w, acc_l, acc_ap, y_first_w, y_first_l, y_last_w, y_last_l};
-#pragma unroll
-            for (int v = 0; v < 7; v++) f[v] = wave_sum_f64(f[v]);
-            if (lane == 0)
-#pragma unroll
-                for (int v = 0; v < 7; v++) s_fin[wave * 7 + v] = f[v];
+            const double f0 = wave_sum_f64(acc_w), f1 = wave_sum_f64(acc_l), f2 = wave_sum_f64(acc_ap);
+            if (lane == 0) { s_fin[wave * 3 + 0] = f0; s_fin[wave * 3 + 1] = f1; s_fin[wave * 3 + 2] = f2; }
             __syncthreads();
             if (tid == 0) {
-                double g[7] = {0, 0, 0, 0, 0, 0, 0};
-                for (int w = 0; w < HP_WAVES; w++)
-                    for (int v = 0; v < 7; v++) g[v] += s_fin[w * 7 + v];
+                double g0 = 0.0, g1 = 0.0, g2 = 0.0;
+                for (int w = 0; w < HP_WAVES; w++) { g0 += s_fin[w * 3 + 0]; g1 += s_fin[w * 3 + 1]; g2 += s_fin[w * 3 + 2]; }
                 if (ahp_len >= 0) {
                     // np.trapz(y, dx) = dx * (sum(y) - (y[0] + y[-1]) / 2), dx = 1 / len(wup) (whole list) or 1 / clip
                     const double dx = 1.0 / (double)((ahp_len > 0) ? ahp_len : eff_len);
-                    orow[2 * nk] = dx * (g[0] - 0.5 * (g[3] + g[5]));
-                    orow[2 * nk + 1] = dx * (g[1] - 0.5 * (g[4] + g[6]));
+                    orow[2 * nk] = dx * (g0 - 0.5 * (s_ends[0] + s_ends[2]));
+                    orow[2 * nk + 1] = dx * (g1 - 0.5 * (s_ends[1] + s_ends[3]));
                 }
-                if (want_ap) orow[2 * nk + 2] = car_r > 0 ? g[2] / (double)car_r : 0.0;
+                if (want_ap) orow[2 * nk + 2] = car_r > 0 ? g2 / (double)car_r : 0.0;
             }
         }
     }
@@ -350,23 +408,49 @@ extern "C" int se_hprec_reciprocal_curves(const double *best_wup, const double *
 
 extern "C" int64_t se_hprec_order_workspace_bytes(int64_t q) { return q < 0 ? 0 : (int64_t)sizeof(int32_t) * (HP_WS_HEAD + q); }
 
-extern "C" int se_hierarchical_precision(const int32_t *rank, int64_t ldr, int64_t q, int64_t list_len, const int32_t *cls,
+namespace se {
+
+struct HpLaunch { int clsw; size_t lds; int grid; };
+
+template <int CLSW>
+static hipError_t hp_occupancy(size_t lds, int *blocks_per_cu)
+{
+    hipError_t e = hipFuncSetAttribute((const void *)hprec_kernel<CLSW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, hprec_kernel<CLSW>, HP_THREADS, lds);
+}
+
+}  // namespace se
+
+extern "C" int se_hierarchical_precision(const int32_t *rank, int64_t ldr, int64_t q, int64_t list_len, const int32_t *cls, int64_t gallery,
                                          const int32_t *qcls, const int32_t *qidx, const double *wup, const double *lcs,
-                                         int num_classes, const double *best_wup, const double *best_lcs, int64_t ldb,
-                                         const double *rcp, int64_t rcp_len, const int32_t *ks, int nk, int64_t ahp_len, int want_ap,
+                                         int num_classes, const double *rcp, int64_t rcp_len, const int32_t *ks, int nk, int64_t ahp_len, int want_ap,
                                          double *out, int64_t ldo, void *order_ws, se_stream_t stream)
 {
-    if (q < 0 || list_len <= 0 || num_classes <= 0 || nk < 0 || nk > HP_MAX_KS || q > 0x7FFFFFFF || list_len > 0x7FFFFFFF)
-        return fail(SE_ERR_INVALID, "se_hierarchical_precision: bad shape q=%lld len=%lld classes=%d nk=%d", (long long)q, (long long)list_len, num_classes, nk);
+    if (q < 0 || list_len <= 0 || gallery <= 0 || num_classes <= 0 || nk < 0 || nk > HP_MAX_KS || q > 0x7FFFFFFF || list_len > 0x7FFFFFFF - 2 * HP_CHUNK)
+        return fail(SE_ERR_INVALID, "se_hierarchical_precision: bad shape q=%lld len=%lld gallery=%lld classes=%d nk=%d", (long long)q,
+                    (long long)list_len, (long long)gallery, num_classes, nk);
     if (q == 0) return SE_OK;
-    if (!rank || !cls || !qcls || !wup || !lcs || !best_wup || !best_lcs || !rcp || !out || (nk > 0 && !ks))
+    if (!rank || !cls || !qcls || !wup || !lcs || !rcp || !out || (nk > 0 && !ks))
         return fail(SE_ERR_INVALID, "se_hierarchical_precision: null pointer");
-    if (ldr < list_len || ldb < list_len || ldo < 2 * nk + 3) return fail(SE_ERR_INVALID, "se_hierarchical_precision: leading dimension too small");
+    if (ldr < list_len || ldo < 2 * nk + 3) return fail(SE_ERR_INVALID, "se_hierarchical_precision: leading dimension too small");
     if (rcp_len < list_len) return fail(SE_ERR_INVALID, "se_hierarchical_precision: the reciprocal curves cover %lld positions, the rankings have %lld", (long long)rcp_len, (long long)list_len);
-    const size_t lds = (size_t)num_classes * sizeof(double2) + (size_t)HP_CHUNK * sizeof(double2) + (size_t)(2 * HP_WAVES * 3 + HP_WAVES * 7) * sizeof(double) + 16;
-    if (lds > 160 * 1024) return fail(SE_ERR_UNSUPPORTED, "se_hierarchical_precision: %d classes exceed the LDS similarity rows", num_classes);
+    const size_t fixed = (size_t)num_classes * sizeof(double2) + (size_t)(2 * HP_WAVES * 3 + HP_WAVES * 3 + 4) * sizeof(double) + (size_t)(2 * nk + 4) * sizeof(int);
+    const size_t cap = 160 * 1024;
+    if (fixed > cap) return fail(SE_ERR_UNSUPPORTED, "se_hierarchical_precision: %d classes exceed the LDS similarity rows", num_classes);
+    // the gallery's classes as bytes / shorts in LDS when they fit (two workgroups per CU preferred for the byte table), else gathered
+    const size_t tab8 = ((size_t)gallery + 15) / 16 * 16, tab16 = ((size_t)gallery * 2 + 15) / 16 * 16;
+    int clsw = 0;
+    if (list_len * (q < 4096 ? q : 4096) < 8 * gallery) clsw = 0;      // short lists / few queries: filling the table would cost more than the gathers
+    else if (num_classes <= 256 && fixed + tab8 <= cap) clsw = 1;
+    else if (num_classes <= 65536 && fixed + tab16 <= cap) clsw = 2;
+    const size_t lds = fixed + (clsw == 1 ? tab8 : clsw == 2 ? tab16 : 0);
     hipStream_t s = (hipStream_t)stream;
-    SE_HIP_CHECK(hipFuncSetAttribute((const void *)hprec_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int per_cu = 0, dev = 0, cus = 0;
+    SE_HIP_CHECK(clsw == 1 ? hp_occupancy<1>(lds, &per_cu) : clsw == 2 ? hp_occupancy<2>(lds, &per_cu) : hp_occupancy<0>(lds, &per_cu));
+    SE_HIP_CHECK(hipGetDevice(&dev));
+    SE_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    if (per_cu < 1) per_cu = 1;
     int32_t *ws = static_cast<int32_t *>(order_ws);
     const size_t order_lds = (size_t)(num_classes + HP_ORDER_THREADS / WAVE) * sizeof(int);
     if (ws) {
@@ -374,12 +458,19 @@ extern "C" int se_hierarchical_precision(const int32_t *rank, int64_t ldr, int64
         hipLaunchKernelGGL(hprec_order_kernel, dim3(1), dim3(HP_ORDER_THREADS), order_lds, s, qcls, q, num_classes, ws);
         SE_LAUNCH_CHECK();
     }
-    const int64_t cap = ws ? 1024 : 2048;       // with a workspace the workgroups pull queries until none are left
-    const int64_t grid = q < cap ? q : cap;
+    // persistent workgroups (the class table is loaded once each): as many as are resident at once
+    const int64_t resident = (int64_t)per_cu * cus;
+    const int64_t grid = q < resident ? q : resident;
     const int vec_ok = (ldr % 4 == 0) && (reinterpret_cast<uintptr_t>(rank) % 16 == 0);
-    hipLaunchKernelGGL(hprec_kernel, dim3((unsigned)grid), dim3(HP_THREADS), lds, s, rank, ldr, q, list_len, cls, qcls, qidx, wup, lcs,
-                       num_classes, best_wup, best_lcs, ldb, reinterpret_cast<const double2 *>(rcp), se_hprec_curve_len(rcp_len), ks, nk,
-                       ahp_len, want_ap, out, ldo, ws, vec_ok);
+    const double2 *rc = reinterpret_cast<const double2 *>(rcp);
+    const int64_t ldc = 2 * se_hprec_curve_len(rcp_len);
+#define SE_HP_LAUNCH(W)                                                                                                                  \
+    hipLaunchKernelGGL(hprec_kernel<W>, dim3((unsigned)grid), dim3(HP_THREADS), lds, s, rank, ldr, q, list_len, cls, gallery, qcls, qidx, \
+                       wup, lcs, num_classes, rc, ldc, ks, nk, ahp_len, want_ap, out, ldo, ws, vec_ok)
+    if (clsw == 1) SE_HP_LAUNCH(1);
+    else if (clsw == 2) SE_HP_LAUNCH(2);
+    else SE_HP_LAUNCH(0);
+#undef SE_HP_LAUNCH
     SE_LAUNCH_CHECK();
     return SE_OK;
 }

@@ -89,8 +89,8 @@ def lib():
     L.se_normalize_rows.argtypes = [vp, c_i64, c_i64, c_i64, vp]
     L.se_pairwise_dist.argtypes = [vp, c_i64, vp, c_i64, vp, vp, c_i64, c_i64, c_i64, c_int,
                                    ctypes.POINTER(ctypes.c_int32), c_int, vp, c_i64, vp]
-    L.se_hierarchical_precision.argtypes = [vp, c_i64, c_i64, c_i64, vp, vp, vp, vp, vp, c_int, vp, vp, c_i64, vp, c_i64, vp, c_int, c_i64,
-                                            c_int, vp, c_i64, vp, vp]
+    L.se_hierarchical_precision.argtypes = [vp, c_i64, c_i64, c_i64, vp, c_i64, vp, vp, vp, vp, c_int, vp, c_i64, vp, c_int,
+                                            c_i64, c_int, vp, c_i64, vp, vp]
     L.se_hprec_order_workspace_bytes.argtypes = [c_i64]
     L.se_hprec_order_workspace_bytes.restype = c_i64
     L.se_hprec_curve_len.argtypes = [c_i64]

@@ -392,26 +392,27 @@ class HprecCurves:
 
 def hprec_reciprocal_curves(best_wup, best_lcs, list_len=None):
     """The best-possible curves pre-divided and laid out for ``hierarchical_precision`` (``se_hprec_reciprocal_curves``): once per
-    gallery.  best_* [C, >=L] f64 -> ``HprecCurves`` (f64 [C, curve_len(L), 2]); pass it as ``curves=``."""
+    gallery.  best_* [C, >=L] f64 -> ``HprecCurves`` (f64 [C, 2, curve_len(L), 2]); pass it as ``curves=``."""
     require_gpu(best_wup, best_lcs)
     _check_curves(best_wup, best_lcs)
     if best_wup.shape != best_lcs.shape or best_wup.stride(0) != best_lcs.stride(0):
         raise SehipError("best_wup and best_lcs must have the same shape and row stride")
     L = best_wup.shape[1] if list_len is None else int(list_len)
     C = best_wup.shape[0]
-    out = torch.empty((C, int(lib().se_hprec_curve_len(L)), 2), dtype=torch.float64, device=best_wup.device)
+    out = torch.empty((C, 2, int(lib().se_hprec_curve_len(L)), 2), dtype=torch.float64, device=best_wup.device)
     check(lib().se_hprec_reciprocal_curves(ptr(best_wup), ptr(best_lcs), best_wup.stride(0), C, L, ptr(out), stream_ptr()),
           "se_hprec_reciprocal_curves")
     return HprecCurves(out, L)
 
 
 def hierarchical_precision(rank, cls, qcls, qidx, wup, lcs, best_wup, best_lcs, ks, ahp_len=-1, want_ap=False, list_len=None, curves=None,
-                           class_order=True):
+                           class_order=None):
     """Per-query hierarchical precision metrics from device rankings (class_hierarchy.py:211-316).
 
     rank [Q, >=L] int32, cls [N] int32, qcls [Q] int32, qidx [Q] int32 | None, wup / lcs [C, C] f64,
     best_* [C, >=L] f64, ks [nk] int32; ``curves`` = ``hprec_reciprocal_curves(best_wup, best_lcs)`` (built here when omitted: callers
-    that evaluate tile after tile build it once).  ``class_order``: visit the queries class by class (faster, same results).
+    that evaluate tile after tile build it once).  ``class_order``: visit the queries class by class (keeps the best curve in L2; same results) -- by default for
+    lists of 4096 ranks and more, where it pays for the counting sort.
     Returns f64 [Q, 2 nk + 3]: P@k (WUP), P@k (LCS_HEIGHT), AHP (WUP), AHP (LCS_HEIGHT), AP."""
     require_gpu(rank, cls, qcls, wup, lcs, best_wup, best_lcs, ks)
     if rank.dtype != torch.int32 or rank.stride(1) != 1:
@@ -429,9 +430,11 @@ def hierarchical_precision(rank, cls, qcls, qidx, wup, lcs, best_wup, best_lcs, 
     if not isinstance(curves, HprecCurves) or curves.data.shape[0] != best_wup.shape[0] or curves.data.device != rank.device:
         raise SehipError("curves must come from hprec_reciprocal_curves for these best curves")
     out = torch.zeros((Q, 2 * nk + 3), dtype=torch.float64, device=rank.device)
+    if class_order is None:
+        class_order = L >= 4096
     order_ws = torch.empty((int(lib().se_hprec_order_workspace_bytes(Q)),), dtype=torch.uint8, device=rank.device) if class_order else None
-    check(lib().se_hierarchical_precision(ptr(rank), rank.stride(0), Q, L, ptr(cls), ptr(qcls), ptr(qidx), ptr(wup), ptr(lcs), C,
-                                          ptr(best_wup), ptr(best_lcs), best_wup.stride(0), ptr(curves.data), curves.list_len, ptr(ks), nk,
+    check(lib().se_hierarchical_precision(ptr(rank), rank.stride(0), Q, L, ptr(cls), cls.numel(), ptr(qcls), ptr(qidx), ptr(wup), ptr(lcs), C,
+                                          ptr(curves.data), curves.list_len, ptr(ks), nk,
                                           int(ahp_len), int(bool(want_ap)), ptr(out), out.stride(0), ptr(order_ws), stream_ptr()),
           "se_hierarchical_precision")
     return out

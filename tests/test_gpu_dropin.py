@@ -123,16 +123,17 @@ def test_training_step_resnet110_fc_uses_hip_loss_and_learns():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n,q,class_order,with_qidx", [(3001, 37, True, True), (3001, 37, False, True), (4096, 64, True, False),
-                                                       (2048, 9, True, True), (700, 300, True, True)])
-def test_se_hierarchical_precision_general_rankings(n, q, class_order, with_qidx):
+@pytest.mark.parametrize("n,q,class_order,with_qidx,C", [(3001, 37, True, True, 23), (3001, 37, False, True, 23), (4096, 64, True, False, 23),
+                                                         (2048, 9, True, True, 23), (700, 300, True, True, 23), (5000, 40, True, True, 300),
+                                                         (170001, 5, True, True, 23), (90000, 6, False, True, 700)])
+def test_se_hierarchical_precision_general_rankings(n, q, class_order, with_qidx, C):
     """se_hierarchical_precision on rankings where the query sits ANYWHERE in its list (ranks ahead of it divide by the unshifted
     best curve, class_hierarchy.py:280-290), rows that are not 16-byte aligned (n = 3001), no query ids at all, cut-offs in several
-    chunks, with and without the class-ordered visit: equal to the NumPy statement of the reference's per-query loop (1e-10)."""
+    chunks, with and without the class-ordered visit, and all three sources of the gallery classes (byte table in LDS: C <= 256; 16-bit
+    table: C = 300; global gather: tables that do not fit): equal to the NumPy statement of the reference's per-query loop (1e-10)."""
     import sehip
     from test_dp_gloo import _hprec_standin
     rng = np.random.default_rng(n + q)
-    C = 23
     cls = rng.integers(0, C, size=n).astype(np.int32)
     tab_w = rng.random((C, C)) * 0.8 + 0.1; tab_w = (tab_w + tab_w.T) / 2; np.fill_diagonal(tab_w, 1.0)
     tab_l = rng.random((C, C)) * 0.8 + 0.1; tab_l = (tab_l + tab_l.T) / 2; np.fill_diagonal(tab_l, 1.0)
@@ -147,7 +148,7 @@ def test_se_hierarchical_precision_general_rankings(n, q, class_order, with_qidx
     last = np.flatnonzero(rk[1] == 1)[0]
     rk[1, last], rk[1, n - 1] = rk[1, n - 1], 1                                        # query 1 comes last in its list
     qidx = np.arange(q, dtype=np.int32)
-    ks = np.array([1, 2, 10, 250, min(n - 1, 2047), min(n - 1, 2049), n - 1], dtype=np.int32)
+    ks = np.array([250, 1, 2, 10, min(n - 1, 2047), min(n - 1, 2049), n - 1, 10], dtype=np.int32)      # unsorted, with a duplicate
     args = [torch.from_numpy(a) for a in (rk, cls, cls[:q].copy(), qidx if with_qidx else np.full(q, -1, np.int32), tab_w, tab_l, best_w, best_l, ks)]
     dev = [a.cuda() for a in args]
     if not with_qidx:
