@@ -270,7 +270,42 @@ def bench_retrieval(args, rank, world):
     }
     if args.verify:
         out.update(verify_last_step(last, pd, rk, metric, world))
-    return out, feats_h
+    return out, feats_h, rk
+
+
+def bench_metrics(args, rk, reps=3):
+    """SURVEY.md 8(f) row 1, the consumer of the step's rankings: hierarchical precision (P@k for k = 1..250, whole-list AHP, AP) of
+    every query of the last step from its ranking, on a synthetic 100-class hierarchy (random symmetric similarity tables, random
+    labels; the best-possible curves built the way ClassHierarchy.hierarchical_precision_device builds them).  Reported beside the
+    step, not part of `value`."""
+    import sehip
+    q, n = rk.shape
+    C = 100
+    rng = np.random.default_rng(1)
+    cls_h = rng.integers(0, C, size=n).astype(np.int32)
+    tab = rng.random((C, C)); tab = (tab + tab.T) / 2; np.fill_diagonal(tab, 1.0)
+    counts = np.bincount(cls_h, minlength=C)
+    best = np.stack([np.cumsum(np.repeat(tab[c][np.argsort(-tab[c], kind="stable")], counts[np.argsort(-tab[c], kind="stable")])) for c in range(C)])
+    cls = torch.from_numpy(cls_h).cuda()
+    tab_d, best_d = torch.from_numpy(tab).cuda(), torch.from_numpy(best).cuda()
+    qcls = cls[:q].contiguous() if q <= n else cls[torch.arange(q, device="cuda") % n].contiguous()
+    qidx = torch.arange(q, dtype=torch.int32, device="cuda")
+    ks = torch.arange(1, 251, dtype=torch.int32, device="cuda")
+    curves = sehip.hprec_reciprocal_curves(best_d, best_d)
+
+    def run():
+        return sehip.hierarchical_precision(rk, cls, qcls, qidx, tab_d, tab_d, best_d, best_d, ks, ahp_len=0, want_ap=True, curves=curves)
+    res = run()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); run(); b.record()
+        torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b))
+    ms = float(np.median(ts))
+    return {"ms": ms, "queries": int(q), "ranks_per_query": int(n), "Mranks_per_sec": q * n / ms / 1e3, "rank_GBps": 4.0 * q * n / ms / 1e6,
+            "metrics": "P@1..250 (WUP, LCS), whole-list AHP (WUP, LCS), AP; 100 classes", "finite": bool(torch.isfinite(res).all().item())}
 
 
 def verify_last_step(last, pd, rk, metric, world):
@@ -441,7 +476,7 @@ def main(argv=None):
             from train_bench import cpu_baseline_train
             out["cpu_baseline"] = cpu_baseline_train(args)
     else:
-        out, feats_h = bench_retrieval(args, rank, world)
+        out, feats_h, rk = bench_retrieval(args, rank, world)
 
         def leg(name, fn):        # the retrieval line must survive a failure of a secondary leg -- but every rank must agree
             try:
@@ -449,6 +484,9 @@ def main(argv=None):
             except Exception as e:
                 out[name] = {"error": "%s: %s" % (type(e).__name__, e)}
 
+        leg("hierarchical_precision", lambda: bench_metrics(args, rk))
+        del rk
+        torch.cuda.empty_cache()
         if args.with_sharded:
             leg("sharded_gallery", lambda: bench_sharded_gallery(args, rank, world))
             torch.cuda.empty_cache()

@@ -566,11 +566,13 @@ def test_bench_line_schema_on_a_small_problem():
     assert len(line) == 1
     d = json.loads(line[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
-              "data", "config", "roofline", "cpu_baseline", "kernels", "verified", "sharded_gallery"):
+              "data", "config", "roofline", "cpu_baseline", "kernels", "verified", "sharded_gallery", "hierarchical_precision"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["verified"] is True and d["value"] > 0
     assert set(("bound", "achieved", "peak", "unit", "frac", "traffic")) <= set(d["roofline"])
     assert d["kernels"]["pairwise_dist"]["flops_executed"] < d["kernels"]["pairwise_dist"]["flops_full_matrix"]
+    hp = d["hierarchical_precision"]
+    assert "error" not in hp and hp["finite"] and hp["queries"] == 4096 and hp["ms"] > 0
     sg = d["sharded_gallery"]
     assert "error" not in sg and sg["merged_lists_sorted_with_index_tiebreak"] and sg["merged_indices_in_range"]
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
