@@ -274,7 +274,7 @@ class ClassHierarchy(object):
 
     def hierarchical_precision_device(self, features, labels, ks=[1, 10, 50, 100], compute_ahp=False, compute_ap=False,
                                       normalize=False, ids=None, tile_rows=None, distributed=False, group=None, kblocks=None,
-                                      gather_per_query=True, kernels=None):
+                                      gather_per_query=True, kernels=None, per_query=True):
         """``hierarchical_precision(pairwise_retrieval(features, normalize), labels, ...)`` (ignore_qids = True, every
         image is query and gallery item) without leaving the GPU: the rankings stay device tensors
         (``evaluate_retrieval.ranking_tiles``) and the per-query gather + prefix sums run in
@@ -283,7 +283,9 @@ class ClassHierarchy(object):
 
         ``features``: float32 ``[N, D]`` array or (device) tensor (a device copy is normalised when ``normalize``);
         ``labels``: class label of image ``ids[i]`` (``ids`` defaults to ``range(N)``), as a sequence or a mapping.
-        Returns ``(means, per_query)`` exactly like ``hierarchical_precision``.
+        Returns ``(means, per_query)`` exactly like ``hierarchical_precision``; ``per_query=False`` returns ``(means, None)`` with
+        the means taken on the device (the CLI only prints means: at N = 50k and 250 cut-offs the per-query dictionaries are
+        25 million Python floats, seconds of host time after milliseconds of kernels).
 
         ``distributed`` (one process per GPU, ``torch.distributed`` initialised): every rank holds all features.
         * metrics that need full rankings (AP, un-clipped AHP): the QUERIES are sharded -- rank r ranks rows
@@ -374,7 +376,7 @@ class ClassHierarchy(object):
         res_d = torch.cat(outs) if outs else torch.zeros((0, ncol), dtype=torch.float64, device=dev)
         sums = None
         if world > 1:
-            if gather_per_query:    # ragged all-gather: pad every shard to the largest one
+            if gather_per_query and per_query:    # ragged all-gather: pad every shard to the largest one
                 rows_max = max(e - s for s, e in shard_bounds(n, world))
                 padded = torch.zeros((rows_max, ncol), dtype=torch.float64, device=dev)
                 padded[:res_d.shape[0]] = res_d
@@ -385,8 +387,6 @@ class ClassHierarchy(object):
             else:                   # the means only: one all-reduce of ncol sums
                 sums = res_d.sum(dim=0)
                 dist.all_reduce(sums, group=group)
-        res = res_d.cpu().numpy()
-
         nk = len(ks)
         my_ids = ids[q0:q1]
         prec = {}
@@ -400,6 +400,12 @@ class ClassHierarchy(object):
             col['AHP{} (LCS_HEIGHT)'.format(sfx)] = 2 * nk + 1
         if compute_ap:
             col['AP'] = 2 * nk + 2
+        if not per_query:
+            if sums is None:        # every row is here (one process, or gathered): the column means
+                sums = res_d.sum(dim=0)
+            sums = sums.cpu().numpy()
+            return {name: float(sums[c]) / n for name, c in col.items()}, None
+        res = res_d.cpu().numpy()
         for name, c in col.items():
             prec[name] = dict(zip(my_ids, res[:, c].tolist()))
         if sums is not None:

@@ -299,7 +299,7 @@ def main(argv=None):
         perf[feat_name] = hierarchy.hierarchical_precision_device(
             features, labels_test, ks, compute_ahp=args.clip_ahp if args.clip_ahp else True, compute_ap=not args.skip_ap,
             normalize=normalize, ids=None if ind2id is None else ind2id.tolist(), distributed=world > 1,
-            kblocks=args.kblocks)[0]
+            kblocks=args.kblocks, per_query=False)[0]      # the tables / plots below use the means only
     if rank != 0:
         return perf
 

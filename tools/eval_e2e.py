@@ -1,0 +1,60 @@
+"""End-to-end timing of the retrieval evaluation the CLI performs (evaluate_retrieval.main -> ClassHierarchy.hierarchical_precision_device):
+N synthetic CIFAR-100-like features, the CIFAR hierarchy of tests/golden/hierarchy_cifar.npz, ks = 1..250, whole-list AHP + AP.
+Prints wall time per phase (cProfile, top entries) -- where the seconds go once the kernels take milliseconds."""
+import argparse
+import cProfile
+import os
+import pstats
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "semantic-embeddings_amd"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=50000)
+    ap.add_argument("--d", type=int, default=100)
+    ap.add_argument("--per-query", action="store_true")
+    ap.add_argument("--profile", action="store_true")
+    args = ap.parse_args()
+    import torch
+    from class_hierarchy import ClassHierarchy
+    g = np.load(os.path.join(ROOT, "tests", "golden", "hierarchy_cifar.npz"))
+    with tempfile.NamedTemporaryFile("w", suffix=".txt", delete=False) as f:
+        for p, c in g["edges"]:
+            f.write("%d %d\n" % (p, c))
+    h = ClassHierarchy.from_file(f.name, id_type=int)
+    os.unlink(f.name)
+    rng = np.random.default_rng(0)
+    classes = sorted(set(g["labels"].tolist()))
+    labels = [classes[i] for i in rng.integers(0, len(classes), size=args.n)]
+    centers = rng.standard_normal((max(classes) + 1, args.d)).astype(np.float32)
+    feats = (centers[labels] + 0.8 * rng.standard_normal((args.n, args.d))).astype(np.float32)
+    ks = list(range(1, 251))
+    kw = dict(compute_ahp=True, compute_ap=True, normalize=True)
+    if not args.per_query:
+        kw["per_query"] = False
+    h.hierarchical_precision_device(feats[:4096].copy(), labels[:4096], ks, **kw)        # warm-up (library load, allocator)
+    torch.cuda.synchronize()
+    pr = cProfile.Profile() if args.profile else None
+    t0 = time.perf_counter()
+    if pr:
+        pr.enable()
+    avg, _ = h.hierarchical_precision_device(feats.copy(), labels, ks, **kw)
+    torch.cuda.synchronize()
+    if pr:
+        pr.disable()
+    dt = time.perf_counter() - t0
+    print("n=%d d=%d per_query=%s: %.3f s end to end   AHP (WUP) %.6f  AP %.6f  P@1 (WUP) %.6f" %
+          (args.n, args.d, args.per_query, dt, avg["AHP (WUP)"], avg["AP"], avg["P@1 (WUP)"]))
+    if pr:
+        pstats.Stats(pr).sort_stats("cumulative").print_stats(18)
+
+
+if __name__ == "__main__":
+    main()
