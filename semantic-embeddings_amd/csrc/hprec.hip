@@ -33,9 +33,19 @@ namespace se {
 #define SE_HP_ITEMS 16
 #define SE_HP_WAVES_PER_SIMD 2
 #endif
+#ifndef SE_HP_PF
+#define SE_HP_PF 1              // chunks of rank look-ahead
+#endif
+#ifndef SE_HP_ABLATE
+#define SE_HP_ABLATE 0          // timing experiments only (1: no curve loads, 2: no rank loads); never in a shipped build
+#endif
+#ifndef SE_HP_PF_CURVE
+#define SE_HP_PF_CURVE 0        // 1: the best curve is requested SE_HP_PF chunks ahead too (SE_HP_PF more register sets of it)
+#endif
 constexpr int HP_THREADS = SE_HP_THREADS;
 constexpr int HP_WAVES = HP_THREADS / WAVE;
 constexpr int HP_ITEMS = SE_HP_ITEMS;
+constexpr int HP_PF = SE_HP_PF;
 constexpr int HP_CHUNK = HP_THREADS * HP_ITEMS;
 constexpr int HP_MAX_KS = 512;
 constexpr int HP_WS_HEAD = 16;      // order_ws: [0, 8) per-XCD cursors, [16, 16 + q) the queries in class order
@@ -71,13 +81,6 @@ __device__ __forceinline__ int wave_incl_scan_i32(int v)
     v += dpp_i32<0x118, 0xf>(v);
     v += dpp_i32<0x142, 0xa>(v);
     v += dpp_i32<0x143, 0xc>(v);
-    return v;
-}
-
-__device__ __forceinline__ double wave_sum_f64(double v)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
 }
 
@@ -191,25 +194,31 @@ __global__ __launch_bounds__(HP_THREADS, SE_HP_WAVES_PER_SIMD) void hprec_kernel
     //      from the next segments once its own is empty; or every gridDim-th query when no workspace was given ----
     const int xcd = blockIdx.x & 7;
     const int64_t seg_len = (Q + 7) / 8;
-    int seg = 0;
+    int seg = 0, ticket = 0;                                       // thread 0: the segment it draws from and its next draw
+    if (order_ws && tid == 0) ticket = atomicAdd(&order_ws[xcd], 1);
     int64_t q_static = blockIdx.x;
+    const int Li = (int)L;                                         // positions are int32 (list_len < 2^31 - 8192 is checked at the entry point)
+    // upper bound of the positions a query can need, known before its own position in the list is: the first ranks are requested
+    // together with everything else a query starts with (one memory latency instead of four in a row)
+    const int lp_bound = (want_ap || ahp_len == 0) ? Li : min(Li, max(kmax, ahp_len > 0 ? (int)ahp_len : 0) + 1);
     for (;;) {
         int64_t q;
         if (order_ws) {
-            __syncthreads();
-            if (tid == 0) {
+            if (tid == 0) {   // resolve the draw made while the previous query was being processed
                 int got = -1;
-                for (; seg < 8; seg++) {
+                for (;;) {
                     const int xs = (xcd + seg) & 7;
                     const int64_t lo = xs * seg_len, hi = (lo + seg_len < Q) ? lo + seg_len : Q;
-                    const int64_t at = lo + atomicAdd(&order_ws[xs], 1);
-                    if (at < hi) { got = order_ws[HP_WS_HEAD + at]; break; }
+                    if (lo + ticket < hi) { got = order_ws[HP_WS_HEAD + lo + ticket]; break; }
+                    if (++seg == 8) break;
+                    ticket = atomicAdd(&order_ws[(xcd + seg) & 7], 1);
                 }
                 *s_next = got;
             }
             __syncthreads();
             q = *s_next;
             if (q < 0) break;
+            if (tid == 0 && seg < 8) ticket = atomicAdd(&order_ws[(xcd + seg) & 7], 1);   // the next draw: in flight during this query
         } else {
             q = q_static;
             if (q >= Q) break;
@@ -220,13 +229,35 @@ __global__ __launch_bounds__(HP_THREADS, SE_HP_WAVES_PER_SIMD) void hprec_kernel
         const int32_t self = qidx ? qidx[q] : -1;
         const double2 *rc = rcp + (int64_t)qc * ldc;
         double *orow = out + q * ldo;
-        __syncthreads();
+        // The ranks a thread owns in a chunk are requested HP_PF chunks ahead (HP_PF register sets, refilled right after the barrier of
+        // the chunk that consumed them).
+        int r[HP_PF][HP_ITEMS];
+        auto load_ranks = [&](int (&dst)[HP_ITEMS], int at, int bound) {
+#if SE_HP_ABLATE & 2            // timing experiment: no ranking traffic (wrong results)
+#pragma unroll
+            for (int e = 0; e < HP_ITEMS; e++) dst[e] = (at + e) % (int)gallery;
+            return;
+#endif
+            if (vec_ok && at + HP_ITEMS <= bound) {
+#pragma unroll
+                for (int v = 0; v < HP_ITEMS / 4; v++) {
+                    const int4 a = *reinterpret_cast<const int4 *>(rrow + at + 4 * v);
+                    dst[4 * v] = a.x; dst[4 * v + 1] = a.y; dst[4 * v + 2] = a.z; dst[4 * v + 3] = a.w;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < HP_ITEMS; e++) dst[e] = (at + e < bound) ? rrow[at + e] : 0;
+            }
+        };
+#pragma unroll
+        for (int u = 0; u < HP_PF; u++) load_ranks(r[u], tid * HP_ITEMS + u * HP_CHUNK, lp_bound);
+        const int32_t first = rrow[0];
         for (int c = tid; c < C; c += HP_THREADS) s_sim[c] = make_double2(wup[(int64_t)qc * C + c], lcs[(int64_t)qc * C + c]);
-        if (tid == 0) *s_qpos = 0x7FFFFFFF;
+        if (tid == 0) *s_qpos = (self >= 0 && first == self) ? 0 : 0x7FFFFFFF;
         if (tid < 4) s_ends[tid] = 0.0;
         __syncthreads();
-        // ---- position of the query in its own ranking (first hit; L if absent) ----
-        if (self >= 0) {   // chunk by chunk with a uniform early exit: the query is normally its own nearest neighbour
+        // ---- position of the query in its own ranking (first hit; L if absent): normally it is its own nearest neighbour (rank 0) ----
+        if (self >= 0 && first != self) {   // otherwise chunk by chunk with a uniform early exit
             for (int64_t b0 = 0; b0 < L; b0 += 4 * HP_THREADS) {
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
@@ -239,9 +270,6 @@ __global__ __launch_bounds__(HP_THREADS, SE_HP_WAVES_PER_SIMD) void hprec_kernel
                 if (found != 0x7FFFFFFF) break; // different exits and pair their barriers out of order)
             }
         }
-        __syncthreads();
-        // positions are int32 from here on (list_len < 2^31 - 4096 is checked at the entry point)
-        const int Li = (int)L;
         const int qpos = (*s_qpos == 0x7FFFFFFF) ? Li : *s_qpos;
         const int eff_len = (qpos < Li) ? Li - 1 : Li;                          // len(wup) after `del wup[qid_ind]`
         const int alen = (ahp_len > 0) ? (ahp_len < eff_len ? (int)ahp_len : eff_len) : eff_len;   // AHP window (effective ranks)
@@ -255,35 +283,39 @@ __global__ __launch_bounds__(HP_THREADS, SE_HP_WAVES_PER_SIMD) void hprec_kernel
         int car_r = 0;                        // relevant items so far
         double acc_w = 0.0, acc_l = 0.0, acc_ap = 0.0;                          // this thread's share of sum(cum / best) and of the AP terms
         int par = 0;
-        const double2 *rct = rc + tid;
+        const double2 *rct = rc;            // uniform: the chunk's table rows, indexed e * HP_THREADS + tid
         const int64_t half = ldc / 2;
-        // the 16 ranks a thread owns in a chunk; the next chunk's are requested right after the barrier of the current one, so that
-        // HBM latency runs under the walk (two workgroups of four waves per CU do not hide it by themselves)
-        int r[HP_ITEMS];
-        auto load_ranks = [&](int at) {
-            if (vec_ok && at + HP_ITEMS <= last_pos) {
+        int base = 0;
+        // 1 / (best - 1) of a thread's positions in a chunk: contiguous across the wave for every e (1 / best for the ranks ahead of
+        // the query: the second half of the class row)
+        auto load_curve = [&](double2 (&dst)[HP_ITEMS], const double2 *rows, int at) {
 #pragma unroll
-                for (int v = 0; v < HP_ITEMS / 4; v++) {
-                    const int4 a = *reinterpret_cast<const int4 *>(rrow + at + 4 * v);
-                    r[4 * v] = a.x; r[4 * v + 1] = a.y; r[4 * v + 2] = a.z; r[4 * v + 3] = a.w;
-                }
-            } else {
+            for (int e = 0; e < HP_ITEMS; e++) dst[e] = rows[e * HP_THREADS + tid + ((at + e < qpos) ? half : 0)];
+#if SE_HP_ABLATE & 1            // timing experiment: no curve traffic (wrong results)
 #pragma unroll
-                for (int e = 0; e < HP_ITEMS; e++) r[e] = (at + e < last_pos) ? rrow[at + e] : 0;
-            }
+            for (int e = 0; e < HP_ITEMS; e++) dst[e] = make_double2(1.0 / (double)(at + e + 2), 0.5);
+#endif
         };
-        load_ranks(tid * HP_ITEMS);
-        for (int base = 0; base < last_pos; base += HP_CHUNK, par ^= 1, rct += HP_CHUNK) {
+#if SE_HP_PF_CURVE
+        double2 tq[HP_PF][HP_ITEMS];            // build option: the curve is requested HP_PF chunks ahead as well
+#pragma unroll
+        for (int u = 0; u < HP_PF; u++)
+            if (u * HP_CHUNK < last_pos) load_curve(tq[u], rct + u * HP_CHUNK, tid * HP_ITEMS + u * HP_CHUNK);
+        auto step = [&](int (&rr)[HP_ITEMS], double2 (&t)[HP_ITEMS]) {
+#else
+        auto step = [&](int (&rr)[HP_ITEMS]) {
+#endif
             const int i0 = base + tid * HP_ITEMS;
             const bool cuts = (nk > 0) && (base <= kmax);               // uniform: a cut-off may fall into this chunk
             // One chunk.  FAST = an interior chunk (uniform test below): every position is live, behind the query, inside the AHP
             // window and away from its end points and from the cut-offs -- nothing to mask or test per rank.
             auto chunk = [&](auto fast_c) {
                 constexpr bool FAST = decltype(fast_c)::value;
+#if !SE_HP_PF_CURVE
                 double2 t[HP_ITEMS];              // 1 / (best - 1) of these positions: contiguous across the wave for every e
-#pragma unroll                                    // (1 / best for the ranks ahead of the query: the second half of the class row)
-                for (int e = 0; e < HP_ITEMS; e++) t[e] = rct[e * HP_THREADS + ((!FAST && i0 + e < qpos) ? half : 0)];
-                double2 sv[HP_ITEMS];             // rank -> class -> similarity pair
+                load_curve(t, rct, i0);
+#endif
+                double2 sv[HP_ITEMS];             // rank -> class -> similarity pair, summed up inside the thread
                 unsigned rel = 0;                 // bit e: position e is of the query's class
                 double tw = 0.0, tl = 0.0;
 #pragma unroll
@@ -291,15 +323,15 @@ __global__ __launch_bounds__(HP_THREADS, SE_HP_WAVES_PER_SIMD) void hprec_kernel
                     const int i = i0 + e;
                     const bool live = FAST || ((i < last_pos) && (i != qpos));
                     int c = 0;
-                    if (CLSW == 1) c = s_cls8[r[e]];
-                    else if (CLSW == 2) c = s_cls16[r[e]];
-                    else if (live) c = cls[r[e]];
+                    if (CLSW == 1) c = s_cls8[rr[e]];
+                    else if (CLSW == 2) c = s_cls16[rr[e]];
+                    else if (live) c = cls[rr[e]];
                     double2 v = s_sim[c];
                     if (!FAST) { v.x = live ? v.x : 0.0; v.y = live ? v.y : 0.0; }
-                    sv[e] = v;
                     rel |= (live && c == qc) ? (1u << e) : 0u;
                     tw += v.x; tl += v.y;
-                }
+                    sv[e] = make_double2(tw, tl);      // inclusive prefix inside the thread: the walk below adds the thread's base to each,
+                }                                      // 16 independent additions instead of a second dependent chain
                 const int tr = __popc(rel);
                 // ---- workgroup exclusive scan of the thread totals: DPP inside the wave, wave totals through LDS ----
                 const double iw = wave_incl_scan_f64(tw), il = wave_incl_scan_f64(tl);
@@ -307,7 +339,7 @@ __global__ __launch_bounds__(HP_THREADS, SE_HP_WAVES_PER_SIMD) void hprec_kernel
                 double *part = s_part + par * (HP_WAVES * 3);
                 if (lane == 63) { part[wave * 3 + 0] = iw; part[wave * 3 + 1] = il; part[wave * 3 + 2] = (double)ir; }
                 __syncthreads();   // the only barrier of a chunk: the other half of s_part is written next time
-                load_ranks(i0 + HP_CHUNK);
+                load_ranks(rr, i0 + HP_PF * HP_CHUNK, last_pos);
                 double cw = car_w + (iw - tw), cl = car_l + (il - tl);     // sums BEFORE this thread's first element
                 int cr = car_r + (ir - tr);
 #pragma unroll
@@ -328,14 +360,16 @@ __global__ __launch_bounds__(HP_THREADS, SE_HP_WAVES_PER_SIMD) void hprec_kernel
                     }
                     if (kat < nk) knext = s_ks[kat];
                 }
+                double odd_w = 0.0, odd_l = 0.0;       // second accumulator pair of the interior path (shorter FMA chains)
 #pragma unroll
                 for (int e = 0; e < HP_ITEMS; e++) {
                     const int i = i0 + e;
-                    cw += sv[e].x; cl += sv[e].y;
+                    const double cwe = cw + sv[e].x, cle = cl + sv[e].y;      // cumulative similarity up to and including this rank
                     if (FAST) {
-                        acc_w += cw * t[e].x; acc_l += cl * t[e].y;
+                        if (e & 1) { odd_w = fma(cwe, t[e].x, odd_w); odd_l = fma(cle, t[e].y, odd_l); }
+                        else { acc_w = fma(cwe, t[e].x, acc_w); acc_l = fma(cle, t[e].y, acc_l); }
                     } else if (i < last_pos && i != qpos) {
-                        const double yw = cw * t[e].x, yl = cl * t[e].y;
+                        const double yw = cwe * t[e].x, yl = cle * t[e].y;
                         const int j = (i < qpos) ? i : i - 1;                   // effective rank
                         if (ahp_len >= 0 && j < alen) {
                             acc_w += yw; acc_l += yl;
@@ -351,6 +385,7 @@ __global__ __launch_bounds__(HP_THREADS, SE_HP_WAVES_PER_SIMD) void hprec_kernel
                         }
                     }
                 }
+                if (FAST) { acc_w += odd_w; acc_l += odd_l; }
                 // ---- AP: precision at the relevant ranks (about one in C ranks: a loop over the set bits, not a test per rank) ----
                 if (want_ap) {
                     for (unsigned m = rel; m; m &= m - 1) {
@@ -359,14 +394,27 @@ __global__ __launch_bounds__(HP_THREADS, SE_HP_WAVES_PER_SIMD) void hprec_kernel
                         acc_ap += (double)(cr + __popc(rel & ((2u << e) - 1u))) * fast_rcp_f64((double)j1);
                     }
                 }
+#if SE_HP_PF_CURVE
+                if (base + HP_PF * HP_CHUNK < last_pos) load_curve(t, rct + HP_PF * HP_CHUNK, i0 + HP_PF * HP_CHUNK);
+#endif
             };
             const bool interior = vec_ok && ahp_len >= 0 && !cuts && base > qpos && base + HP_CHUNK <= last_pos && base + HP_CHUNK - 2 < alen - 1;
             if (interior) chunk(std::true_type{}); else chunk(std::false_type{});
+            base += HP_CHUNK; par ^= 1; rct += HP_CHUNK;
+        };
+        while (base < last_pos) {
+#pragma unroll
+            for (int u = 0; u < HP_PF; u++)
+#if SE_HP_PF_CURVE
+                if (base < last_pos) step(r[u], tq[u]);
+#else
+                if (base < last_pos) step(r[u]);
+#endif
         }
         // ---- finish: trapezoid and AP (the end points were left in LDS by whichever thread owned ranks 0 and alen - 1) ----
         {
-            const double f0 = wave_sum_f64(acc_w), f1 = wave_sum_f64(acc_l), f2 = wave_sum_f64(acc_ap);
-            if (lane == 0) { s_fin[wave * 3 + 0] = f0; s_fin[wave * 3 + 1] = f1; s_fin[wave * 3 + 2] = f2; }
+            const double f0 = wave_incl_scan_f64(acc_w), f1 = wave_incl_scan_f64(acc_l), f2 = wave_incl_scan_f64(acc_ap);   // lane 63: the wave's sums
+            if (lane == 63) { s_fin[wave * 3 + 0] = f0; s_fin[wave * 3 + 1] = f1; s_fin[wave * 3 + 2] = f2; }
             __syncthreads();
             if (tid == 0) {
                 double g0 = 0.0, g1 = 0.0, g2 = 0.0;

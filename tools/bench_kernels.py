@@ -28,6 +28,7 @@ def timeit(fn, reps):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("what", choices=["pdist", "rank", "loss", "topk", "hprec", "shard"])
+    ap.add_argument("--hp-mode", default="all", choices=["all", "whole", "sweep"], help="hprec: every configuration, or whole-list AHP + AP in class order only (profiling)")
     ap.add_argument("--n", type=int, default=50000)
     ap.add_argument("--q", type=int, default=None)
     ap.add_argument("--d", type=int, default=100)
@@ -77,12 +78,17 @@ def main():
         qidx = torch.arange(qq, dtype=torch.int32, device="cuda")
         curves = sehip.hprec_reciprocal_curves(best_d, best_d)
         qcls = cls[:qq].contiguous()
-        for name, ahp in (("whole-list AHP + AP", 0), ("AHP@250, no AP", 250)):
-            for order in (True, False):
+        for name, ahp in (("whole-list AHP + AP", 0), ("AHP@250, no AP", 250))[:1 if args.hp_mode != "all" else 2]:
+            for order in (True, False)[:1 if args.hp_mode != "all" else 2]:
                 med, mn = timeit(lambda: sehip.hierarchical_precision(rk, cls, qcls, qidx, tab_d, tab_d, best_d, best_d, ks, ahp_len=ahp,
                                                                       want_ap=(ahp == 0), curves=curves, class_order=order), args.reps)
                 print("hprec %-22s %-14s q=%d n=%d: median %.3f ms (min %.3f)  %.1f GB/s of ranks, %.1f Mranks/s" %
                       (name, "class order" if order else "query order", qq, n, med, mn, 4.0 * qq * n / med / 1e6, qq * n / med / 1e3))
+        if args.hp_mode == "sweep":     # per-query overhead (intercept) vs per-rank cost (slope)
+            for ll in (512, 4096, 8192, 16384, 32768, n):
+                med, mn = timeit(lambda: sehip.hierarchical_precision(rk, cls, qcls, qidx, tab_d, tab_d, best_d, best_d, ks, ahp_len=0, want_ap=True,
+                                                                      curves=curves, class_order=True, list_len=ll), args.reps)
+                print("hprec sweep list_len=%d: median %.3f ms" % (ll, med))
         med, mn = timeit(lambda: sehip.hprec_reciprocal_curves(best_d, best_d), args.reps)
         print("hprec reciprocal curves C=%d n=%d: median %.3f ms" % (C, n, med))
     elif args.what == "shard":
