@@ -7,16 +7,21 @@
 // the descending-sorted similarities of the whole gallery, cumulated) are computed once on the host and passed in;
 // the 0.6 h the reference spends here at N = 50k is the gather + prefix sums over Q x N ranks, which is this kernel.
 //
-// One 256-thread workgroup per query walks its ranking in 2048-rank chunks (thread t owns 8 consecutive ranks):
-// gather class -> similarity pair (LDS), float64 running sums by a DPP wave scan + one barrier per chunk (wave totals
-// double-buffered in LDS, the carry replicated in every thread), per-thread accumulation of the trapezoid / AP terms
-// (reduced once per query).  What the memory system sees, per rank: 4 B of the ranking (HBM, streamed), a 4-byte class
-// gather (L2) and 16 B of the query class's best curve.  The best curve enters as the pre-divided, chunk-transposed table
-// of `se_hprec_reciprocal_curves` -- 1 / (best[i] - 1) for both similarities, laid out so that a wave's loads are
-// contiguous -- which turns two float64 divisions per rank into two multiplications; and the queries are visited in class
-// order (`order_ws`: a counting sort of `qcls`, one contiguous segment of that order per XCD, handed out by per-XCD
-// atomic counters) so that the workgroups resident on an XCD stream the SAME 16 N-byte curve and it stays in that XCD's
-// 4 MB L2 instead of coming from HBM once per query.
+// Persistent 256-thread workgroups (two per CU) take one query at a time and walk its ranking in 4096-rank chunks (thread t owns
+// 16 consecutive ranks): rank -> class (a byte / 16-bit copy of the gallery's classes in LDS, filled once per workgroup) ->
+// similarity pair (LDS), float64 running sums by a DPP wave scan + ONE barrier per chunk (wave totals double-buffered in LDS,
+// the carry replicated in every thread), per-thread accumulation of the trapezoid / AP terms (reduced once per query).  Chunks
+// come in three forms: interior ones (every rank live, behind the query, inside the AHP window, no cut-off: 2 adds + 2 FMAs per
+// rank and nothing else), the one the list ends in (masked, otherwise the same), and the general form (first chunk: the query's
+// own position, the cut-offs -- sorted once per workgroup and merged with each thread's consecutive ranks -- and the end points).
+// What the memory system sees per rank: 4 B of the ranking (HBM, requested a chunk ahead) and 16 B of the query class's best
+// curve.  The curve enters as the pre-divided, chunk-transposed table of `se_hprec_reciprocal_curves` -- 1 / (best[i] - 1) for
+// the ranks behind the query, 1 / best[i] for those ahead of it, laid out so that a wave's loads are contiguous -- which turns
+// two float64 divisions per rank into two multiplications; and the queries are visited in class order (`order_ws`: a counting
+// sort of `qcls`, one contiguous segment of that order per XCD, handed out by per-XCD atomic counters, the next draw in flight
+// while a query is processed) so that the workgroups resident on an XCD stream the SAME 16 N-byte curve and it stays in that
+// XCD's 4 MB L2 instead of coming from HBM once per query.  Measured bound (phase profile, -DSE_HP_PROFILE=1): the interior
+// chunks wait on their 20 B per rank of L2 -> L1 traffic (~9 TB/s aggregate); DESIGN.md section 5.3b has the numbers.
 // Bookkeeping kept from the reference: the query itself is dropped from its ranking (position q_pos), which shifts
 // the best curve left there and subtracts its self-similarity 1.0 (class_hierarchy.py:280-290); AHP is numpy's
 // trapz of cum / best with dx = 1 / length; AP is the mean over the relevant ranks of precision at that rank.
@@ -36,11 +41,14 @@ namespace se {
 #ifndef SE_HP_PF
 #define SE_HP_PF 1              // chunks of rank look-ahead
 #endif
-#ifndef SE_HP_ABLATE
-#define SE_HP_ABLATE 0          // timing experiments only (1: no curve loads, 2: no rank loads); never in a shipped build
+#ifndef SE_HP_PROFILE
+#define SE_HP_PROFILE 0         // experiment build: shader-clock cycles per phase of wave 0 of every workgroup, printed after each launch
 #endif
-#ifndef SE_HP_PF_CURVE
-#define SE_HP_PF_CURVE 0        // 1: the best curve is requested SE_HP_PF chunks ahead too (SE_HP_PF more register sets of it)
+#if SE_HP_PROFILE
+__device__ unsigned long long hp_prof[16];
+#define HP_T(i) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); if (tid == 0) hp_acc[i] += now_ - hp_last; hp_last = now_; }
+#else
+#define HP_T(i) {}
 #endif
 constexpr int HP_THREADS = SE_HP_THREADS;
 constexpr int HP_WAVES = HP_THREADS / WAVE;
@@ -167,10 +175,20 @@ __global__ __launch_bounds__(HP_THREADS, SE_HP_WAVES_PER_SIMD) void hprec_kernel
     unsigned short *s_cls16 = reinterpret_cast<unsigned short *>(s_cls8);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
+#if SE_HP_PROFILE
+    unsigned long long hp_acc[16] = {}, hp_last = __builtin_amdgcn_s_memtime();
+#endif
     // ---- once per workgroup: the gallery's classes into LDS, the cut-offs sorted (rank by counting; ties keep their order) ----
     if (CLSW == 1) {
         unsigned *w = reinterpret_cast<unsigned *>(s_cls8);
-        for (int64_t i = (int64_t)tid * 4; i < gallery; i += HP_THREADS * 4) {
+        const int64_t quads = (reinterpret_cast<uintptr_t>(cls) % 16 == 0) ? gallery / 4 : 0;     // 16-byte loads, 8 in flight per thread
+        const int4 *c4 = reinterpret_cast<const int4 *>(cls);
+#pragma unroll 8
+        for (int64_t g = tid; g < quads; g += HP_THREADS) {
+            const int4 v = c4[g];
+            w[g] = ((unsigned)v.x & 0xFFu) | (((unsigned)v.y & 0xFFu) << 8) | (((unsigned)v.z & 0xFFu) << 16) | ((unsigned)v.w << 24);
+        }
+        for (int64_t i = quads * 4 + (int64_t)tid * 4; i < gallery; i += HP_THREADS * 4) {
             unsigned v = 0;
 #pragma unroll
             for (int e = 0; e < 4; e++) v |= (i + e < gallery ? (unsigned)cls[i + e] & 0xFFu : 0u) << (8 * e);
@@ -178,17 +196,31 @@ __global__ __launch_bounds__(HP_THREADS, SE_HP_WAVES_PER_SIMD) void hprec_kernel
         }
     } else if (CLSW == 2) {
         unsigned *w = reinterpret_cast<unsigned *>(s_cls16);
+#pragma unroll 8
         for (int64_t i = (int64_t)tid * 2; i < gallery; i += HP_THREADS * 2)
             w[i >> 1] = ((unsigned)cls[i] & 0xFFFFu) | ((i + 1 < gallery ? (unsigned)cls[i + 1] & 0xFFFFu : 0u) << 16);
     }
-    for (int s = tid; s < nk; s += HP_THREADS) {
-        const int k = ks[s];
+    for (int s = tid; s < nk; s += HP_THREADS) s_perm[s] = ks[s];       // raw cut-offs (LDS copy), ranked below
+    __syncthreads();
+    int my_k[(HP_MAX_KS + HP_THREADS - 1) / HP_THREADS], my_r[(HP_MAX_KS + HP_THREADS - 1) / HP_THREADS];
+#pragma unroll
+    for (int v = 0; v < (HP_MAX_KS + HP_THREADS - 1) / HP_THREADS; v++) {
+        const int s = tid + v * HP_THREADS;
+        my_k[v] = s < nk ? s_perm[s] : 0;
         int r = 0;
-        for (int u = 0; u < nk; u++) { const int ku = ks[u]; r += (ku < k || (ku == k && u < s)) ? 1 : 0; }
-        s_ks[r] = k; s_perm[r] = s;
+        if (s < nk)
+            for (int u = 0; u < nk; u++) { const int ku = s_perm[u]; r += (ku < my_k[v] || (ku == my_k[v] && u < s)) ? 1 : 0; }
+        my_r[v] = r;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int v = 0; v < (HP_MAX_KS + HP_THREADS - 1) / HP_THREADS; v++) {
+        const int s = tid + v * HP_THREADS;
+        if (s < nk) { s_ks[my_r[v]] = my_k[v]; s_perm[my_r[v]] = s; }
     }
     __syncthreads();
     const int kmax = nk > 0 ? s_ks[nk - 1] : 0;                    // cut-offs live at original positions <= kmax
+    HP_T(0)
 
     // ---- which queries this workgroup takes: class order, one segment of it per XCD (blockIdx round-robins the XCDs), stealing
     //      from the next segments once its own is empty; or every gridDim-th query when no workspace was given ----
@@ -233,11 +265,6 @@ __global__ __launch_bounds__(HP_THREADS, SE_HP_WAVES_PER_SIMD) void hprec_kernel
         // the chunk that consumed them).
         int r[HP_PF][HP_ITEMS];
         auto load_ranks = [&](int (&dst)[HP_ITEMS], int at, int bound) {
-#if SE_HP_ABLATE & 2            // timing experiment: no ranking traffic (wrong results)
-#pragma unroll
-            for (int e = 0; e < HP_ITEMS; e++) dst[e] = (at + e) % (int)gallery;
-            return;
-#endif
             if (vec_ok && at + HP_ITEMS <= bound) {
 #pragma unroll
                 for (int v = 0; v < HP_ITEMS / 4; v++) {
@@ -279,6 +306,7 @@ __global__ __launch_bounds__(HP_THREADS, SE_HP_WAVES_PER_SIMD) void hprec_kernel
         if (want_ap) need = eff_len;
         const int last_pos = (need < Li) ? need + 1 : Li;                       // original positions [0, last_pos) cover `need` effective ranks
 
+        HP_T(1)
         double car_w = 0.0, car_l = 0.0;      // running similarity sums up to the current chunk (the same value in every thread)
         int car_r = 0;                        // relevant items so far
         double acc_w = 0.0, acc_l = 0.0, acc_ap = 0.0;                          // this thread's share of sum(cum / best) and of the AP terms
@@ -288,40 +316,30 @@ __global__ __launch_bounds__(HP_THREADS, SE_HP_WAVES_PER_SIMD) void hprec_kernel
         int base = 0;
         // 1 / (best - 1) of a thread's positions in a chunk: contiguous across the wave for every e (1 / best for the ranks ahead of
         // the query: the second half of the class row)
-        auto load_curve = [&](double2 (&dst)[HP_ITEMS], const double2 *rows, int at) {
+        auto load_curve = [&](auto behind_c, double2 (&dst)[HP_ITEMS], const double2 *rows, int at) {
+            constexpr bool BEHIND = decltype(behind_c)::value;       // every position is known to lie behind the query
 #pragma unroll
-            for (int e = 0; e < HP_ITEMS; e++) dst[e] = rows[e * HP_THREADS + tid + ((at + e < qpos) ? half : 0)];
-#if SE_HP_ABLATE & 1            // timing experiment: no curve traffic (wrong results)
-#pragma unroll
-            for (int e = 0; e < HP_ITEMS; e++) dst[e] = make_double2(1.0 / (double)(at + e + 2), 0.5);
-#endif
+            for (int e = 0; e < HP_ITEMS; e++) dst[e] = rows[e * HP_THREADS + tid + ((!BEHIND && at + e < qpos) ? half : 0)];
         };
-#if SE_HP_PF_CURVE
-        double2 tq[HP_PF][HP_ITEMS];            // build option: the curve is requested HP_PF chunks ahead as well
-#pragma unroll
-        for (int u = 0; u < HP_PF; u++)
-            if (u * HP_CHUNK < last_pos) load_curve(tq[u], rct + u * HP_CHUNK, tid * HP_ITEMS + u * HP_CHUNK);
-        auto step = [&](int (&rr)[HP_ITEMS], double2 (&t)[HP_ITEMS]) {
-#else
         auto step = [&](int (&rr)[HP_ITEMS]) {
-#endif
             const int i0 = base + tid * HP_ITEMS;
             const bool cuts = (nk > 0) && (base <= kmax);               // uniform: a cut-off may fall into this chunk
-            // One chunk.  FAST = an interior chunk (uniform test below): every position is live, behind the query, inside the AHP
-            // window and away from its end points and from the cut-offs -- nothing to mask or test per rank.
-            auto chunk = [&](auto fast_c) {
-                constexpr bool FAST = decltype(fast_c)::value;
-#if !SE_HP_PF_CURVE
+            // One chunk, in one of three forms (uniform tests below).  FAST: an interior chunk -- every position is live, behind the
+            // query, inside the AHP window and away from its end points and from the cut-offs: nothing to mask or test per rank.
+            // TAIL: the same except that the list ends inside the chunk (whole-list AHP: its last end point is taken in the finish
+            // step): positions are masked, nothing else.  Otherwise the general form.
+            auto chunk = [&](auto mode_c) {
+                constexpr int MODE = decltype(mode_c)::value;
+                constexpr bool FAST = MODE == 1, TAIL = MODE == 2;
                 double2 t[HP_ITEMS];              // 1 / (best - 1) of these positions: contiguous across the wave for every e
-                load_curve(t, rct, i0);
-#endif
+                load_curve(std::integral_constant<bool, FAST || TAIL>{}, t, rct, i0);
                 double2 sv[HP_ITEMS];             // rank -> class -> similarity pair, summed up inside the thread
                 unsigned rel = 0;                 // bit e: position e is of the query's class
                 double tw = 0.0, tl = 0.0;
 #pragma unroll
                 for (int e = 0; e < HP_ITEMS; e++) {
                     const int i = i0 + e;
-                    const bool live = FAST || ((i < last_pos) && (i != qpos));
+                    const bool live = FAST || ((i < last_pos) && (TAIL || i != qpos));
                     int c = 0;
                     if (CLSW == 1) c = s_cls8[rr[e]];
                     else if (CLSW == 2) c = s_cls16[rr[e]];
@@ -333,12 +351,15 @@ __global__ __launch_bounds__(HP_THREADS, SE_HP_WAVES_PER_SIMD) void hprec_kernel
                     sv[e] = make_double2(tw, tl);      // inclusive prefix inside the thread: the walk below adds the thread's base to each,
                 }                                      // 16 independent additions instead of a second dependent chain
                 const int tr = __popc(rel);
+                if (FAST) HP_T(2)
                 // ---- workgroup exclusive scan of the thread totals: DPP inside the wave, wave totals through LDS ----
                 const double iw = wave_incl_scan_f64(tw), il = wave_incl_scan_f64(tl);
                 const int ir = wave_incl_scan_i32(tr);
+                if (FAST) HP_T(3)
                 double *part = s_part + par * (HP_WAVES * 3);
                 if (lane == 63) { part[wave * 3 + 0] = iw; part[wave * 3 + 1] = il; part[wave * 3 + 2] = (double)ir; }
                 __syncthreads();   // the only barrier of a chunk: the other half of s_part is written next time
+                if (FAST) HP_T(4)
                 load_ranks(rr, i0 + HP_PF * HP_CHUNK, last_pos);
                 double cw = car_w + (iw - tw), cl = car_l + (il - tl);     // sums BEFORE this thread's first element
                 int cr = car_r + (ir - tr);
@@ -349,9 +370,10 @@ __global__ __launch_bounds__(HP_THREADS, SE_HP_WAVES_PER_SIMD) void hprec_kernel
                     if (w < wave) { cw += pw; cl += pl; cr += pr; }
                     car_w += pw; car_l += pl; car_r += pr;
                 }
+                if (FAST) HP_T(5)
                 // ---- walk the 16 positions: cumulative sums, cum / best, trapezoid terms, the cut-offs ----
                 int kat = 0, knext = 0x7FFFFFFF;
-                if (!FAST && cuts) {            // lower bound of this thread's first effective rank + 1 among the sorted cut-offs
+                if (MODE == 0 && cuts) {        // lower bound of this thread's first effective rank + 1 among the sorted cut-offs
                     const int k0 = (i0 <= qpos) ? i0 + 1 : i0;
                     int hi = nk;
                     while (kat < hi) {
@@ -368,13 +390,15 @@ __global__ __launch_bounds__(HP_THREADS, SE_HP_WAVES_PER_SIMD) void hprec_kernel
                     if (FAST) {
                         if (e & 1) { odd_w = fma(cwe, t[e].x, odd_w); odd_l = fma(cle, t[e].y, odd_l); }
                         else { acc_w = fma(cwe, t[e].x, acc_w); acc_l = fma(cle, t[e].y, acc_l); }
+                    } else if (TAIL) {
+                        if (i < last_pos) { acc_w = fma(cwe, t[e].x, acc_w); acc_l = fma(cle, t[e].y, acc_l); }
                     } else if (i < last_pos && i != qpos) {
                         const double yw = cwe * t[e].x, yl = cle * t[e].y;
                         const int j = (i < qpos) ? i : i - 1;                   // effective rank
                         if (ahp_len >= 0 && j < alen) {
                             acc_w += yw; acc_l += yl;
                             if (j == 0) { s_ends[0] = yw; s_ends[1] = yl; }
-                            if (j == alen - 1) { s_ends[2] = yw; s_ends[3] = yl; }
+                            if (ahp_len > 0 && j == alen - 1) { s_ends[2] = yw; s_ends[3] = yl; }   // whole list: taken in the finish step
                         }
                         if (cuts && j < kmax) {   // hierarchical precision at k = j + 1, if that is a cut-off: the thread's ranks are
                             while (knext < j + 1) knext = (++kat < nk) ? s_ks[kat] : 0x7FFFFFFF;   // consecutive, so it merges them with
@@ -386,6 +410,7 @@ __global__ __launch_bounds__(HP_THREADS, SE_HP_WAVES_PER_SIMD) void hprec_kernel
                     }
                 }
                 if (FAST) { acc_w += odd_w; acc_l += odd_l; }
+                if (FAST) HP_T(6)
                 // ---- AP: precision at the relevant ranks (about one in C ranks: a loop over the set bits, not a test per rank) ----
                 if (want_ap) {
                     for (unsigned m = rel; m; m &= m - 1) {
@@ -394,22 +419,18 @@ __global__ __launch_bounds__(HP_THREADS, SE_HP_WAVES_PER_SIMD) void hprec_kernel
                         acc_ap += (double)(cr + __popc(rel & ((2u << e) - 1u))) * fast_rcp_f64((double)j1);
                     }
                 }
-#if SE_HP_PF_CURVE
-                if (base + HP_PF * HP_CHUNK < last_pos) load_curve(t, rct + HP_PF * HP_CHUNK, i0 + HP_PF * HP_CHUNK);
-#endif
             };
             const bool interior = vec_ok && ahp_len >= 0 && !cuts && base > qpos && base + HP_CHUNK <= last_pos && base + HP_CHUNK - 2 < alen - 1;
-            if (interior) chunk(std::true_type{}); else chunk(std::false_type{});
+            const bool tail = ahp_len == 0 && !cuts && base > qpos;
+            if (interior) { chunk(std::integral_constant<int, 1>{}); HP_T(7) }
+            else if (tail) { chunk(std::integral_constant<int, 2>{}); HP_T(8) }
+            else { chunk(std::integral_constant<int, 0>{}); HP_T(8) }
             base += HP_CHUNK; par ^= 1; rct += HP_CHUNK;
         };
         while (base < last_pos) {
 #pragma unroll
             for (int u = 0; u < HP_PF; u++)
-#if SE_HP_PF_CURVE
-                if (base < last_pos) step(r[u], tq[u]);
-#else
                 if (base < last_pos) step(r[u]);
-#endif
         }
         // ---- finish: trapezoid and AP (the end points were left in LDS by whichever thread owned ranks 0 and alen - 1) ----
         {
@@ -419,6 +440,11 @@ __global__ __launch_bounds__(HP_THREADS, SE_HP_WAVES_PER_SIMD) void hprec_kernel
             if (tid == 0) {
                 double g0 = 0.0, g1 = 0.0, g2 = 0.0;
                 for (int w = 0; w < HP_WAVES; w++) { g0 += s_fin[w * 3 + 0]; g1 += s_fin[w * 3 + 1]; g2 += s_fin[w * 3 + 2]; }
+                if (ahp_len == 0 && eff_len > 0) {   // whole list: y[-1] = all similarities / best at the last rank that is not the query
+                    const int i_last = (eff_len - 1 < qpos) ? eff_len - 1 : eff_len;
+                    const double2 tl = rc[hp_slot(i_last) + (i_last < qpos ? half : 0)];
+                    s_ends[2] = car_w * tl.x; s_ends[3] = car_l * tl.y;
+                }
                 if (ahp_len >= 0) {
                     // np.trapz(y, dx) = dx * (sum(y) - (y[0] + y[-1]) / 2), dx = 1 / len(wup) (whole list) or 1 / clip
                     const double dx = 1.0 / (double)((ahp_len > 0) ? ahp_len : eff_len);
@@ -428,7 +454,12 @@ __global__ __launch_bounds__(HP_THREADS, SE_HP_WAVES_PER_SIMD) void hprec_kernel
                 if (want_ap) orow[2 * nk + 2] = car_r > 0 ? g2 / (double)car_r : 0.0;
             }
         }
+        HP_T(9)
     }
+#if SE_HP_PROFILE
+    if (tid == 0)
+        for (int i = 0; i < 16; i++) atomicAdd(&hp_prof[i], hp_acc[i]);
+#endif
 }
 
 }  // namespace se
@@ -520,5 +551,19 @@ extern "C" int se_hierarchical_precision(const int32_t *rank, int64_t ldr, int64
     else SE_HP_LAUNCH(0);
 #undef SE_HP_LAUNCH
     SE_LAUNCH_CHECK();
+#if SE_HP_PROFILE
+    {
+        unsigned long long h[16], z[16] = {};
+        SE_HIP_CHECK(hipStreamSynchronize(s));
+        SE_HIP_CHECK(hipMemcpyFromSymbol(h, HIP_SYMBOL(hp_prof), sizeof(h)));
+        SE_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(hp_prof), z, sizeof(z)));
+        static const char *names[10] = {"setup", "query-prologue", "lookups", "scans", "barrier", "parts", "walk", "ap+rest(fast)", "slow-chunk", "finish"};
+        double tot = 0;
+        for (int i = 0; i < 10; i++) tot += (double)h[i];
+        fprintf(stderr, "[se_hierarchical_precision profile] grid=%lld q=%lld len=%lld: cycles per workgroup %.0f;", (long long)grid, (long long)q, (long long)list_len, tot / (double)grid);
+        for (int i = 0; i < 10; i++) fprintf(stderr, " %s %.1f%%", names[i], 100.0 * (double)h[i] / tot);
+        fprintf(stderr, "\n");
+    }
+#endif
     return SE_OK;
 }
