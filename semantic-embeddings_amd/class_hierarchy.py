@@ -274,7 +274,7 @@ class ClassHierarchy(object):
 
     def hierarchical_precision_device(self, features, labels, ks=[1, 10, 50, 100], compute_ahp=False, compute_ap=False,
                                       normalize=False, ids=None, tile_rows=None, distributed=False, group=None, kblocks=None,
-                                      gather_per_query=True, kernels=None, per_query=True):
+                                      gather_per_query=True, kernels=None, per_query=True, head_via_topk=True):
         """``hierarchical_precision(pairwise_retrieval(features, normalize), labels, ...)`` (ignore_qids = True, every
         image is query and gallery item) without leaving the GPU: the rankings stay device tensors
         (``evaluate_retrieval.ranking_tiles``) and the per-query gather + prefix sums run in
@@ -294,6 +294,8 @@ class ClassHierarchy(object):
         * otherwise (P@k and AHP@clip only) the GALLERY is sharded: per-shard fused distance + top-L with
           L = max(ks, clip) + 1, RCCL all-gather of the ``(distance, global index)`` lists, canonical k-way merge
           (``sharded_retrieval.sharded_topk``), then each rank scores its share of the queries.
+        With one process the same fused top-L path serves P@k / AHP@clip-only requests (``head_via_topk``; the full-ranking
+        path otherwise).
         ``kernels`` (tests): CPU stand-ins ``{'ranking_tiles', 'hierarchical_precision', 'local_topk', 'merge', 'device'}``."""
         import torch
         from sharded_retrieval import shard_bounds, sharded_topk
@@ -347,8 +349,9 @@ class ClassHierarchy(object):
             import sehip
             return {'curves': sehip.hprec_reciprocal_curves(args_d[2], args_d[3])}
 
-        if world > 1 and head_only:
-            # ---- sharded gallery: top-L lists are enough for every requested metric ----
+        if head_only and (world > 1 or (head_via_topk and kblocks is None)):
+            # ---- top-L lists are enough for every requested metric: fused distance + top-L (the N x N matrix is never written),
+            #      over this rank's shard of the gallery when there are several ranks ----
             L = min(n, max(ks + [ahp_clip or 0]) + 1)
             best_w, best_l = best_w[:, :L + 1], best_l[:, :L + 1]
             args_d = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (wup_t, lcs_t, best_w, best_l)]
