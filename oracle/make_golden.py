@@ -10,6 +10,8 @@ from /root/reference (see oracle/ref_import.py), on seeded inputs:
 * hierarchy_cifar.npz ``ClassHierarchy.hierarchical_precision`` outputs
                       (class_hierarchy.py:211-316) for a small retrieval problem + the taxonomy
                       edges (Cifar-Hierarchy/cifar.parent-child.txt: data file)
+* hierarchy_cub.npz, hierarchy_ilsvrc.npz   the same for the reference's CUB balanced (200 classes) and ILSVRC WordNet min-tree
+                      (1000 string-id classes) taxonomies
 * loss_cifar100.npz   seeded inputs + loss oracle outputs (round-1 fixture, kept)
 * loss_ref_*.npz      seeded inputs + the outputs of the reference's OWN utils.py:34-127 and
                       learn_labelembedding.py:17-37, imported unmodified and evaluated on the NumPy
@@ -79,6 +81,44 @@ def probe_kblocks(feat):
             return kb
     raise RuntimeError("host BLAS summation order not reproduced for D=%d" % x.shape[1])
 
+
+
+def hierarchy_goldens_more(er, ch):
+    """hierarchy_cub.npz / hierarchy_ilsvrc.npz: ``ClassHierarchy.hierarchical_precision`` (class_hierarchy.py:211-316) of the
+    unmodified reference on its own rankings for the two other taxonomies it ships -- CUB balanced (200 integer classes) and the
+    ILSVRC WordNet min-tree (1000 string-id classes: more than 256, the 16-bit class table of the GPU kernel).  Small retrieval
+    problems (the reference walks every ranking in Python); whole-list and clipped AHP, AP, cosine and Euclidean branch."""
+    import json
+    rng = np.random.default_rng(23)
+    cases = {}
+    with open(os.path.join(REF, "CUB-Hierarchy", "classes_balanced.txt")) as f:
+        cub_classes = [int(l.split()[0]) for l in f if l.strip()]
+    cases["cub"] = (os.path.join(REF, "CUB-Hierarchy", "cub_balanced.parent-child.txt"), int, cub_classes[:200], 520, 24)
+    with open(os.path.join(REF, "ILSVRC", "imagenet_class_index.json")) as f:
+        idx = json.load(f)
+    cases["ilsvrc"] = (os.path.join(REF, "ILSVRC", "wordnet.parent-child.mintree.txt"), str, [idx[str(i)][0] for i in range(1000)], 1400, 32)
+    for name, (path, id_type, classes, n, d) in cases.items():
+        hier = ch.ClassHierarchy.from_file(path, id_type=id_type)
+        with open(path) as f:
+            edges = np.array([l.split()[:2] for l in f if l.strip()])
+        lab_idx = np.concatenate([np.arange(len(classes)), rng.integers(0, len(classes), size=n - len(classes))]) if n > len(classes) \
+            else rng.integers(0, len(classes), size=n)
+        rng.shuffle(lab_idx)
+        labels = [classes[i] for i in lab_idx]
+        centers = rng.standard_normal((len(classes), d)).astype(np.float32)
+        feats = (centers[lab_idx] + 0.9 * rng.standard_normal((n, d))).astype(np.float32)
+        ks = [1, 10, 50, 100]
+        res = {}
+        for norm in (True, False):
+            for ahp in (True, 50):
+                avg, _ = hier.hierarchical_precision(er.pairwise_retrieval(feats.copy(), normalize=norm), labels, ks, compute_ahp=ahp,
+                                                     compute_ap=True, all_ids=list(range(n)))
+                for m, v in avg.items():
+                    res["%s|norm=%d|ahp=%s" % (m, norm, ahp)] = v
+        np.savez_compressed(os.path.join(OUT, "hierarchy_%s.npz" % name), edges=edges, labels=np.array(labels), features=feats,
+                            ks=np.array(ks), metric_names=np.array(list(res.keys())), metric_values=np.array(list(res.values())),
+                            id_type=np.array("int" if id_type is int else "str"))
+        print("hierarchy", name, "classes", len(set(labels)), "n", n, {k: round(v, 4) for k, v in list(res.items())[:3]})
 
 def regenerate_imagenet_mintree():
     """embeddings/imagenet_mintree.unitsphere.pickle is missing from the checkout (.MISSING_LARGE_BLOBS): rerun the reference's
@@ -258,6 +298,8 @@ def main():
                         metric_values=np.array(list(res.values())), wup=wup, lcs=lcs,
                         heights=np.array([hier.heights[i] for i in sorted(hier.nodes)]),
                         nodes=np.array(sorted(hier.nodes)), max_height=hier.max_height)
+
+    hierarchy_goldens_more(er, ch)
 
     # ---------------------------------------------------------------- loss golden (oracle; unpinned)
     rng = np.random.default_rng(1)

@@ -160,6 +160,29 @@ def test_se_hierarchical_precision_general_rankings(n, q, class_order, with_qidx
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", ["cub", "ilsvrc"])
+def test_hierarchical_precision_device_other_taxonomies(name, tmp_path):
+    """Device metrics on CUB (200 classes: byte class table) and the ILSVRC min-tree (1000 string-id classes: 16-bit class table when
+    the lists are long, global gather for the clipped ones; queries without any relevant image) vs the REFERENCE's own outputs
+    (tests/golden/hierarchy_{cub,ilsvrc}.npz), full rankings and the fused top-L path."""
+    from test_host import TIE_NOISE, _hierarchy_from_fixture
+    g = np.load(os.path.join(GOLDEN, "hierarchy_%s.npz" % name))
+    h, labels = _hierarchy_from_fixture(g, tmp_path)
+    ks = g["ks"].tolist()
+    want = dict(zip(g["metric_names"].tolist(), g["metric_values"].tolist()))
+    for norm in (True, False):
+        for ahp in (True, 50):
+            avg, per_q = h.hierarchical_precision_device(g["features"].copy(), labels, ks, compute_ahp=ahp, compute_ap=True, normalize=norm)
+            assert len(per_q["AP"]) == len(labels)
+            for m, v in avg.items():
+                assert v == pytest.approx(want["%s|norm=%d|ahp=%s" % (m, norm, ahp)], rel=1e-10 + TIE_NOISE[norm], abs=1e-10 + TIE_NOISE[norm]), (m, norm, ahp)
+        head, none = h.hierarchical_precision_device(g["features"].copy(), labels, ks, compute_ahp=50, compute_ap=False, normalize=norm, per_query=False)
+        assert none is None
+        for m, v in head.items():      # P@k and AHP@50 from top-101 lists only
+            assert v == pytest.approx(want["%s|norm=%d|ahp=50" % (m, norm)], rel=1e-10 + TIE_NOISE[norm], abs=1e-10 + TIE_NOISE[norm]), (m, norm)
+
+
+@pytest.mark.gpu
 def test_training_graph_replay_matches_eager_steps_and_keeps_state():
     """Trainer.enable_graphs (fp32 NCHW backbone_mode of the CIFAR ResNets): capture must leave parameters, velocity and
     BatchNorm buffers untouched, replayed steps must follow the eager trajectory, a short batch runs eagerly."""
