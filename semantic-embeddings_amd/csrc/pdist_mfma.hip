@@ -43,7 +43,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define SE_PD_WGS 2
 #endif
 constexpr int PD_BM = 128, PD_BN = 128, PD_BK = SE_PD_BK;   // K-chunk staged per barrier pair: 64 or 32
-constexpr int PD_THREADS = 512;
+#ifndef SE_PD_THREADS
+#define SE_PD_THREADS 512        // 512: 4 x 2 waves of 32 x 64 outputs; 256: 2 x 2 waves of 64 x 64 (smaller workgroups, more of them per CU)
+#endif
+constexpr int PD_THREADS = SE_PD_THREADS;
+constexpr int PD_WAVES = PD_THREADS / 64;
+constexpr int PD_WROWS = PD_BM / (PD_WAVES / 2);              // tile rows per wave (its columns: 64)
+constexpr int PD_MI = PD_WROWS / 32;                          // 32-row MFMA blocks per wave along m
 constexpr int PD_LD = PD_BK + 4;  // padded LDS row pitch in floats
 constexpr int PD_SP = PD_BN + 4;  // row pitch of the epilogue stage
 // rows of the output tile staged at a time: the whole tile when the operand buffers can hold it (BK = 64), else half
@@ -182,11 +188,12 @@ __device__ __forceinline__ void pd_stream_rows(const float *stage, float *gbase,
 {
     const int tid = threadIdx.x;
     const int r0 = tid >> 5, c4 = (tid & 31) * 4;
+    constexpr int RPP = PD_THREADS / 32;                         // rows per pass of the workgroup
     char *gb = (char *)gbase;                                    // uniform base + 32-bit byte offsets
     const uint32_t ldo4 = ldo * 4u;
 #pragma unroll
-    for (int p = 0; p < PD_SR / 16; p++) {
-        const int row = p * 16 + r0;
+    for (int p = 0; p < PD_SR / RPP; p++) {
+        const int row = p * RPP + r0;
         const float4 v = *(const float4 *)&stage[row * PD_SP + c4];
         if (dry) { asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w)); continue; }   // tuning aid: stage traffic without HBM writes
         float *dp = (float *)(gb + ((uint32_t)row * ldo4 + (uint32_t)c4 * 4u));
@@ -214,7 +221,7 @@ __device__ __forceinline__ float pd_finish(float v, float sa, float sb)
 constexpr int PDF_VEC_A = 1, PDF_VEC_B = 2, PDF_VEC_O = 4, PDF_NO_STORE = 8, PDF_NO_MFMA = 16, PDF_STAGGER = 32, PDF_PLAIN_ST = 64, PDF_NO_GSTORE = 128;
 
 template <int METRIC, bool MULTI_KB, bool SYM, bool VEC>
-__global__ __launch_bounds__(PD_THREADS, 2 * PD_WGS_PER_CU) void pdist_kernel(
+__global__ __launch_bounds__(PD_THREADS, (PD_WAVES / 4) * PD_WGS_PER_CU) void pdist_kernel(
     const float *__restrict__ A, uint32_t lda, const float *__restrict__ Bm, uint32_t ldb,
     const float *__restrict__ sqa, const float *__restrict__ sqb, int64_t Q, int64_t N, int64_t D,
     KBlocks kbs, int nchunks, float *__restrict__ out, uint32_t ldo, int tiles_m, int tiles_n, int64_t ntiles, int flags,
@@ -240,18 +247,19 @@ __global__ __launch_bounds__(PD_THREADS, 2 * PD_WGS_PER_CU) void pdist_kernel(
     }
 
     const int lane = lane_id(), wave = threadIdx.x >> 6;
-    const int wm = wave >> 1, wn = wave & 1;      // 4 x 2 waves: 32 rows x 64 cols each
+    const int wm = wave >> 1, wn = wave & 1;      // (PD_WAVES / 2) x 2 waves: PD_WROWS rows x 64 cols each
     const int col = lane & 31, hi = lane >> 5;
     const bool vec_o = flags & PDF_VEC_O;
     const bool nt = !(flags & PDF_PLAIN_ST);   // streaming (nontemporal) stores: the 10 GB result is never re-read by this kernel
 
-    f32x16 acc[2], tot[2];
+    constexpr int NB = 2 * PD_MI;                 // 32 x 32 accumulator blocks per wave: [mi][j] at mi * 2 + j
+    f32x16 acc[NB], tot[NB];
 #pragma unroll
-    for (int j = 0; j < 2; j++)
+    for (int j = 0; j < NB; j++)
 #pragma unroll
         for (int r = 0; r < 16; r++) { acc[j][r] = 0.f; if (MULTI_KB) tot[j][r] = 0.f; }
 
-    const float *pa = sA + (wm * 32 + col) * PD_LD + hi * (PD_BK / 2);
+    const float *pa = sA + (wm * PD_WROWS + col) * PD_LD + hi * (PD_BK / 2);      // block mi: + mi * 32 rows
     const float *pb0 = sB + (wn * 64 + col) * PD_LD + hi * (PD_BK / 2);
     const float *pb1 = pb0 + 32 * PD_LD;
 
@@ -309,29 +317,33 @@ __global__ __launch_bounds__(PD_THREADS, 2 * PD_WGS_PER_CU) void pdist_kernel(
         // ---- MFMA over the chunk in LDS: 2 k per step, 4 steps per 16-byte operand read ----
         const int steps = (flags & PDF_NO_MFMA) ? 0 : ((kc + 1) >> 1);
         const int full = steps & ~3;
-#define PD_STEP(C)                                                                \
-    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.C, b0.C, acc[0], 0, 0, 0);   \
-    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4.C, b1.C, acc[1], 0, 0, 0);
+#define PD_STEP(C)                                                                                \
+    _Pragma("unroll") for (int mi = 0; mi < PD_MI; mi++) {                                        \
+        acc[mi * 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[mi].C, b0.C, acc[mi * 2], 0, 0, 0);         \
+        acc[mi * 2 + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[mi].C, b1.C, acc[mi * 2 + 1], 0, 0, 0); \
+    }
+#define PD_READ(S)                                                                                \
+    float4 a4[PD_MI];                                                                             \
+    _Pragma("unroll") for (int mi = 0; mi < PD_MI; mi++) a4[mi] = *(const float4 *)(pa + mi * 32 * PD_LD + (S)); \
+    const float4 b0 = *(const float4 *)(pb0 + (S));                                               \
+    const float4 b1 = *(const float4 *)(pb1 + (S));
         for (int s = 0; s < full; s += 4) {
-            const float4 a4 = *(const float4 *)(pa + s);
-            const float4 b0 = *(const float4 *)(pb0 + s);
-            const float4 b1 = *(const float4 *)(pb1 + s);
+            PD_READ(s)
             PD_STEP(x) PD_STEP(y) PD_STEP(z) PD_STEP(w)
         }
         if (steps & 3) {
-            const float4 a4 = *(const float4 *)(pa + full);
-            const float4 b0 = *(const float4 *)(pb0 + full);
-            const float4 b1 = *(const float4 *)(pb1 + full);
+            PD_READ(full)
             PD_STEP(x)
             if ((steps & 3) > 1) { PD_STEP(y) }
             if ((steps & 3) > 2) { PD_STEP(z) }
         }
+#undef PD_READ
 #undef PD_STEP
 
         PD_T(4)
         if (MULTI_KB && cur_closes) {
 #pragma unroll
-            for (int j = 0; j < 2; j++)
+            for (int j = 0; j < NB; j++)
 #pragma unroll
                 for (int r = 0; r < 16; r++) {
                     tot[j][r] = first_kb ? acc[j][r] : (tot[j][r] + acc[j][r]);
@@ -344,7 +356,7 @@ __global__ __launch_bounds__(PD_THREADS, 2 * PD_WGS_PER_CU) void pdist_kernel(
         if (c + 1 == nchunks) {
             if (flags & PDF_NO_STORE) {
 #pragma unroll
-                for (int j = 0; j < 2; j++)
+                for (int j = 0; j < NB; j++)
 #pragma unroll
                     for (int r = 0; r < 16; r++) asm volatile("" ::"v"(acc[j][r]));
             } else {
@@ -356,13 +368,13 @@ __global__ __launch_bounds__(PD_THREADS, 2 * PD_WGS_PER_CU) void pdist_kernel(
                 const int rows_here = (int)((Q - cur_m0 < PD_BM) ? (Q - cur_m0) : PD_BM);
                 const int cols_here = (int)((N - cur_n0 < PD_BN) ? (N - cur_n0) : PD_BN);
                 const bool fast = (rows_here == PD_BM) && (cols_here == PD_BN) && vec_o;
-                int lr0 = wm * 32 + 4 * hi;                                       // + (r&3) + 8*(r>>2)
+                int lr0 = wm * PD_WROWS + 4 * hi;                                 // + mi * 32 + (r&3) + 8*(r>>2)
                 asm volatile("" : "+v"(lr0));   // opaque per tile: nothing of the epilogue is hoisted out of the tile loop
                 // (values are finished at the point of use: a [2][16] copy of the tile would cost 32 more VGPRs)
-#define PD_VAL(J, R)                                                                                                         \
-    pd_finish<METRIC>(MULTI_KB ? tot[J][R] : acc[J][R],                                                                        \
-                      METRIC == SE_METRIC_EUCLID ? sa_[((R) & 3) + 4 * ((R) >> 2)] : 0.f, METRIC == SE_METRIC_EUCLID ? sb_[J] : 0.f)
-                float sa_[16], sb_[2];   // Euclidean epilogue only: |a|^2 of this lane's 16 rows, |b|^2 of its 2 columns
+#define PD_VAL(MI_, J, R)                                                                                                    \
+    pd_finish<METRIC>(MULTI_KB ? tot[(MI_) * 2 + (J)][R] : acc[(MI_) * 2 + (J)][R],                                            \
+                      METRIC == SE_METRIC_EUCLID ? sa_[MI_][((R) & 3) + 4 * ((R) >> 2)] : 0.f, METRIC == SE_METRIC_EUCLID ? sb_[J] : 0.f)
+                float sa_[PD_MI][16], sb_[2];   // Euclidean epilogue only: |a|^2 of this lane's 16 rows per block, |b|^2 of its 2 columns
                 if (METRIC == SE_METRIC_EUCLID) {
 #pragma unroll
                     for (int j = 0; j < 2; j++) {
@@ -370,23 +382,27 @@ __global__ __launch_bounds__(PD_THREADS, 2 * PD_WGS_PER_CU) void pdist_kernel(
                         sb_[j] = sqb[cur_n0 + (lc < cols_here ? lc : cols_here - 1)];
                     }
 #pragma unroll
-                    for (int r = 0; r < 16; r++) {
-                        const int lr = lr0 + (r & 3) + 8 * (r >> 2);
-                        sa_[r] = sqa[cur_m0 + (lr < rows_here ? lr : rows_here - 1)];
-                    }
+                    for (int mi = 0; mi < PD_MI; mi++)
+#pragma unroll
+                        for (int r = 0; r < 16; r++) {
+                            const int lr = lr0 + mi * 32 + (r & 3) + 8 * (r >> 2);
+                            sa_[mi][r] = sqa[cur_m0 + (lr < rows_here ? lr : rows_here - 1)];
+                        }
                 }
 #pragma unroll
                 for (int h = 0; h < PD_BM / PD_SR; h++) {
                     __syncthreads();   // operands of the last chunk / the previous stage contents are no longer needed
                     PD_T(6)
                     // tile rows [h SR, (h+1) SR) -> stage[row][col]: per instruction lanes 0-31 fill 32 consecutive floats of one row
-                    if ((wm * 32) / PD_SR == h) {
 #pragma unroll
-                        for (int j = 0; j < 2; j++)
+                    for (int mi = 0; mi < PD_MI; mi++)
+                        if ((wm * PD_WROWS + mi * 32) / PD_SR == h) {
 #pragma unroll
-                            for (int r = 0; r < 16; r++)
-                                smem[(lr0 - h * PD_SR + (r & 3) + 8 * (r >> 2)) * PD_SP + wn * 64 + j * 32 + col] = PD_VAL(j, r);
-                    }
+                            for (int j = 0; j < 2; j++)
+#pragma unroll
+                                for (int r = 0; r < 16; r++)
+                                    smem[(lr0 + mi * 32 - h * PD_SR + (r & 3) + 8 * (r >> 2)) * PD_SP + wn * 64 + j * 32 + col] = PD_VAL(mi, j, r);
+                        }
                     PD_T(7)
                     __syncthreads();
                     PD_T(8)
@@ -403,11 +419,13 @@ __global__ __launch_bounds__(PD_THREADS, 2 * PD_WGS_PER_CU) void pdist_kernel(
                         PD_T(6)
                         if ((wn * 64) / PD_SR == h) {
 #pragma unroll
-                            for (int j = 0; j < 2; j++)
+                            for (int mi = 0; mi < PD_MI; mi++)
 #pragma unroll
-                                for (int g = 0; g < 4; g++)
-                                    *(float4 *)&smem[(wn * 64 - h * PD_SR + j * 32 + col) * PD_SP + lr0 + 8 * g] =
-                                        make_float4(PD_VAL(j, 4 * g), PD_VAL(j, 4 * g + 1), PD_VAL(j, 4 * g + 2), PD_VAL(j, 4 * g + 3));
+                                for (int j = 0; j < 2; j++)
+#pragma unroll
+                                    for (int g = 0; g < 4; g++)
+                                        *(float4 *)&smem[(wn * 64 - h * PD_SR + j * 32 + col) * PD_SP + lr0 + mi * 32 + 8 * g] =
+                                            make_float4(PD_VAL(mi, j, 4 * g), PD_VAL(mi, j, 4 * g + 1), PD_VAL(mi, j, 4 * g + 2), PD_VAL(mi, j, 4 * g + 3));
                         }
                         PD_T(7)
                         __syncthreads();
@@ -421,7 +439,7 @@ __global__ __launch_bounds__(PD_THREADS, 2 * PD_WGS_PER_CU) void pdist_kernel(
 #undef PD_VAL
             }
 #pragma unroll
-            for (int j = 0; j < 2; j++)
+            for (int j = 0; j < NB; j++)
 #pragma unroll
                 for (int r = 0; r < 16; r++) acc[j][r] = 0.f;
             first_kb = true;
