@@ -88,14 +88,18 @@ def _resolve_kblocks(kblocks, d):
     return kblocks if len(kblocks) > 1 else None
 
 
-def ranking_tiles(features, normalize=False, tile_rows=None, idx64=False, queries=None, kblocks=None):
+def ranking_tiles(features, normalize=False, tile_rows=None, idx64=False, queries=None, kblocks=None, whole_if_fits=False):
     """Generator over ``(first_row, rank_tile)`` with ``rank_tile`` an int32 (int64 if ``idx64``)
     DEVICE tensor ``[rows, N]``: the canonical ranking of queries ``first_row .. first_row+rows``.
 
     ``features`` must already be a float32 device tensor ``[N, D]``; it is normalised in place when
     ``normalize`` is set (like the reference mutates its input, evaluate_retrieval.py:58).
     ``queries`` optionally restricts the query rows to ``range(*queries)``; ``kblocks`` (None | 'openblas' | list) makes
-    the FMA chain restart per K block like the host BLAS the reference ran on (see ``host_blas_kblocks``)."""
+    the FMA chain restart per K block like the host BLAS the reference ran on (see ``host_blas_kblocks``).
+    ``whole_if_fits``: rank all queries as ONE tile when distances + ranks (8 N^2 bytes) fit into a third of the free device
+    memory -- all-pairs then takes the symmetric distance kernel (3.4 instead of 5.4 ms at 50k x 50k).  Off by default: a one-shot
+    evaluation pays more for the two fresh 10 GB allocations (0.24 s measured) than the kernels save; callers that reuse their
+    buffers (bench.py) call the kernels directly."""
     import torch
     import sehip
 
@@ -106,9 +110,11 @@ def ranking_tiles(features, normalize=False, tile_rows=None, idx64=False, querie
         metric, sq = sehip.METRIC_COSINE, None
     else:
         metric, sq = sehip.METRIC_EUCLID, sehip.row_sqnorm(features)
+    q0, q1 = (0, n) if queries is None else queries
     if tile_rows is None:
         tile_rows = max(128, min(n, (DEFAULT_TILE_BYTES // (8 * max(n, 1))) // 128 * 128))
-    q0, q1 = (0, n) if queries is None else queries
+        if whole_if_fits and features.is_cuda and 8 * n * (q1 - q0) <= torch.cuda.mem_get_info(features.device)[0] // 3:
+            tile_rows = max(tile_rows, q1 - q0)
     pd = torch.empty((min(tile_rows, max(q1 - q0, 1)), n), dtype=torch.float32, device=features.device)
     for r0 in range(q0, q1, tile_rows):
         rows = min(tile_rows, q1 - r0)
