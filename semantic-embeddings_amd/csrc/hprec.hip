@@ -167,7 +167,7 @@ __global__ __launch_bounds__(HP_THREADS, SE_HP_WAVES_PER_SIMD) void hprec_kernel
     double *s_part = reinterpret_cast<double *>(s_sim + C);        // [2][HP_WAVES][3] wave totals of the scans, double-buffered
     double *s_fin = s_part + 2 * HP_WAVES * 3;                     // [HP_WAVES][3] end-of-query reduction, then [4] trapezoid end points
     double *s_ends = s_fin + HP_WAVES * 3;
-    int *s_ks = reinterpret_cast<int *>(s_ends + 4);     // [nk] the cut-offs, ascending
+    int *s_ks = reinterpret_cast<int *>(s_ends + 4);               // [nk] the cut-offs, ascending
     int *s_perm = s_ks + nk;                                       // [nk] their slots in the output row
     int *s_qpos = s_perm + nk;
     int *s_next = s_qpos + 1;
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(HP_THREADS, SE_HP_WAVES_PER_SIMD) void hprec_kernel
 #pragma unroll 8
         for (int64_t g = tid; g < quads; g += HP_THREADS) {
             const int4 v = c4[g];
-            w[g] = ((unsigned)v.x & 0xFFu) | (((unsigned)v.y & 0xFFu) << 8) | (((unsigned)v.z & 0xFFu) << 16) | ((unsigned)v.w << 24);
+            w[g] = ((unsigned)v.x & 0xFFu) | (((unsigned)v.y & 0xFFu) << 8) | (((unsigned)v.z & 0xFFu) << 16) | (((unsigned)v.w & 0xFFu) << 24);
         }
         for (int64_t i = quads * 4 + (int64_t)tid * 4; i < gallery; i += HP_THREADS * 4) {
             unsigned v = 0;
