@@ -220,6 +220,11 @@ __global__ __launch_bounds__(HP_THREADS, SE_HP_WAVES_PER_SIMD) void hprec_kernel
     }
     __syncthreads();
     const int kmax = nk > 0 ? s_ks[nk - 1] : 0;                    // cut-offs live at original positions <= kmax
+    // the cut-offs the CLI asks for are 1, 2, ..., K in that order (evaluate_retrieval.py: range(1, plot_max + 1)): rank j then IS
+    // slot j -- no look-up at all.  One vote per workgroup.
+    bool iota = true;
+    for (int s = tid; s < nk; s += HP_THREADS) iota = iota && (s_ks[s] == s + 1) && (s_perm[s] == s);
+    const bool ks_iota = __syncthreads_and(iota ? 1 : 0) != 0;
     HP_T(0)
 
     // ---- which queries this workgroup takes: class order, one segment of it per XCD (blockIdx round-robins the XCDs), stealing
@@ -373,7 +378,7 @@ __global__ __launch_bounds__(HP_THREADS, SE_HP_WAVES_PER_SIMD) void hprec_kernel
                 if (FAST) HP_T(5)
                 // ---- walk the 16 positions: cumulative sums, cum / best, trapezoid terms, the cut-offs ----
                 int kat = 0, knext = 0x7FFFFFFF;
-                if (MODE == 0 && cuts) {        // lower bound of this thread's first effective rank + 1 among the sorted cut-offs
+                if (MODE == 0 && cuts && !ks_iota) {   // lower bound of this thread's first effective rank + 1 among the sorted cut-offs
                     const int k0 = (i0 <= qpos) ? i0 + 1 : i0;
                     int hi = nk;
                     while (kat < hi) {
@@ -400,7 +405,9 @@ __global__ __launch_bounds__(HP_THREADS, SE_HP_WAVES_PER_SIMD) void hprec_kernel
                             if (j == 0) { s_ends[0] = yw; s_ends[1] = yl; }
                             if (ahp_len > 0 && j == alen - 1) { s_ends[2] = yw; s_ends[3] = yl; }   // whole list: taken in the finish step
                         }
-                        if (cuts && j < kmax) {   // hierarchical precision at k = j + 1, if that is a cut-off: the thread's ranks are
+                        if (cuts && ks_iota) {
+                            if (j < nk) { orow[j] = yw; orow[nk + j] = yl; }
+                        } else if (cuts && j < kmax) {   // hierarchical precision at k = j + 1, if that is a cut-off: the thread's ranks are
                             while (knext < j + 1) knext = (++kat < nk) ? s_ks[kat] : 0x7FFFFFFF;   // consecutive, so it merges them with
                             while (knext == j + 1) {                                            // the sorted cut-offs from its lower bound
                                 orow[s_perm[kat]] = yw; orow[nk + s_perm[kat]] = yl;

@@ -160,6 +160,35 @@ def test_se_hierarchical_precision_general_rankings(n, q, class_order, with_qidx
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("nk", [1, 250, 300, 512])
+def test_se_hierarchical_precision_consecutive_cutoffs(nk):
+    """ks = 1, 2, ..., K in order (what evaluate_retrieval.main asks for with --plot_max K): the kernel's slot == rank short cut, across a
+    workgroup's ranking threads (K > 256), with the query at rank 0, in the middle of the cut-offs and absent."""
+    import sehip
+    from test_dp_gloo import _hprec_standin
+    rng = np.random.default_rng(nk)
+    n, q, C = 1500, 24, 31
+    cls = rng.integers(0, C, size=n).astype(np.int32)
+    tab = rng.random((C, C)) * 0.8 + 0.1; tab = (tab + tab.T) / 2; np.fill_diagonal(tab, 1.0)
+    counts = np.bincount(cls, minlength=C)
+    best = np.stack([np.cumsum(np.repeat(tab[c][np.argsort(-tab[c], kind="stable")], counts[np.argsort(-tab[c], kind="stable")])) for c in range(C)])
+    rk = np.stack([rng.permutation(n) for _ in range(q)]).astype(np.int32)
+    for r in range(q):          # query r at rank 0 (r even) or at rank 7 r (r odd); query 5 is not in its list at all
+        want_pos = 0 if r % 2 == 0 else min(7 * r, n - 1)
+        at = np.flatnonzero(rk[r] == r)[0]
+        rk[r, at], rk[r, want_pos] = rk[r, want_pos], r
+    qidx = np.arange(q, dtype=np.int32)
+    qidx[5] = -1
+    ks = np.arange(1, nk + 1, dtype=np.int32)
+    args = [torch.from_numpy(a) for a in (rk, cls, cls[:q].copy(), qidx, tab, tab.T.copy(), best, best, ks)]
+    dev = [a.cuda() for a in args]
+    for ahp, ap in ((0, True), (100, False)):
+        want = _hprec_standin(*args, ahp_len=ahp, want_ap=ap).numpy()
+        got = sehip.hierarchical_precision(*dev, ahp_len=ahp, want_ap=ap).cpu().numpy()
+        assert np.abs(got - want).max() <= 1e-10, (ahp, ap, np.abs(got - want).max())
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name", ["cub", "ilsvrc"])
 def test_hierarchical_precision_device_other_taxonomies(name, tmp_path):
     """Device metrics on CUB (200 classes: byte class table) and the ILSVRC min-tree (1000 string-id classes: 16-bit class table when
