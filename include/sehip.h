@@ -241,7 +241,7 @@ int se_retrieve_topk(const float *queries, int64_t ldq, const float *gallery, in
  *             for (>= this call's list_len)
  *   ks        [nk] int32 cut-offs; ahp_len: -1 no AHP, 0 whole list, K > 0 clipped AHP@K; want_ap: 0 / 1
  *   out       [q, 2 nk + 3] f64: P@k WUP x nk, P@k LCS x nk, AHP WUP, AHP LCS, AP (ldo elements between rows)
- *   order_ws  NULL, or se_hprec_order_workspace_bytes(q) bytes of device scratch: the queries are then visited in
+ *   order_ws  NULL, or se_hprec_order_workspace_bytes(q) bytes of 16-byte aligned device scratch: the queries are then visited in
  *             class order (one contiguous part of it per XCD), which keeps the best curve being streamed in L2.
  *             The results do not depend on it.
  */

@@ -56,7 +56,7 @@ constexpr int HP_ITEMS = SE_HP_ITEMS;
 constexpr int HP_PF = SE_HP_PF;
 constexpr int HP_CHUNK = HP_THREADS * HP_ITEMS;
 constexpr int HP_MAX_KS = 512;
-constexpr int HP_WS_HEAD = 16;      // order_ws: [0, 8) per-XCD cursors, [16, 16 + q) the queries in class order
+constexpr int HP_WS_HEAD = 16;      // order_ws (ints): [0, 8) per-XCD cursors, then one int4 per query in class order: (query, its class, its own gallery index or -1, 0)
 constexpr int HP_ORDER_THREADS = 1024;
 
 // ---- DPP wave scans (no LDS traffic): Kogge-Stone inside the 16-lane rows, then the row totals by row_bcast ----
@@ -126,7 +126,8 @@ __global__ __launch_bounds__(HP_THREADS) void hprec_rcp_kernel(const double *__r
 }
 
 // Counting sort of the queries by class (any order inside a class) + the per-XCD cursors of hprec_kernel.
-__global__ __launch_bounds__(HP_ORDER_THREADS) void hprec_order_kernel(const int32_t *__restrict__ qcls, int64_t Q, int C, int32_t *__restrict__ ws)
+__global__ __launch_bounds__(HP_ORDER_THREADS) void hprec_order_kernel(const int32_t *__restrict__ qcls, const int32_t *__restrict__ qidx, int64_t Q, int C,
+                                                                       int32_t *__restrict__ ws)
 {
     extern __shared__ int hp_hist[];            // [C] class counts -> cursors, then [16] wave totals
     int *s_wt = hp_hist + C;
@@ -146,7 +147,11 @@ __global__ __launch_bounds__(HP_ORDER_THREADS) void hprec_order_kernel(const int
     for (int w = 0; w < wave; w++) run += s_wt[w];
     for (int c = lo; c < hi; c++) { const int t = hp_hist[c]; hp_hist[c] = run; run += t; }
     __syncthreads();
-    for (int64_t i = tid; i < Q; i += HP_ORDER_THREADS) ws[HP_WS_HEAD + atomicAdd(&hp_hist[qcls[i]], 1)] = (int32_t)i;
+    int4 *ent = reinterpret_cast<int4 *>(ws + HP_WS_HEAD);      // everything a workgroup needs to start a query, in one 16-byte load
+    for (int64_t i = tid; i < Q; i += HP_ORDER_THREADS) {
+        const int c = qcls[i];
+        ent[atomicAdd(&hp_hist[c], 1)] = make_int4((int)i, c, qidx ? qidx[i] : -1, 0);
+    }
 }
 
 // out row layout: [P@k WUP x nk][P@k LCS x nk][AHP WUP][AHP LCS][AP]
@@ -246,7 +251,11 @@ __global__ __launch_bounds__(HP_THREADS, SE_HP_WAVES_PER_SIMD) void hprec_kernel
                 for (;;) {
                     const int xs = (xcd + seg) & 7;
                     const int64_t lo = xs * seg_len, hi = (lo + seg_len < Q) ? lo + seg_len : Q;
-                    if (lo + ticket < hi) { got = order_ws[HP_WS_HEAD + lo + ticket]; break; }
+                    if (lo + ticket < hi) {
+                        const int4 e = reinterpret_cast<const int4 *>(order_ws + HP_WS_HEAD)[lo + ticket];
+                        got = e.x; s_next[1] = e.y; s_next[2] = e.z;
+                        break;
+                    }
                     if (++seg == 8) break;
                     ticket = atomicAdd(&order_ws[(xcd + seg) & 7], 1);
                 }
@@ -262,8 +271,8 @@ __global__ __launch_bounds__(HP_THREADS, SE_HP_WAVES_PER_SIMD) void hprec_kernel
             q_static += gridDim.x;
         }
         const int32_t *rrow = rank + q * ldr;
-        const int qc = qcls[q];
-        const int32_t self = qidx ? qidx[q] : -1;
+        const int qc = order_ws ? s_next[1] : qcls[q];
+        const int32_t self = order_ws ? s_next[2] : (qidx ? qidx[q] : -1);
         const double2 *rc = rcp + (int64_t)qc * ldc;
         double *orow = out + q * ldo;
         // The ranks a thread owns in a chunk are requested HP_PF chunks ahead (HP_PF register sets, refilled right after the barrier of
@@ -311,13 +320,20 @@ __global__ __launch_bounds__(HP_THREADS, SE_HP_WAVES_PER_SIMD) void hprec_kernel
         if (want_ap) need = eff_len;
         const int last_pos = (need < Li) ? need + 1 : Li;                       // original positions [0, last_pos) cover `need` effective ranks
 
+        const int64_t half = ldc / 2;
+        // whole-list AHP: its last end point is (all similarities) / best at the last rank that is not the query -- the divisor is
+        // requested here, by the thread that will need it in the finish step
+        double2 t_last = make_double2(0.0, 0.0);
+        if (tid == 0 && ahp_len == 0 && eff_len > 0) {
+            const int i_last = (eff_len - 1 < qpos) ? eff_len - 1 : eff_len;
+            t_last = rc[hp_slot(i_last) + (i_last < qpos ? half : 0)];
+        }
         HP_T(1)
         double car_w = 0.0, car_l = 0.0;      // running similarity sums up to the current chunk (the same value in every thread)
         int car_r = 0;                        // relevant items so far
         double acc_w = 0.0, acc_l = 0.0, acc_ap = 0.0;                          // this thread's share of sum(cum / best) and of the AP terms
         int par = 0;
         const double2 *rct = rc;            // uniform: the chunk's table rows, indexed e * HP_THREADS + tid
-        const int64_t half = ldc / 2;
         int base = 0;
         // 1 / (best - 1) of a thread's positions in a chunk: contiguous across the wave for every e (1 / best for the ranks ahead of
         // the query: the second half of the class row)
@@ -447,11 +463,7 @@ __global__ __launch_bounds__(HP_THREADS, SE_HP_WAVES_PER_SIMD) void hprec_kernel
             if (tid == 0) {
                 double g0 = 0.0, g1 = 0.0, g2 = 0.0;
                 for (int w = 0; w < HP_WAVES; w++) { g0 += s_fin[w * 3 + 0]; g1 += s_fin[w * 3 + 1]; g2 += s_fin[w * 3 + 2]; }
-                if (ahp_len == 0 && eff_len > 0) {   // whole list: y[-1] = all similarities / best at the last rank that is not the query
-                    const int i_last = (eff_len - 1 < qpos) ? eff_len - 1 : eff_len;
-                    const double2 tl = rc[hp_slot(i_last) + (i_last < qpos ? half : 0)];
-                    s_ends[2] = car_w * tl.x; s_ends[3] = car_l * tl.y;
-                }
+                if (ahp_len == 0 && eff_len > 0) { s_ends[2] = car_w * t_last.x; s_ends[3] = car_l * t_last.y; }   // whole list: y[-1]
                 if (ahp_len >= 0) {
                     // np.trapz(y, dx) = dx * (sum(y) - (y[0] + y[-1]) / 2), dx = 1 / len(wup) (whole list) or 1 / clip
                     const double dx = 1.0 / (double)((ahp_len > 0) ? ahp_len : eff_len);
@@ -492,7 +504,7 @@ extern "C" int se_hprec_reciprocal_curves(const double *best_wup, const double *
     return SE_OK;
 }
 
-extern "C" int64_t se_hprec_order_workspace_bytes(int64_t q) { return q < 0 ? 0 : (int64_t)sizeof(int32_t) * (HP_WS_HEAD + q); }
+extern "C" int64_t se_hprec_order_workspace_bytes(int64_t q) { return q < 0 ? 0 : (int64_t)sizeof(int32_t) * (HP_WS_HEAD + 4 * q); }
 
 namespace se {
 
@@ -541,7 +553,8 @@ extern "C" int se_hierarchical_precision(const int32_t *rank, int64_t ldr, int64
     const size_t order_lds = (size_t)(num_classes + HP_ORDER_THREADS / WAVE) * sizeof(int);
     if (ws) {
         SE_HIP_CHECK(hipFuncSetAttribute((const void *)hprec_order_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)order_lds));
-        hipLaunchKernelGGL(hprec_order_kernel, dim3(1), dim3(HP_ORDER_THREADS), order_lds, s, qcls, q, num_classes, ws);
+        if (reinterpret_cast<uintptr_t>(ws) % 16 != 0) return fail(SE_ERR_INVALID, "se_hierarchical_precision: order_ws must be 16-byte aligned");
+        hipLaunchKernelGGL(hprec_order_kernel, dim3(1), dim3(HP_ORDER_THREADS), order_lds, s, qcls, qidx, q, num_classes, ws);
         SE_LAUNCH_CHECK();
     }
     // persistent workgroups (the class table is loaded once each): as many as are resident at once
