@@ -390,6 +390,16 @@ typedef long long rr_i64x2 __attribute__((ext_vector_type(2)));
 constexpr int RR_GH = SE_RR_GH;    // returning adds in flight per lane
 constexpr int RR_HW_BITS = 11;   // digit width of the hardware-ordered variant: 3 passes (11 + 11 + 10 bits; rows of >= 32,768 columns: 10 + 10 + 12) instead of 4
 constexpr int RR_WIDE_WORDS = 2048;   // counter words per wave of the 12-bit pass (4096 packed 16-bit counters)
+#ifndef SE_RR_TWO
+#define SE_RR_TWO 1                   // build parameter: 0 = never take the two-pass path below
+#endif
+// Two-pass path of the long-row kernel: when all keys of a row but at most RR_TWO_OUT lie within RR_TWO_SPAN codes below its largest
+// key (cosine / Euclidean rows of one data set do: the outliers are the query's own distance and its near-duplicates), the row is
+// sorted on (key - lo + 1) << 8 -- 24 significant bits -- in TWO passes of 12 bits, and the few keys below the window, which that
+// mapping sends to 0 (first places, index order), are put into their true order afterwards by one wave.  7 instead of 12 random LDS
+// operations per key.  Rows that do not qualify take the three passes.
+constexpr uint32_t RR_TWO_SPAN = (1u << 24) - 3u;
+constexpr int RR_TWO_OUT = 64;
 // Counters are 16 bits wide, two per LDS word (8 waves x 2048 digits x 2 B = 32 KB next to the 100 KB exchange
 // buffer): a wave holds at most 64 x 104 keys and a destination is < 53,248, so neither half can carry into the
 // other.  The returning add is done on the word with the increment shifted into the digit's half.
@@ -475,13 +485,14 @@ struct RRRankHW {
     }
 };
 
-template <int ITEMS, bool PROF, bool HWORD, bool PEEL>
+template <int ITEMS, bool PROF, bool HWORD, int VAR>   // VAR: 0 plain, 1 group-peeling rank phase of the last pass, 2 two-pass path for rows that qualify
 __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_kernel(const float *__restrict__ pdist, int64_t ldp, int64_t Q,
                                                                     int N, void *rank, int64_t ldr, int idx64, int vec_ok,
                                                                     unsigned long long *prof, const uint32_t *skew_flag)
 {
-    // two launches per call when the detector is used: the variant that does not match the flag leaves at once
-    if (skew_flag && ((*skew_flag != 0) != PEEL)) return;
+    // one launch per variant when the detector is used: the variants that do not match its flag leave at once
+    if (skew_flag && *skew_flag != (uint32_t)VAR) return;
+    constexpr bool PEEL = VAR == 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char rr_raw[];
     constexpr int BITS = HWORD ? RR_HW_BITS : 8;                        // digit width (narrow passes)
     constexpr int NB = 1 << BITS;
@@ -530,7 +541,7 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
         }                                                                                                             \
     }
 #define RR_PREFETCH_NEXT_ROW() \
-    if (p == NPASS - 1 && more) { \
+    if (end >= 32 && more) { \
                 const char *nrow = (const char *)(pdist + (row + gridDim.x) * ldp); \
                 const uint32_t row_bytes = (uint32_t)N * 4u; \
                 for (uint32_t off = (uint32_t)tid * 128u; off < row_bytes; off += RR_THREADS * 128u) \
@@ -548,6 +559,50 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
     [[maybe_unused]] int rr_pass = -1;   // profile build: pass index for the per-pass phase times
     for (int64_t row = blockIdx.x; row < Q; row += gridDim.x) {
         const bool more = row + gridDim.x < Q;
+        // ---- does the row qualify for the two-pass path?  (uniform per row; before the index registers exist: only the keys are live) ----
+        bool two = false;
+        [[maybe_unused]] int n_out = 0;
+        if constexpr (WIDE && VAR == 2) {
+            uint32_t *stat = wave_tot;                                  // [0, 8): per-wave maxima, [8, 16): per-wave counts below the window
+            uint2 *outl = reinterpret_cast<uint2 *>(wcnt);              // (key, position) of the keys below the window (the dedicated counters are idle on this path)
+            uint32_t mx = 0;
+#pragma unroll
+            for (int s = 0; s < ITEMS; s++) { const uint32_t k = key[s]; mx = max(mx, k == 0xFFFFFFFFu ? 0u : k); }   // NaN / padding sort last anyway
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, off, 64));
+            if (lane == 0) stat[wave] = mx;
+            __syncthreads();
+#pragma unroll
+            for (int w = 0; w < RR_WAVES; w++) mx = max(mx, stat[w]);
+            const uint32_t lo = mx > RR_TWO_SPAN ? mx - RR_TWO_SPAN : 0u;
+            uint32_t below = 0;
+#pragma unroll
+            for (int s = 0; s < ITEMS; s++) below += key[s] < lo ? 1u : 0u;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) below += (uint32_t)__shfl_xor((int)below, off, 64);
+            if (lane == 0) stat[RR_WAVES + wave] = below;
+            if (tid == 0) stat[2 * RR_WAVES] = 0;                        // cursor of the list
+            __syncthreads();
+            below = 0;
+#pragma unroll
+            for (int w = 0; w < RR_WAVES; w++) below += stat[RR_WAVES + w];
+            two = below <= (uint32_t)RR_TWO_OUT;
+            n_out = (int)below;
+            {   // branch-free on purpose: a conditional re-definition of the ITEMS key registers makes hipcc copy them through scratch
+                int wpos = wpos0;
+                opaque(wpos);
+                const uint32_t lo_push = two ? lo : 0u;                  // (no key is below 0: nothing is pushed on the three-pass path)
+#pragma unroll
+                for (int s = 0; s < ITEMS; s++) {
+                    const uint32_t k = key[s];
+                    if (k < lo_push) outl[atomicAdd(&stat[2 * RR_WAVES], 1u)] = make_uint2(k, (uint32_t)(wpos + s * WAVE));
+                    const uint32_t t = (k == 0xFFFFFFFFu) ? 0xFFFFFF00u : (k < lo ? 0u : (k - lo + 1u) << 8);
+                    key[s] = two ? t : k;
+                }
+            }
+            // (the first barrier of pass 0 orders these LDS accesses before anything that follows)
+        }
+        __builtin_amdgcn_sched_barrier(0);
         {
             int wpos = wpos0;
             opaque(wpos);
@@ -556,10 +611,11 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
         }
 #pragma unroll 1
         for (int p = 0; p < NPASS; p++) {
-            const int shift = WIDE ? p * 10 : p * BITS;
+            const int shift = two ? 8 + 12 * p : (WIDE ? p * 10 : p * BITS);
             rr_pass = p;
-            const int end = WIDE ? (p == 2 ? 32 : shift + 10) : ((shift + BITS < 32) ? shift + BITS : 32);   // bits [0, end) are sorted after this pass
-            const bool wide = WIDE && p == 2;                               // 12-bit digit, counters aliased onto the exchange buffer
+            const int end = two ? (p == 1 ? 32 : 20)                        // bits [0, end) are sorted after this pass
+                                : (WIDE ? (p == 2 ? 32 : shift + 10) : ((shift + BITS < 32) ? shift + BITS : 32));
+            const bool wide = WIDE && (two || p == 2);                      // 12-bit digit, counters aliased onto the exchange buffer
             // ---- R: stable rank inside the wave ----
             // counters of this pass: the wave's slice of the dedicated region, or (wide pass) of the idle exchange buffer
             uint32_t *pcnt = wcnt;              // [RR_WAVES][pcw]
@@ -581,7 +637,7 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
             [[maybe_unused]] const uint32_t wlo = wide ? 11u : 10u, whi = (uint32_t)(end - shift) - wlo, hshift = (uint32_t)(shift + (int)wlo) & 31u;
             if constexpr (HWORD) {
                 uint32_t hr[RR_GH], hs[RR_GH], hg[RR_GH];
-                RRRankHW<ITEMS, PEEL>::run(ir, key, hr, hs, hg, (uint32_t)shift, hshift, wlo, whi, cb, lane, p == NPASS - 1);
+                RRRankHW<ITEMS, PEEL>::run(ir, key, hr, hs, hg, (uint32_t)shift, hshift, wlo, whi, cb, lane, end >= 32 && !two);
             }
             else RRRank<ITEMS>::run(ir, key, shift, lane, cb);
             lds_wait();
@@ -726,6 +782,21 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
         }
 #undef RR_DST
         rr_pass = -1;
+        if constexpr (WIDE && VAR == 2) {
+            if (two && n_out > 1) {   // the keys below the window hold the first n_out places in index order: order them by (key, index)
+                const uint2 *outl = reinterpret_cast<const uint2 *>(wcnt);
+                if (tid < n_out) {
+                    const uint2 me = outl[tid];
+                    int r = 0;
+                    for (int j = 0; j < n_out; j++) {
+                        const uint2 o = outl[j];
+                        r += (o.x < me.x || (o.x == me.x && o.y < me.y)) ? 1 : 0;
+                    }
+                    xbuf[r] = (uint16_t)me.y;
+                }
+                __syncthreads();
+            }
+        }
         // ---- the exchange buffer now holds the ranking: canonicalise the next row's keys (waits for its loads), then stream the ranks out ----
         // (the loads sit after the pass loop, not inside its last iteration: a re-definition of the key registers on the `break` path makes
         // hipcc copy all ITEMS index registers there, and a separate straight-line instance of the last pass -- measured, DESIGN.md 5.2 --
@@ -824,37 +895,54 @@ static bool rank_use_tiled(int64_t n)
 // digit over 3 rows x 1024 evenly spaced columns; flag = 1 when one value holds >= 30 % of them.  The two kernel variants launched
 // behind it read the flag and the one it does not select returns immediately -- no host round trip.
 __global__ __launch_bounds__(256) void rank_skew_detect_kernel(const float *__restrict__ pdist, int64_t ldp, int64_t Q, int N,
-                                                               int shift, uint32_t *__restrict__ flag)
+                                                               int shift, int two_ok, uint32_t *__restrict__ flag)
 {
     constexpr int NBIN = 4096;   // values of the most significant digit: 1024 (10 bits, shift 22) or 4096 (12 bits, shift 20)
     __shared__ uint32_t hist[NBIN];
-    __shared__ uint32_t best;
+    __shared__ uint32_t best, row_max[3], row_below[3];
     for (int i = threadIdx.x; i < NBIN; i += 256) hist[i] = 0;
     if (threadIdx.x == 0) best = 0;
+    if (threadIdx.x < 3) { row_max[threadIdx.x] = 0; row_below[threadIdx.x] = 0; }
     __syncthreads();
     const int cols = N < 1024 ? N : 1024;
     for (int r = 0; r < 3; r++) {
         const int64_t row = (r == 0) ? 0 : (r == 1 ? Q / 2 : Q - 1);
         const float *drow = pdist + row * ldp;
-        for (int i = threadIdx.x; i < cols; i += 256) atomicAdd(&hist[canon_key(drow[(int64_t)i * N / cols]) >> shift], 1u);
+        for (int i = threadIdx.x; i < cols; i += 256) {
+            const uint32_t k = canon_key(drow[(int64_t)i * N / cols]);
+            atomicAdd(&hist[k >> shift], 1u);
+            if (k != 0xFFFFFFFFu) atomicMax(&row_max[r], k);
+        }
     }
     __syncthreads();
+    // two-pass candidates: (nearly) every sampled key of every sampled row within RR_TWO_SPAN codes of the row's largest one --
+    // one sampled key below the window stands for ~N / 1024 in the row; each row checks itself again inside the kernel
+    for (int r = 0; r < 3; r++) {
+        const int64_t row = (r == 0) ? 0 : (r == 1 ? Q / 2 : Q - 1);
+        const float *drow = pdist + row * ldp;
+        const uint32_t lo = row_max[r] > RR_TWO_SPAN ? row_max[r] - RR_TWO_SPAN : 0u;
+        for (int i = threadIdx.x; i < cols; i += 256)
+            if (canon_key(drow[(int64_t)i * N / cols]) < lo) atomicAdd(&row_below[r], 1u);
+    }
     uint32_t mine = 0;
     for (int i = threadIdx.x; i < NBIN; i += 256) mine = hist[i] > mine ? hist[i] : mine;
     atomicMax(&best, mine);
     __syncthreads();
     // peeling pays from roughly a 30 % share of one digit (two-valued Euclidean rows: ~50 %; mixed-sign cosine rows: ~10 %)
-    if (threadIdx.x == 0) *flag = (10u * best >= 3u * 3u * (uint32_t)cols) ? 1u : 0u;
+    if (threadIdx.x == 0) {
+        const bool two = two_ok && row_below[0] <= 1 && row_below[1] <= 1 && row_below[2] <= 1;
+        *flag = two ? 2u : ((10u * best >= 3u * 3u * (uint32_t)cols) ? 1u : 0u);
+    }
 }
 
-template <int ITEMS, bool HW, bool PEEL>
+template <int ITEMS, bool HW, int VAR>
 static int launch_rank_reg_variant(const float *pdist, int64_t ldp, int64_t q, int n, void *rank, int idx64, int64_t ldr,
                                    const uint32_t *skew_flag, hipStream_t s)
 {
     const size_t cnt_words = HW ? (size_t)(1 << RR_HW_BITS) / 2 : (size_t)RK_NB;   // per wave (packed 16-bit vs 32-bit counters)
     const size_t lds = (RR_WAVES * cnt_words + 32) * sizeof(uint32_t) + (size_t)RR_THREADS * ITEMS * sizeof(uint16_t);
     static const bool profile = tuning_env("SE_RR_PROFILE") != nullptr;   // -DSE_TUNING build only: allocates, synchronises, prints
-    auto kern = (kTuning && profile) ? rank_rows_reg_kernel<ITEMS, kTuning && (ITEMS == 98), HW, PEEL> : rank_rows_reg_kernel<ITEMS, false, HW, PEEL>;
+    auto kern = (kTuning && profile) ? rank_rows_reg_kernel<ITEMS, kTuning && (ITEMS == 98), HW, VAR> : rank_rows_reg_kernel<ITEMS, false, HW, VAR>;
     // per instantiation, computed once (thread-safe static initialisation): resident workgroups = CUs x occupancy
     struct Resident { hipError_t err; int64_t grid; };
     static const Resident res = [&]() -> Resident {
@@ -888,7 +976,7 @@ static int launch_rank_reg_variant(const float *pdist, int64_t ldp, int64_t q, i
         double tot = 0;
         for (int i = 0; i < 8; i++) tot += (double)h[i];
         if (tot > 0) {
-            fprintf(stderr, "[se_rank_rows profile] ITEMS=%d hw=%d peel=%d grid=%lld:", ITEMS, (int)HW, (int)PEEL, (long long)grid);
+            fprintf(stderr, "[se_rank_rows profile] ITEMS=%d hw=%d peel=%d grid=%lld:", ITEMS, (int)HW, VAR, (long long)grid);
             for (int i = 0; i < 8; i++) fprintf(stderr, " %s %.1f%%", names[i], 100.0 * (double)h[i] / tot);
             fprintf(stderr, "  (%.0f cycles per row)\n[se_rank_rows profile] cycles per row by phase and pass:", tot / (double)q);
             for (int i = 1; i < 7; i++) fprintf(stderr, " %s %.0f/%.0f/%.0f", names[i], (double)h[12 + 3 * i] / (double)q, (double)h[13 + 3 * i] / (double)q, (double)h[14 + 3 * i] / (double)q);
@@ -904,20 +992,26 @@ template <int ITEMS>
 static int launch_rank_reg(const float *pdist, int64_t ldp, int64_t q, int n, void *rank, int idx64, int64_t ldr, bool hw, void *scratch,
                            hipStream_t s)
 {
-    if (!hw) return launch_rank_reg_variant<ITEMS, false, false>(pdist, ldp, q, n, rank, idx64, ldr, nullptr, s);
-    static const char *force = tuning_env("SE_RANK_PEEL");   // -DSE_TUNING build only: "0" / "1" pins the variant
+    if (!hw) return launch_rank_reg_variant<ITEMS, false, 0>(pdist, ldp, q, n, rank, idx64, ldr, nullptr, s);
+    // long rows (12-bit last digit, counters aliased onto the exchange buffer: WIDE in the kernel) also have the two-pass variant
+    constexpr bool wide = (size_t)RR_THREADS * ITEMS * sizeof(uint16_t) >= (size_t)RR_WAVES * RR_WIDE_WORDS * sizeof(uint32_t);
+    constexpr bool two_ok = wide && SE_RR_TWO;
+    static const char *force = tuning_env("SE_RANK_PEEL");   // -DSE_TUNING build only: "0" / "1" / "2" pins the variant
     if (force || !scratch) {
-        if (force && force[0] == '1') return launch_rank_reg_variant<ITEMS, true, true>(pdist, ldp, q, n, rank, idx64, ldr, nullptr, s);
-        return launch_rank_reg_variant<ITEMS, true, false>(pdist, ldp, q, n, rank, idx64, ldr, nullptr, s);
+        if (force && force[0] == '1') return launch_rank_reg_variant<ITEMS, true, 1>(pdist, ldp, q, n, rank, idx64, ldr, nullptr, s);
+        if (force && force[0] == '2' && two_ok) return launch_rank_reg_variant<ITEMS, true, two_ok ? 2 : 0>(pdist, ldp, q, n, rank, idx64, ldr, nullptr, s);
+        return launch_rank_reg_variant<ITEMS, true, 0>(pdist, ldp, q, n, rank, idx64, ldr, nullptr, s);
     }
     uint32_t *flag = (uint32_t *)scratch + 16;   // (words 0-1 belong to the capability probe)
-    // first bit of the most significant digit: 20 for the instantiations whose last pass is 12 bits wide (see WIDE in the kernel), else 22
-    const int top_shift = ((size_t)RR_THREADS * ITEMS * sizeof(uint16_t) >= (size_t)RR_WAVES * RR_WIDE_WORDS * sizeof(uint32_t)) ? 20 : 2 * RR_HW_BITS;
-    hipLaunchKernelGGL(rank_skew_detect_kernel, dim3(1), dim3(256), 0, s, pdist, ldp, q, n, top_shift, flag);
+    // first bit of the most significant digit: 20 for the instantiations whose last pass is 12 bits wide, else 22
+    const int top_shift = wide ? 20 : 2 * RR_HW_BITS;
+    hipLaunchKernelGGL(rank_skew_detect_kernel, dim3(1), dim3(256), 0, s, pdist, ldp, q, n, top_shift, two_ok ? 1 : 0, flag);
     SE_LAUNCH_CHECK();
-    int rc = launch_rank_reg_variant<ITEMS, true, false>(pdist, ldp, q, n, rank, idx64, ldr, flag, s);
+    int rc = launch_rank_reg_variant<ITEMS, true, 0>(pdist, ldp, q, n, rank, idx64, ldr, flag, s);
     if (rc != SE_OK) return rc;
-    return launch_rank_reg_variant<ITEMS, true, true>(pdist, ldp, q, n, rank, idx64, ldr, flag, s);
+    rc = launch_rank_reg_variant<ITEMS, true, 1>(pdist, ldp, q, n, rank, idx64, ldr, flag, s);
+    if (rc != SE_OK || !two_ok) return rc;
+    return launch_rank_reg_variant<ITEMS, true, two_ok ? 2 : 0>(pdist, ldp, q, n, rank, idx64, ldr, flag, s);
 }
 
 // ---- capability probe for the hardware-ordered ranking --------------------------------------------------

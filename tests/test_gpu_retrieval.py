@@ -159,6 +159,38 @@ def test_rank_rows_skewed_top_digit_rows(sehip, n):
     assert np.array_equal(got2, ro.canon_rank_rows(pd2))
 
 
+@pytest.mark.parametrize("n", [32768, 40961, 50000, 53248])
+def test_rank_rows_two_pass_path(sehip, n):
+    """Long rows whose keys (all but a few) lie within 2^24 codes of the row maximum -- Euclidean-distance rows: the query's own
+    distance is the outlier -- take the two-pass path of the register-resident kernel (detector flag 2); every row re-checks itself:
+    up to 64 keys below the window are ordered by one wave afterwards (here: none, 1, exactly 64, with ties / zeros / negatives among
+    them, and at columns the detector does not sample), 65 send the row back to the three passes, as do NaN-free rows that are too
+    wide.  Also exact ties inside the window, keys exactly on the window's lower edge, +inf (window anchored at inf: everything else
+    is 'below'), NaN and padding-like all-ones."""
+    rng = np.random.default_rng(n)
+    q = 11
+    pd = (200.0 + 25.0 * rng.standard_normal((q, n))).astype(np.float32).clip(120.0, 300.0)
+    free = np.setdiff1d(np.arange(n), (np.arange(1024) * n) // 1024)         # columns the detector's 1024-column sample skips
+    pd[0, 0] = 0.0                                                           # the query's own distance (sampled: one below per row is allowed)
+    pd[1, free[:64]] = rng.choice(np.array([0.0, -0.0, 1e-3, -1e-3, 2.5, 2.5, -7.0], dtype=np.float32), size=64)   # 64 below, with ties
+    pd[2, free[:65]] = np.linspace(-1.0, 1.0, 65, dtype=np.float32)          # 65 below: three passes for this row
+    pd[3] = np.round(pd[3])                                                  # ~180 distinct values: long tie runs inside the window
+    pd[4] = 210.0                                                            # one value
+    m = np.float32(pd[5].max())
+    edge = (m.view(np.uint32) - np.uint32((1 << 24) - 3)).view(np.float32)   # the smallest key still inside the window of row 5
+    pd[5, free[:6]] = np.array([edge, np.nextafter(edge, np.float32(0)), edge, np.nextafter(edge, np.float32(1e9)), 0.5, edge], dtype=np.float32)
+    pd[6, free[10]] = np.inf                                                 # window at +inf: the row falls back
+    pd[7, free[3:9]] = np.nan                                                # NaN keys sort last on either path
+    pd[8] = (1e-3 * np.abs(rng.standard_normal(n)) + 1e-6).astype(np.float32)   # positive but 2^30 codes wide: three passes
+    pd[9, free[:20]] = -np.abs(rng.standard_normal(20)).astype(np.float32)   # 20 distinct negatives below the window
+    got = sehip.rank_rows(dev(pd)).cpu().numpy()
+    want = ro.canon_rank_rows(pd)
+    for r in range(q):
+        assert np.array_equal(got[r], want[r]), r
+    got64 = sehip.rank_rows(dev(pd[:3]), idx64=True).cpu().numpy()           # the reference's index dtype through the same path
+    assert np.array_equal(got64, want[:3])
+
+
 def test_rank_rows_strided_and_unaligned_output(sehip):
     """Row pitches that are not multiples of 16 bytes (scalar write-out) and a strided input."""
     pdw = gauss(6, 3001, seed=5)
@@ -195,10 +227,10 @@ def test_rank_rows_ballot_kernel_in_subprocess():
     assert "hardware-ordered" not in out.stdout
 
 
-@pytest.mark.parametrize("peel", ["0", "1"])
+@pytest.mark.parametrize("peel", ["0", "1", "2"])
 def test_rank_rows_pinned_peel_variants_in_subprocess(peel):
-    """Both builds of the hardware-ordered kernel (plain / group-peeling last pass) on every row shape, whatever the skew
-    detector would choose: SE_RANK_PEEL pins the build (read once per process, hence the subprocess).  Long rows use
+    """All builds of the hardware-ordered kernel (plain / group-peeling last pass / two-pass path, the last one for long rows only) on
+    every row shape, whatever the skew detector would choose: SE_RANK_PEEL pins the build (read once per process, hence the subprocess).  Long rows use
     the 12-bit last digit whose counters alias the exchange buffer; all-positive rows make lane 0's digit group large."""
     import subprocess
     import sys
