@@ -396,10 +396,10 @@ constexpr int RR_WIDE_WORDS = 2048;   // counter words per wave of the 12-bit pa
 // Two-pass path of the long-row kernel: when all keys of a row but at most RR_TWO_OUT lie within RR_TWO_SPAN codes below its largest
 // key (cosine / Euclidean rows of one data set do: the outliers are the query's own distance and its near-duplicates), the row is
 // sorted on (key - lo + 1) << 8 -- 24 significant bits -- in TWO passes of 12 bits, and the few keys below the window, which that
-// mapping sends to 0 (first places, index order), are put into their true order afterwards by one wave.  7 instead of 12 random LDS
+// mapping sends to 0 (first places, index order), are put into their true order afterwards (rank by counting, one thread each).  7 instead of 12 random LDS
 // operations per key.  Rows that do not qualify take the three passes.
 constexpr uint32_t RR_TWO_SPAN = (1u << 24) - 3u;
-constexpr int RR_TWO_OUT = 64;
+constexpr int RR_TWO_OUT = 256;
 // Counters are 16 bits wide, two per LDS word (8 waves x 2048 digits x 2 B = 32 KB next to the 100 KB exchange
 // buffer): a wave holds at most 64 x 104 keys and a destination is < 53,248, so neither half can carry into the
 // other.  The returning add is done on the word with the increment shifted into the digit's half.
@@ -930,7 +930,7 @@ __global__ __launch_bounds__(256) void rank_skew_detect_kernel(const float *__re
     __syncthreads();
     // peeling pays from roughly a 30 % share of one digit (two-valued Euclidean rows: ~50 %; mixed-sign cosine rows: ~10 %)
     if (threadIdx.x == 0) {
-        const bool two = two_ok && row_below[0] <= 1 && row_below[1] <= 1 && row_below[2] <= 1;
+        const bool two = two_ok && row_below[0] <= 4 && row_below[1] <= 4 && row_below[2] <= 4;   // ~N / 1024 keys of the row per sampled key
         *flag = two ? 2u : ((10u * best >= 3u * 3u * (uint32_t)cols) ? 1u : 0u);
     }
 }

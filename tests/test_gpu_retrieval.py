@@ -163,8 +163,8 @@ def test_rank_rows_skewed_top_digit_rows(sehip, n):
 def test_rank_rows_two_pass_path(sehip, n):
     """Long rows whose keys (all but a few) lie within 2^24 codes of the row maximum -- Euclidean-distance rows: the query's own
     distance is the outlier -- take the two-pass path of the register-resident kernel (detector flag 2); every row re-checks itself:
-    up to 64 keys below the window are ordered by one wave afterwards (here: none, 1, exactly 64, with ties / zeros / negatives among
-    them, and at columns the detector does not sample), 65 send the row back to the three passes, as do NaN-free rows that are too
+    up to 256 keys below the window are put in order afterwards (here: none, 1, exactly 256, with ties / zeros / negatives among
+    them, and at columns the detector does not sample), 257 send the row back to the three passes, as do NaN-free rows that are too
     wide.  Also exact ties inside the window, keys exactly on the window's lower edge, +inf (window anchored at inf: everything else
     is 'below'), NaN and padding-like all-ones."""
     rng = np.random.default_rng(n)
@@ -172,8 +172,8 @@ def test_rank_rows_two_pass_path(sehip, n):
     pd = (200.0 + 25.0 * rng.standard_normal((q, n))).astype(np.float32).clip(120.0, 300.0)
     free = np.setdiff1d(np.arange(n), (np.arange(1024) * n) // 1024)         # columns the detector's 1024-column sample skips
     pd[0, 0] = 0.0                                                           # the query's own distance (sampled: one below per row is allowed)
-    pd[1, free[:64]] = rng.choice(np.array([0.0, -0.0, 1e-3, -1e-3, 2.5, 2.5, -7.0], dtype=np.float32), size=64)   # 64 below, with ties
-    pd[2, free[:65]] = np.linspace(-1.0, 1.0, 65, dtype=np.float32)          # 65 below: three passes for this row
+    pd[1, free[:256]] = rng.choice(np.array([0.0, -0.0, 1e-3, -1e-3, 2.5, 2.5, -7.0], dtype=np.float32), size=256)   # 256 below, with ties
+    pd[2, free[:257]] = np.linspace(-1.0, 1.0, 257, dtype=np.float32)        # 257 below: three passes for this row
     pd[3] = np.round(pd[3])                                                  # ~180 distinct values: long tie runs inside the window
     pd[4] = 210.0                                                            # one value
     m = np.float32(pd[5].max())
