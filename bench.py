@@ -46,6 +46,9 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 peak
 # LDS floor of the 3-pass register-resident ranking: LDS wave-instructions per key x measured cycles per
 # wave-instruction of each kind (tools/probes/lds_throughput.hip, profiles/r01_i_lds_throughput_probe.txt) at 2.4 GHz, 256 CUs
 RANK_LDS_FLOOR_CYCLES_PER_KEY = 73000.0 / 50000.0
+# the two-pass path (rows whose keys lie within 2^24 codes of their maximum: the synthetic Euclidean rows do): 7 random + 3 linear
+# LDS operations per key instead of 12 + 5
+RANK_LDS_FLOOR_CYCLES_PER_KEY_TWO_PASS = 43300.0 / 50000.0
 SHADER_CLOCK_GHZ = 2.4
 N_CUS = 256
 
@@ -230,7 +233,8 @@ def bench_retrieval(args, rank, world):
     # algorithmic bytes / flops per launch
     pd_bytes, pd_full, pd_exec, pd_floor = pdist_cost_model(q, n, d, symmetric=queries0 is None)
     rk_bytes = 4.0 * q * n + 4.0 * q * n
-    rk_lds_floor_ms = RANK_LDS_FLOOR_CYCLES_PER_KEY * q * n / (N_CUS * SHADER_CLOCK_GHZ * 1e9) * 1e3
+    two_pass = metric == sehip.METRIC_EUCLID and n >= 32768      # what the ranking kernel's detector selects for these rows
+    rk_lds_floor_ms = (RANK_LDS_FLOOR_CYCLES_PER_KEY_TWO_PASS if two_pass else RANK_LDS_FLOOR_CYCLES_PER_KEY) * q * n / (N_CUS * SHADER_CLOCK_GHZ * 1e9) * 1e3
     pms, rms = kms["pairwise_dist"], kms["rank_rows"]
     kernels = {
         "pairwise_dist": {"ms": pms, "algorithmic_GB": pd_bytes / 1e9, "GBps": pd_bytes / 1e6 / pms, "frac_hbm": pd_bytes / 1e6 / pms / HBM_PEAK_GBS,
@@ -241,8 +245,8 @@ def bench_retrieval(args, rank, world):
                           "frac_of_floor": pd_floor / pms},
         "rank_rows": {"ms": rms, "algorithmic_GB": rk_bytes / 1e9, "GBps": rk_bytes / 1e6 / rms, "frac_hbm": rk_bytes / 1e6 / rms / HBM_PEAK_GBS,
                       "lds_floor_ms": rk_lds_floor_ms, "frac_of_lds_floor": rk_lds_floor_ms / rms,
-                      "lds_floor": "3-pass LSD radix, 17.25 LDS wave-instructions per 64 keys at their measured throughput "
-                                   "(DESIGN.md 5.2), 256 CUs x 2.4 GHz"},
+                      "lds_floor": ("2-pass LSD radix on 24 significant key bits, 10" if two_pass else "3-pass LSD radix, 17.25") +
+                                   " LDS wave-instructions per 64 keys at their measured throughput (DESIGN.md 5.2), 256 CUs x 2.4 GHz"},
     }
     dominant = max(("pairwise_dist", "rank_rows"), key=lambda k: kms[k])
     tr = pmc_traffic_gb(dominant, q, n, d)
