@@ -565,40 +565,43 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
         if constexpr (WIDE && VAR == 2) {
             uint32_t *stat = wave_tot;                                  // [0, 8): per-wave maxima, [8, 16): per-wave counts below the window
             uint2 *outl = reinterpret_cast<uint2 *>(wcnt);              // (key, position) of the keys below the window (the dedicated counters are idle on this path)
-            uint32_t mx = 0;
+            // (every step below is written for its instruction count: two waves per SIMD execute each of them over 98 keys)
+            uint32_t mx = 0;                                             // max of key + 1: NaN / padding (all ones) wrap to 0 and drop out
 #pragma unroll
-            for (int s = 0; s < ITEMS; s++) { const uint32_t k = key[s]; mx = max(mx, k == 0xFFFFFFFFu ? 0u : k); }   // NaN / padding sort last anyway
+            for (int s = 0; s < ITEMS; s++) mx = max(mx, key[s] + 1u);
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, off, 64));
             if (lane == 0) stat[wave] = mx;
+            if (tid == 0) stat[2 * RR_WAVES] = 0;                        // cursor of the list
             __syncthreads();
 #pragma unroll
             for (int w = 0; w < RR_WAVES; w++) mx = max(mx, stat[w]);
-            const uint32_t lo = mx > RR_TWO_SPAN ? mx - RR_TWO_SPAN : 0u;
-            uint32_t below = 0;
+            const uint32_t kmax = mx ? mx - 1u : 0u;
+            // window [lo, kmax]; lo >= 1 (no finite or infinite value has a key below 0x00800000), so lo - 1 exists
+            const uint32_t lo = kmax > RR_TWO_SPAN ? kmax - RR_TWO_SPAN : 1u, lo1 = lo - 1u;
+            uint32_t below_w = 0;                                        // keys of this WAVE below the window: a scalar count
 #pragma unroll
-            for (int s = 0; s < ITEMS; s++) below += key[s] < lo ? 1u : 0u;
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) below += (uint32_t)__shfl_xor((int)below, off, 64);
-            if (lane == 0) stat[RR_WAVES + wave] = below;
-            if (tid == 0) stat[2 * RR_WAVES] = 0;                        // cursor of the list
+            for (int s = 0; s < ITEMS; s++) below_w += (uint32_t)__popcll(__ballot(key[s] < lo));
+            if (lane == 0) stat[RR_WAVES + wave] = below_w;
             __syncthreads();
-            below = 0;
+            uint32_t below = 0;
 #pragma unroll
             for (int w = 0; w < RR_WAVES; w++) below += stat[RR_WAVES + w];
             two = below <= (uint32_t)RR_TWO_OUT;
             n_out = (int)below;
-            {   // branch-free on purpose: a conditional re-definition of the ITEMS key registers makes hipcc copy them through scratch
+            if (two && below_w != 0) {   // wave-uniform and rare: only the waves that hold such keys walk theirs (reads only -- no register is re-defined here)
                 int wpos = wpos0;
                 opaque(wpos);
-                const uint32_t lo_push = two ? lo : 0u;                  // (no key is below 0: nothing is pushed on the three-pass path)
 #pragma unroll
-                for (int s = 0; s < ITEMS; s++) {
-                    const uint32_t k = key[s];
-                    if (k < lo_push) outl[atomicAdd(&stat[2 * RR_WAVES], 1u)] = make_uint2(k, (uint32_t)(wpos + s * WAVE));
-                    const uint32_t t = (k == 0xFFFFFFFFu) ? 0xFFFFFF00u : (k < lo ? 0u : (k - lo + 1u) << 8);
-                    key[s] = two ? t : k;
-                }
+                for (int s = 0; s < ITEMS; s++)
+                    if (key[s] < lo) outl[atomicAdd(&stat[2 * RR_WAVES], 1u)] = make_uint2(key[s], (uint32_t)(wpos + s * WAVE));
+            }
+            // key' = min(sat(key - (lo - 1)), 0xFFFFFF) << 8: 0 below the window, 1 .. 2^24 - 2 inside it, 0xFFFFFF for NaN / padding.
+            // Branch-free on purpose: a conditional re-definition of the ITEMS key registers makes hipcc copy them through scratch.
+#pragma unroll
+            for (int s = 0; s < ITEMS; s++) {
+                const uint32_t t = min(__builtin_elementwise_sub_sat(key[s], lo1), 0xFFFFFFu) << 8;
+                key[s] = two ? t : key[s];
             }
             // (the first barrier of pass 0 orders these LDS accesses before anything that follows)
         }
