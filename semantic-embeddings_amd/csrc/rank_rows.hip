@@ -394,7 +394,8 @@ constexpr int RR_WIDE_WORDS = 2048;   // counter words per wave of the 12-bit pa
 #define SE_RR_TWO 1                   // build parameter: 0 = never take the two-pass path below
 #endif
 // Two-pass path of the long-row kernel: when all keys of a row but at most RR_TWO_OUT lie within RR_TWO_SPAN codes below its largest
-// key (cosine / Euclidean rows of one data set do: the outliers are the query's own distance and its near-duplicates), the row is
+// key (Euclidean-distance rows of one data set do: the outliers are the query's own distance and its near-duplicates; the reference's
+// cosine rows -- -dot, both signs around zero, ~2^31 codes wide -- do not), the row is
 // sorted on (key - lo + 1) << 8 -- 24 significant bits -- in TWO passes of 12 bits, and the few keys below the window, which that
 // mapping sends to 0 (first places, index order), are put into their true order afterwards (rank by counting, one thread each).  7 instead of 12 random LDS
 // operations per key.  Rows that do not qualify take the three passes.
