@@ -217,14 +217,27 @@ int se_topk_merge(const float *d, const int32_t *idx, int parts, int64_t q, int 
                   int32_t *out_i, se_stream_t stream);
 
 /*
- * Fused convenience driver: query tile x gallery -> distances -> top-k, never materialising
- * more than a [q_tile, n] slab of the distance matrix in `workspace`.
+ * Fused distance + top-k: the k nearest gallery rows of every query WITHOUT the [q, n] distance matrix
+ * (SURVEY.md section 8d "fused top-k": bytes = 4 (q + n) d + 8 q k).
+ * Replaces: the head of evaluate_retrieval.py:57-67 (normalise / distances / np.argsort) for consumers that read only the
+ *           first k entries of every ranking (P@k and clipped AHP without AP, class_hierarchy.py:300-309), and it is the
+ *           per-shard step of the sharded-gallery split (gallery shard r passes col_offset = its first global row).
+ * Same arithmetic as se_pairwise_dist (sequential fp32 FMA chain, optional K-block list `kblocks` -- HOST pointer, may be
+ * NULL -- for d > 448, evaluate_retrieval.py:59 on OpenBLAS) and the same canonical order as se_rank_rows: out_i[i, :] ==
+ * the first k entries of se_rank_rows(se_pairwise_dist(queries, gallery))[i], out_d the distances, bit for bit.
+ * Galleries of >= 16384 rows: a sample pass over <= 4096 gallery rows gives every query a distance threshold, the main
+ * pass appends the few values below it to per-query candidate lists from the MFMA tile epilogue, a per-query kernel
+ * sorts them; queries whose list missed [k, capacity] are redone exactly.  Smaller galleries go
+ * through a [rows, n] distance slab in the workspace.
+ *   metric: SE_METRIC_COSINE or SE_METRIC_EUCLID (then sqq [q], sqg [n] = se_row_sqnorm of the operands).
+ *   workspace: se_retrieve_topk_workspace_bytes(q, n, ldg, k) bytes, 256-byte aligned.
  */
-int64_t se_retrieve_topk_workspace_bytes(int64_t q, int64_t n, int k);
+int64_t se_retrieve_topk_workspace_bytes(int64_t q, int64_t n, int64_t ldg, int k);
 int se_retrieve_topk(const float *queries, int64_t ldq, const float *gallery, int64_t ldg,
                      const float *sqq, const float *sqg, int64_t q, int64_t n, int64_t d,
-                     int metric, int64_t col_offset, int k, float *out_d, int32_t *out_i,
-                     void *workspace, int64_t workspace_bytes, se_stream_t stream);
+                     int metric, const int32_t *kblocks, int nkb, int64_t col_offset, int k,
+                     float *out_d, int32_t *out_i, void *workspace, int64_t workspace_bytes,
+                     se_stream_t stream);
 
 /*
  * Hierarchical retrieval metrics of every query from its ranking (the consumer of se_rank_rows / se_retrieve_topk).

@@ -21,6 +21,8 @@ from /root/reference (see oracle/ref_import.py), on seeded inputs:
                       with its own clr_callback.py / sgdr_callback.py driven epoch by epoch
 * retrieval_d555_*.npz, retrieval_d1000_*.npz   D > 448: this host's OpenBLAS restarts its FMA chain per
                       K block; the probed block list travels in the fixture (``kblocks``)
+* topk_head_*.npz   heads (first 256 entries) of the reference's rankings on 640-item D = 555 / D = 1000 problems, for
+                      the top-k / sharded-gallery path (features rebuilt from a seed, SHA-1 checked)
 * imagenet_mintree_unitsphere.npz   the class embedding missing from the reference checkout, regenerated
                       by the reference's compute_class_embedding.py:14-40,176-250 in JSON class order
 
@@ -229,7 +231,29 @@ def lr_schedule_goldens():
     print("lr schedules", {k: np.shape(v) for k, v in out.items()})
 
 
+def topk_goldens(er):
+    """topk_head_*.npz: the HEAD (first 256 entries) of the imported reference's rankings on D > 448 problems large
+    enough for top-251 lists (the sharded-gallery / clipped-AHP consumers; BASELINE configs[4] is D = 1000), with the probed
+    BLAS K-block list.  evaluate_retrieval.py:57-67."""
+    import hashlib
+    from oracle.retrieval_oracle import topk_feature_matrix
+    e_inet = np.load(os.path.join(OUT, "imagenet_mintree_unitsphere.npz"))["embedding"]
+    n = 640
+    for name, kind, seed, norm in (("d1000_cos", "inet", 11, True), ("d1000_euc", "inet", 12, False), ("d555_cos", "gauss", 13, True),
+                                   ("d555_euc", "gauss", 14, False)):
+        feat = topk_feature_matrix(kind, seed, n, e_inet)
+        rank = ref_ranking(er, feat, norm)
+        kb = probe_kblocks(feat)
+        np.savez_compressed(os.path.join(OUT, "topk_head_%s.npz" % name), kind=np.array(kind), seed=np.int64(seed), n=np.int64(n),
+                            sha1=np.array(hashlib.sha1(feat.tobytes()).hexdigest()), normalize=np.bool_(norm),
+                            ref_head=rank[:, :256].astype(np.int16), kblocks=np.array(kb, dtype=np.int32))
+        print("topk", name, feat.shape, norm, "kblocks", kb)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "topk":      # only the round-3 top-k fixtures (everything else untouched)
+        topk_goldens(ref_import.import_reference("evaluate_retrieval"))
+        return
     os.makedirs(OUT, exist_ok=True)
     er = ref_import.import_reference("evaluate_retrieval")
     ch = ref_import.import_reference("class_hierarchy")
@@ -339,6 +363,7 @@ def main():
     emb["imagenet_mintree_unitsphere"] = e_inet.astype(np.float32)   # as committed (the fixture must be self-consistent)
     loss_reference_goldens(emb)
     lr_schedule_goldens()
+    topk_goldens(er)
     print("done ->", OUT)
 
 

@@ -185,3 +185,29 @@ def probe_host_blas_is_fma_chain(d=100, n=256, seed=0):
     rng = np.random.default_rng(seed)
     x = rng.standard_normal((n, d)).astype(np.float32)
     return bool(np.array_equal(np.dot(x, x.T), canon_pdist(x, None, METRIC_DOT)))
+
+
+# --------------------------------------------------------------------------------------------------
+# topk_head_*.npz fixtures (oracle/make_golden.py topk_goldens): features rebuilt from their seed
+# --------------------------------------------------------------------------------------------------
+
+def topk_feature_matrix(kind, seed, n, emb=None):
+    """The feature matrices of the topk_head_* fixtures (they store seed / SHA-1 instead of 2.5 MB of incompressible
+    floats).  'inet': ILSVRC-like trained features (class-embedding row + noise, D = 1000); 'gauss': plain gaussian, D = 555."""
+    rng = np.random.default_rng(seed)
+    if kind == "inet":
+        y = rng.integers(0, emb.shape[0], size=n)
+        return (emb[y] + 0.03 * rng.standard_normal((n, emb.shape[1]))).astype(np.float32)
+    return rng.standard_normal((n, 555)).astype(np.float32)
+
+
+def load_topk_fixture(path):
+    """-> (features f32 [n, D], normalize, kblocks list, ref_head int64 [n, 256]) of a topk_head_*.npz fixture;
+    raises if this NumPy does not regenerate the exact feature bytes the reference was run on."""
+    import hashlib
+    g = np.load(path)
+    emb = np.load(os.path.join(os.path.dirname(path), "imagenet_mintree_unitsphere.npz"))["embedding"]
+    feat = topk_feature_matrix(str(g["kind"]), int(g["seed"]), int(g["n"]), emb)
+    if hashlib.sha1(feat.tobytes()).hexdigest() != str(g["sha1"]):
+        raise RuntimeError("fixture %s: regenerated features differ from the ones the reference ranked" % path)
+    return feat, bool(g["normalize"]), g["kblocks"].tolist(), g["ref_head"].astype(np.int64)

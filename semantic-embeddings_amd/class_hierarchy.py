@@ -295,7 +295,9 @@ class ClassHierarchy(object):
           L = max(ks, clip) + 1, RCCL all-gather of the ``(distance, global index)`` lists, canonical k-way merge
           (``sharded_retrieval.sharded_topk``), then each rank scores its share of the queries.
         With one process the same fused top-L path serves P@k / AHP@clip-only requests (``head_via_topk``; the full-ranking
-        path otherwise).
+        path otherwise).  ``kblocks`` (None | 'openblas' | list: the BLAS K-block list for D > 448) reaches BOTH paths -- the
+        top-L kernels restart their FMA chain per block exactly like the full-ranking ones, so one process and G processes
+        return the same near-tie orders.
         ``kernels`` (tests): CPU stand-ins ``{'ranking_tiles', 'hierarchical_precision', 'local_topk', 'merge', 'device'}``."""
         import torch
         from sharded_retrieval import shard_bounds, sharded_topk
@@ -349,7 +351,7 @@ class ClassHierarchy(object):
             import sehip
             return {'curves': sehip.hprec_reciprocal_curves(args_d[2], args_d[3])}
 
-        if head_only and (world > 1 or (head_via_topk and kblocks is None)):
+        if head_only and (world > 1 or head_via_topk):
             # ---- top-L lists are enough for every requested metric: fused distance + top-L (the N x N matrix is never written),
             #      over this rank's shard of the gallery when there are several ranks ----
             L = min(n, max(ks + [ahp_clip or 0]) + 1)
@@ -363,8 +365,10 @@ class ClassHierarchy(object):
                 metric = sehip.METRIC_COSINE if normalize else sehip.METRIC_EUCLID
             else:
                 metric = None
+            from evaluate_retrieval import _resolve_kblocks
             _, top_i = sharded_topk(feats, feats[g0:g1], L, g0, metric=metric, group=group,
-                                    local_topk=kernels.get('local_topk'), merge=kernels.get('merge'))
+                                    local_topk=kernels.get('local_topk'), merge=kernels.get('merge'),
+                                    kblocks=_resolve_kblocks(kblocks, int(feats.shape[1])))
             if q1 > q0:
                 outs.append(kernels['hierarchical_precision'](top_i[q0:q1].contiguous(), cls_d, cls_d[q0:q1].contiguous(),
                                                              qidx_d[q0:q1].contiguous(), *args_d, ks_d, ahp_len=ahp_len, want_ap=False,

@@ -63,10 +63,7 @@ constexpr int PD_RPP = PD_THREADS / PD_F4R;                  // operand rows cov
 constexpr int PD_NLOAD = PD_BM / PD_RPP;                     // pieces per operand per thread (4 at BK = 64, 2 at BK = 32)
 constexpr int64_t PD_MAX_LD = (int64_t)1 << 23;              // 128 rows * ld must fit 32-bit offsets
 
-struct KBlocks {
-    int n;
-    int len[PD_MAX_KB];
-};
+static_assert(PD_MAX_KB == SE_MAX_KB, "KBlocks capacity");
 
 __device__ __forceinline__ float mask_f(float x, bool keep)
 {
@@ -220,13 +217,14 @@ __device__ __forceinline__ float pd_finish(float v, float sa, float sb)
 // flags
 constexpr int PDF_VEC_A = 1, PDF_VEC_B = 2, PDF_VEC_O = 4, PDF_NO_STORE = 8, PDF_NO_MFMA = 16, PDF_STAGGER = 32, PDF_PLAIN_ST = 64, PDF_NO_GSTORE = 128;
 
-template <int METRIC, bool MULTI_KB, bool SYM, bool VEC>
+template <int METRIC, bool MULTI_KB, bool SYM, bool VEC, int EPI>
 __global__ __launch_bounds__(PD_THREADS, (PD_WAVES / 4) * PD_WGS_PER_CU) void pdist_kernel(
     const float *__restrict__ A, uint32_t lda, const float *__restrict__ Bm, uint32_t ldb,
     const float *__restrict__ sqa, const float *__restrict__ sqb, int64_t Q, int64_t N, int64_t D,
     KBlocks kbs, int nchunks, float *__restrict__ out, uint32_t ldo, int tiles_m, int tiles_n, int64_t ntiles, int flags,
-    unsigned long long *prof)
+    unsigned long long *prof, FusedArgs fa)
 {
+    static_assert(EPI == EPI_STORE || !SYM, "the fused top-k epilogues walk the general tile order");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *sA = smem;
     float *sB = smem + PD_BM * PD_LD;
@@ -359,6 +357,70 @@ __global__ __launch_bounds__(PD_THREADS, (PD_WAVES / 4) * PD_WGS_PER_CU) void pd
                 for (int j = 0; j < NB; j++)
 #pragma unroll
                     for (int r = 0; r < 16; r++) asm volatile("" ::"v"(acc[j][r]));
+            } else if (EPI != EPI_STORE) {
+                // ---- fused top-k passes (se_retrieve_topk): rows of the tile = gallery, columns = queries; lane (col, hi) of wave
+                //      (wm, wn) holds, per 32 x 32 block (mi, j), 16 gallery rows of the ONE query  cur_n0 + wn*64 + j*32 + col ----
+                const int rows_here = (int)((Q - cur_m0 < PD_BM) ? (Q - cur_m0) : PD_BM);
+                const int cols_here = (int)((N - cur_n0 < PD_BN) ? (N - cur_n0) : PD_BN);
+                const bool full_rows = rows_here == PD_BM;
+                const int lr0 = wm * PD_WROWS + 4 * hi;
+#define PD_FVAL(MI_, J, R)                                                                                                   \
+    pd_finish<METRIC>(MULTI_KB ? tot[(MI_) * 2 + (J)][R] : acc[(MI_) * 2 + (J)][R],                                            \
+                      METRIC == SE_METRIC_EUCLID ? fsa[((R) & 3) + 4 * ((R) >> 2)] : 0.f, sbq)
+#pragma unroll
+                for (int mi = 0; mi < PD_MI; mi++) {
+                    float fsa[16];
+                    if (METRIC == SE_METRIC_EUCLID) {
+#pragma unroll
+                        for (int r = 0; r < 16; r++) {
+                            const int lr = lr0 + mi * 32 + (r & 3) + 8 * (r >> 2);
+                            fsa[r] = sqa[(cur_m0 + (lr < rows_here ? lr : rows_here - 1)) * fa.sqa_stride];
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 2; j++) {
+                        const int lc = wn * 64 + j * 32 + col;
+                        const bool qok = lc < cols_here;
+                        const int64_t qg = cur_n0 + (qok ? lc : cols_here - 1);
+                        const float sbq = METRIC == SE_METRIC_EUCLID ? sqb[qg] : 0.f;
+                        if (EPI == EPI_GROUPMIN) {
+                            float m = __builtin_inff();
+                            bool any = false;
+#pragma unroll
+                            for (int r = 0; r < 16; r++) {
+                                const int lr = lr0 + mi * 32 + (r & 3) + 8 * (r >> 2);
+                                const float v = PD_FVAL(mi, j, r);
+                                const bool ok = (full_rows || lr < rows_here) && (v == v);
+                                m = (ok && v < m) ? v : m;
+                                any = any || ok;
+                            }
+                            if (!any) m = __builtin_nanf("");     // a group of NaNs only: sorted last by the threshold kernel
+                            if (qok) fa.gm[qg * fa.gm_ld + (cur_m0 / PD_BM) * (PD_WAVES * PD_MI) + (wm * PD_MI + mi) * 2 + hi] = m;
+                        } else {
+                            const float tau = fa.tau[qg];
+                            unsigned cnt = 0;
+#pragma unroll
+                            for (int r = 0; r < 16; r++) {
+                                const int lr = lr0 + mi * 32 + (r & 3) + 8 * (r >> 2);
+                                cnt += ((PD_FVAL(mi, j, r) <= tau) && (full_rows || lr < rows_here)) ? 1u : 0u;
+                            }
+                            if (qok && cnt) {
+                                unsigned slot = atomicAdd(&fa.rowcnt[qg], cnt);
+                                uint2 *lst = fa.lists + qg * fa.cap;
+#pragma unroll
+                                for (int r = 0; r < 16; r++) {
+                                    const int lr = lr0 + mi * 32 + (r & 3) + 8 * (r >> 2);
+                                    const float v = PD_FVAL(mi, j, r);
+                                    if ((v <= tau) && (full_rows || lr < rows_here)) {
+                                        if (slot < (unsigned)fa.cap) lst[slot] = make_uint2(__float_as_uint(v), (uint32_t)(cur_m0 + lr));
+                                        slot++;
+                                    }
+                                }
+                            }
+                        }
+                    }
+                }
+#undef PD_FVAL
             } else {
                 // Staged epilogue: the finished tile goes through the (now idle) operand LDS so that HBM sees
                 // whole 512-byte row segments, two rows per wave instruction, as streaming (nontemporal) 16-byte
@@ -465,9 +527,10 @@ static int pd_num_cus()
     return cus;
 }
 
-template <int METRIC, bool MULTI, bool SYM, bool VEC>
+template <int METRIC, bool MULTI, bool SYM, bool VEC, int EPI = EPI_STORE>
 static int launch_pdist3(const float *a, int64_t lda, const float *b, int64_t ldb, const float *sqa, const float *sqb,
-                         int64_t q, int64_t n, int64_t d, const KBlocks &kbs, float *out, int64_t ldo, hipStream_t s)
+                         int64_t q, int64_t n, int64_t d, const KBlocks &kbs, float *out, int64_t ldo, hipStream_t s,
+                         const FusedArgs &fa = FusedArgs{nullptr, 0, nullptr, nullptr, nullptr, 0, 1})
 {
     const int tiles_m = (int)((q + PD_BM - 1) / PD_BM), tiles_n = (int)((n + PD_BN - 1) / PD_BN);
     const int64_t ntiles = SYM ? ((int64_t)tiles_n * (tiles_n + 1) / 2) : ((int64_t)tiles_m * tiles_n);
@@ -494,7 +557,7 @@ static int launch_pdist3(const float *a, int64_t lda, const float *b, int64_t ld
     grid = grid / 8 * 8;
     if (grid > ntiles) grid = ntiles;
     if (grid < 1) grid = 1;
-    auto kern = pdist_kernel<METRIC, MULTI, SYM, VEC>;
+    auto kern = pdist_kernel<METRIC, MULTI, SYM, VEC, EPI>;
     SE_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     static const bool profile = tuning_env("SE_PD_PROFILE") != nullptr;   // -DSE_TUNING build only: allocates, synchronises, prints
     unsigned long long *prof = nullptr;
@@ -503,7 +566,7 @@ static int launch_pdist3(const float *a, int64_t lda, const float *b, int64_t ld
         SE_HIP_CHECK(hipMemsetAsync(prof, 0, 12 * sizeof(unsigned long long), s));
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(PD_THREADS), lds, s, a, (uint32_t)lda, b, (uint32_t)ldb, sqa, sqb, q, n,
-                       d, kbs, nchunks, out, (uint32_t)ldo, tiles_m, tiles_n, ntiles, flags, prof);
+                       d, kbs, nchunks, out, (uint32_t)ldo, tiles_m, tiles_n, ntiles, flags, prof, fa);
     SE_LAUNCH_CHECK();
     if (profile) {
         unsigned long long h[12];
@@ -547,6 +610,57 @@ static int launch_pdist(const float *a, int64_t lda, const float *b, int64_t ldb
                  : launch_pdist2<METRIC, false, false>(a, lda, b, ldb, sqa, sqb, q, n, d, kbs, out, ldo, s);
 }
 
+// ---- the two tile-loop passes of the fused distance + top-k (driver: topk.hip) ----
+template <int METRIC, int EPI>
+static int launch_fused2(const float *g, int64_t ldg, const float *qs, int64_t ldq, const float *sqg, const float *sqq, int64_t n_a,
+                         int64_t n_q, int64_t d, const KBlocks &kbs, bool multi, const FusedArgs &fa, hipStream_t s)
+{
+    bool vec = (ldg % 4 == 0) && ((((uintptr_t)g) & 15) == 0) && (ldq % 4 == 0) && ((((uintptr_t)qs) & 15) == 0);
+    int64_t beg = 0;
+    for (int i = 0; i < kbs.n; i++) { if (beg & 3) vec = false; beg += kbs.len[i]; }
+    if (multi) return vec ? launch_pdist3<METRIC, true, false, true, EPI>(g, ldg, qs, ldq, sqg, sqq, n_a, n_q, d, kbs, nullptr, n_q, s, fa)
+                          : launch_pdist3<METRIC, true, false, false, EPI>(g, ldg, qs, ldq, sqg, sqq, n_a, n_q, d, kbs, nullptr, n_q, s, fa);
+    return vec ? launch_pdist3<METRIC, false, false, true, EPI>(g, ldg, qs, ldq, sqg, sqq, n_a, n_q, d, kbs, nullptr, n_q, s, fa)
+               : launch_pdist3<METRIC, false, false, false, EPI>(g, ldg, qs, ldq, sqg, sqq, n_a, n_q, d, kbs, nullptr, n_q, s, fa);
+}
+
+int launch_fused_pass(int epi, const float *gallery, int64_t lda, const float *queries, int64_t ldq, const float *sqg, const float *sqq,
+                      int64_t n_a, int64_t n_q, int64_t d, int metric, const KBlocks &kbs, bool multi, const FusedArgs &fa, hipStream_t s)
+{
+    if (lda >= PD_MAX_LD || ldq >= PD_MAX_LD) return fail(SE_ERR_UNSUPPORTED, "fused top-k pass: leading dimension too large");
+    if (metric == SE_METRIC_COSINE) {
+        return epi == EPI_GROUPMIN ? launch_fused2<SE_METRIC_COSINE, EPI_GROUPMIN>(gallery, lda, queries, ldq, sqg, sqq, n_a, n_q, d, kbs, multi, fa, s)
+                                   : launch_fused2<SE_METRIC_COSINE, EPI_FILTER>(gallery, lda, queries, ldq, sqg, sqq, n_a, n_q, d, kbs, multi, fa, s);
+    }
+    if (metric == SE_METRIC_EUCLID) {
+        return epi == EPI_GROUPMIN ? launch_fused2<SE_METRIC_EUCLID, EPI_GROUPMIN>(gallery, lda, queries, ldq, sqg, sqq, n_a, n_q, d, kbs, multi, fa, s)
+                                   : launch_fused2<SE_METRIC_EUCLID, EPI_FILTER>(gallery, lda, queries, ldq, sqg, sqq, n_a, n_q, d, kbs, multi, fa, s);
+    }
+    return fail(SE_ERR_UNSUPPORTED, "fused top-k pass: metric %d", metric);
+}
+
+int64_t pdist_max_ld() { return PD_MAX_LD; }
+
+int make_kblocks(const char *who, const int32_t *kblocks, int nkb, int64_t d, KBlocks &kbs, bool &multi)
+{
+    kbs.n = 1;
+    kbs.len[0] = (int)d;
+    multi = false;
+    if (kblocks && nkb > 1) {
+        if (nkb > SE_MAX_KB) return fail(SE_ERR_UNSUPPORTED, "%s: at most %d K-blocks", who, SE_MAX_KB);
+        int64_t sum = 0;
+        for (int i = 0; i < nkb; i++) {
+            if (kblocks[i] <= 0) return fail(SE_ERR_INVALID, "%s: K-block %d has length %d", who, i, kblocks[i]);
+            kbs.len[i] = kblocks[i];
+            sum += kblocks[i];
+        }
+        if (sum != d) return fail(SE_ERR_INVALID, "%s: K-blocks sum to %lld, expected %lld", who, (long long)sum, (long long)d);
+        kbs.n = nkb;
+        multi = true;
+    }
+    return SE_OK;
+}
+
 }  // namespace se
 
 #ifdef SE_PD_WS_BUILD
@@ -572,21 +686,8 @@ extern "C" int se_pairwise_dist(const float *a, int64_t lda, const float *b, int
     if (lda >= PD_MAX_LD || ldb >= PD_MAX_LD || ldo >= PD_MAX_LD)
         return fail(SE_ERR_UNSUPPORTED, "se_pairwise_dist: leading dimensions must be < %lld elements", (long long)PD_MAX_LD);
     KBlocks kbs;
-    kbs.n = 1;
-    kbs.len[0] = (int)d;
     bool multi = false;
-    if (kblocks && nkb > 1) {
-        if (nkb > PD_MAX_KB) return fail(SE_ERR_UNSUPPORTED, "se_pairwise_dist: at most %d K-blocks", PD_MAX_KB);
-        int64_t sum = 0;
-        for (int i = 0; i < nkb; i++) {
-            if (kblocks[i] <= 0) return fail(SE_ERR_INVALID, "se_pairwise_dist: K-block %d has length %d", i, kblocks[i]);
-            kbs.len[i] = kblocks[i];
-            sum += kblocks[i];
-        }
-        if (sum != d) return fail(SE_ERR_INVALID, "se_pairwise_dist: K-blocks sum to %lld, expected %lld", (long long)sum, (long long)d);
-        kbs.n = nkb;
-        multi = true;
-    }
+    if (const int rc = make_kblocks("se_pairwise_dist", kblocks, nkb, d, kbs, multi)) return rc;
     hipStream_t s = (hipStream_t)stream;
 #ifdef SE_PD_WS_BUILD
     if (!multi && (metric == SE_METRIC_COSINE || metric == SE_METRIC_EUCLID || metric == SE_METRIC_DOT)) {

@@ -74,4 +74,34 @@ __device__ __forceinline__ float wave_sum(float v)
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
+// K-block list of the canonical dot product: the FMA chain restarts per block, block sums are added in order
+constexpr int SE_MAX_KB = 16;
+struct KBlocks {
+    int n;
+    int len[SE_MAX_KB];
+};
+// host: validate a caller's K-block list into `kbs`; *multi = more than one block.  SE_OK or an error code (text set).
+int make_kblocks(const char *who, const int32_t *kblocks, int nkb, int64_t d, KBlocks &kbs, bool &multi);
+
+// ---- fused distance + top-k (se_retrieve_topk): the two passes that run on the tile loop of pdist_mfma.hip ----
+// Both take the GALLERY as the row operand and the QUERIES as the column operand of the MFMA tiles, so that a lane owns ONE
+// query per 32-column block and sees 16 gallery rows of it per tile.
+constexpr int EPI_STORE = 0;      // se_pairwise_dist: the tile goes to the distance matrix
+constexpr int EPI_GROUPMIN = 1;   // sample pass: min over each lane's 16 values -> gm[query, group]
+constexpr int EPI_FILTER = 2;     // main pass: values <= tau[query] are appended to the query's candidate list
+constexpr int FUSED_GROUP = 16;   // values per group minimum (one lane, one 32 x 32 accumulator block)
+struct FusedArgs {
+    float *gm;             // EPI_GROUPMIN: [queries, gm_ld] group minima; group = 8 * (tile row index) + 2 * wave row + lane half
+    int64_t gm_ld;
+    const float *tau;      // EPI_FILTER: [queries] thresholds
+    unsigned *rowcnt;      // EPI_FILTER: [queries] candidates appended so far (may exceed cap: the row is then redone)
+    uint2 *lists;          // EPI_FILTER: [queries, cap] (float bits of the distance, gallery row)
+    int64_t cap;
+    int64_t sqa_stride;    // Euclidean epilogue: |a|^2 of row r is sqa[r * sqa_stride] (the sample pass strides through the gallery)
+};
+// host: one pass over (gallery rows [n_a, d] with pitch lda) x (queries [n_q, d]); metric SE_METRIC_COSINE / SE_METRIC_EUCLID
+int launch_fused_pass(int epi, const float *gallery, int64_t lda, const float *queries, int64_t ldq, const float *sqg, const float *sqq,
+                      int64_t n_a, int64_t n_q, int64_t d, int metric, const KBlocks &kbs, bool multi, const FusedArgs &fa, hipStream_t s);
+int64_t pdist_max_ld();
+
 }  // namespace se

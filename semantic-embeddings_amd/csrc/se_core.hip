@@ -20,6 +20,6 @@ int fail(int code, const char *fmt, ...)
 
 }  // namespace se
 
-extern "C" int se_version(void) { return 100; /* 0.1.0 */ }
+extern "C" int se_version(void) { return 300; /* 0.3.0: se_retrieve_topk takes K-blocks and ldg (fused distance + top-k) */ }
 extern "C" const char *se_last_error(void) { return se::err_buf(); }
 extern "C" const char *se_build_arch(void) { return "gfx950"; }

@@ -44,26 +44,21 @@ __device__ __forceinline__ void bitonic_sort_u64(uint64_t *v, int P, int nthread
     __syncthreads();
 }
 
-__global__ __launch_bounds__(TK_THREADS) void topk_rows_kernel(const float *__restrict__ pdist, int64_t ldp,
-                                                               int64_t Q, int N, int64_t col_offset, int k, int P,
-                                                               float *__restrict__ out_d, int32_t *__restrict__ out_i, int only_flagged)
+// One row: exact radix SELECT of the k-th smallest canonical key, tie-aware collection, sort, output (whole workgroup).
+// lds: P * 8 + (TK_NB + TK_WAVES + 1 + 4) * 4 bytes.
+__device__ __forceinline__ void topk_select_row(const float *__restrict__ drow, int N, int64_t col_offset, int k, int P,
+                                                float *__restrict__ od, int32_t *__restrict__ oi, uint64_t *lds)
 {
-    extern __shared__ __attribute__((aligned(16))) uint64_t tk_lds64[];
-    uint64_t *cand = tk_lds64;                          // [P]
-    uint32_t *hist = (uint32_t *)(tk_lds64 + P);        // [TK_NB]
+    uint64_t *cand = lds;                               // [P]
+    uint32_t *hist = (uint32_t *)(lds + P);             // [TK_NB]
     uint32_t *wcnt = hist + TK_NB;                      // [TK_WAVES + 1]
     uint32_t *ctl = wcnt + TK_WAVES + 1;                // [4]: prefix, remaining k, n_lt cursor
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-
     int chunk = (N + TK_WAVES - 1) / TK_WAVES;
     chunk = (chunk + WAVE - 1) / WAVE * WAVE;
     const int beg = wave * chunk;
     const int end = (beg + chunk < N) ? (beg + chunk) : N;
-
-    for (int64_t row = blockIdx.x; row < Q; row += gridDim.x) {
-        const float *drow = pdist + row * ldp;
-        if (only_flagged && out_i[row * k] != TK_REDO) continue;   // repair pass behind topk_sample_kernel (uniform per workgroup)
-
+    {
         // ---------- radix select: find the canonical key of the k-th smallest ----------
         uint32_t prefix = 0, prefix_mask = 0;
         uint32_t remaining = (uint32_t)k;  // rank (1-based) of the wanted key among keys matching prefix
@@ -150,9 +145,20 @@ __global__ __launch_bounds__(TK_THREADS) void topk_rows_kernel(const float *__re
         bitonic_sort_u64(cand, P, TK_THREADS);
         for (int r = tid; r < k; r += TK_THREADS) {
             const uint64_t c = cand[r];
-            out_d[row * k + r] = key_to_float((uint32_t)(c >> 32));
-            out_i[row * k + r] = (int32_t)(col_offset + (int64_t)(uint32_t)c);
+            od[r] = key_to_float((uint32_t)(c >> 32));
+            oi[r] = (int32_t)(col_offset + (int64_t)(uint32_t)c);
         }
+    }
+}
+
+__global__ __launch_bounds__(TK_THREADS) void topk_rows_kernel(const float *__restrict__ pdist, int64_t ldp,
+                                                               int64_t Q, int N, int64_t col_offset, int k, int P,
+                                                               float *__restrict__ out_d, int32_t *__restrict__ out_i, int only_flagged)
+{
+    extern __shared__ __attribute__((aligned(16))) uint64_t tk_lds64[];
+    for (int64_t row = blockIdx.x; row < Q; row += gridDim.x) {
+        if (only_flagged && out_i[row * k] != TK_REDO) continue;   // repair pass behind topk_sample_kernel (uniform per workgroup)
+        topk_select_row(pdist + row * ldp, N, col_offset, k, P, out_d + row * k, out_i + row * k, tk_lds64);
     }
 }
 
@@ -415,11 +421,238 @@ extern "C" int se_topk_merge(const float *d, const int32_t *idx, int parts, int6
 }
 
 // ------------------------------------------------------------------------------------------------
-// fused driver: distance slab -> top-k, query tile by query tile
+// se_retrieve_topk: distances + top-k without the distance matrix (SURVEY.md section 8d "fused top-k": bytes =
+// 4 (Q + N) D + 8 Q k).  Replaces the head of evaluate_retrieval.py:57-67 for consumers that only need the first k
+// entries of every ranking (clipped AHP / P@k without AP; the per-shard step of the sharded-gallery split).
+//
+// Three steps on the tile loop of pdist_mfma.hip (gallery = row operand, queries = column operand: a lane owns one query
+// per 32-column block), no [Q, N] slab in between:
+//   1. SAMPLE pass (EPI_GROUPMIN): S evenly spaced gallery rows x all queries; every lane writes the minimum of the 16
+//      values it holds of its query -> gm[query, S / 16 group minima].
+//   2. THRESHOLD: tau[query] = the j-th smallest group minimum (one wave per query, bitonic sort in registers).  A
+//      group minimum is <= x as soon as ONE of its 16 samples is, so the number of groups below the k/N quantile is
+//      Binomial(G, 1 - (1 - k/N)^16): j is chosen on the host so that fewer than k gallery items lie below tau with
+//      probability <= 1e-6 per query, and the list capacity so that more than `cap` do with the same probability.
+//   3. MAIN pass (EPI_FILTER): all N gallery rows; values <= tau[query] (about 2-3 k of the N) are appended to the
+//      query's candidate list (one returning atomic per lane and tile for the slots), then a per-query kernel sorts the
+//      candidates on the canonical (key, index) composite and writes the first k.
+// Every key of the true top-k is <= the k-th smallest key <= tau whenever the list holds >= k entries, so the result is
+// EXACTLY the head of the canonical ranking; queries whose list holds < k or > cap entries (NaN rows, huge tie groups, a
+// gallery the strided sample misrepresents) are redone by an exact kernel that recomputes their distance row with the same
+// FMA chain on the vector ALU (bit-identical to the MFMA chain) and runs the radix select on it.
+// Small problems (n < 16384, or k/N too large for the sample to resolve) keep the distance-slab path below.
 // ------------------------------------------------------------------------------------------------
+
+namespace se {
+
+constexpr int FB_GRID = 256;                    // workgroups (and scratch rows) of the exact fallback kernel
+constexpr double FUSED_P_FAIL = 1e-6;           // per-query probability of needing it, by design
+
+static double binom_sf(int G, double p, int j)  // P(Binomial(G, p) >= j)
+{
+    if (j <= 0) return 1.0;
+    if (j > G) return 0.0;
+    if (p <= 0.0) return 0.0;
+    if (p >= 1.0) return 1.0;
+    double sum = 0.0;
+    const double lp = log(p), lq = log1p(-p);
+    for (int x = j; x <= G; x++) sum += exp(lgamma(G + 1.0) - lgamma(x + 1.0) - lgamma(G - x + 1.0) + x * lp + (G - x) * lq);
+    return sum < 1.0 ? sum : 1.0;
+}
+
+struct FusedPlan {
+    bool ok;
+    int S;          // sampled gallery rows (multiple of 128)
+    int64_t step;   // sample i = gallery row i * step
+    int G;          // group minima per query = S / 16
+    int j;          // tau = j-th smallest group minimum (1-based)
+    int cap;        // candidate list capacity per query
+};
+
+static FusedPlan fused_plan(int64_t n, int64_t ldg, int k)
+{
+    FusedPlan p = {false, 0, 0, 0, 0, 0};
+    int force = -1;                                                          // -DSE_TUNING build: SE_TOPK_FUSED=0 / 1 pins the path
+    if (const char *e = tuning_env("SE_TOPK_FUSED")) force = atoi(e);
+    if (force == 0) return p;
+    if (n < (force == 1 ? 256 : 16384)) return p;
+    int S = n >= 65536 ? 4096 : 2048;
+    if ((int64_t)S > n / 2) S = (int)(n / 2 / 128 * 128);
+    if (const char *e = tuning_env("SE_TOPK_SAMPLES")) S = atoi(e) / 128 * 128;
+    if (S < 128) return p;
+    int64_t step = n / S;
+    if (step * ldg >= pdist_max_ld()) step = (pdist_max_ld() - 1) / ldg;    // 32-bit tile offsets: sample a prefix of the gallery more densely
+    if (step < 1) return p;
+    const int G = S / FUSED_GROUP;
+    if (G > 256) return p;                                                   // threshold kernel: 4 minima per lane
+    const double q0 = (double)k / (double)n;
+    const double pi0 = 1.0 - pow(1.0 - q0, (double)FUSED_GROUP);
+    int j = 1;
+    while (j <= G && binom_sf(G, pi0, j) > FUSED_P_FAIL) j++;
+    const bool forced = force == 1;                                          // tests: small galleries through the fused kernels anyway
+    if (j > G / 2) {                                                         // k / n too large for this sample to resolve
+        if (!forced) return p;
+        if (j > G) j = G;
+    }
+    // largest plausible fraction of the gallery below tau: the j-th group minimum lies above the q1 quantile with probability
+    // P(Binomial(G, pi(q1)) < j); grow q1 until that is <= FUSED_P_FAIL
+    double q1 = q0;
+    for (int it = 0; it < 400 && q1 < 1.0; it++) {
+        const double pi1 = 1.0 - pow(1.0 - q1, (double)FUSED_GROUP);
+        if (1.0 - binom_sf(G, pi1, j) <= FUSED_P_FAIL) break;
+        q1 *= 1.05;
+    }
+    if (q1 > 0.25 && !forced) return p;
+    if (q1 > 1.0) q1 = 1.0;
+    double capd = q1 * (double)n + 6.0 * sqrt(q1 * (double)n) + 64.0;
+    if (capd < 2.0 * k) capd = 2.0 * k;
+    if (capd > (double)n) capd = (double)n;
+    int cap = (int)((capd + 255.0) / 256.0) * 256;
+    if (forced && cap > TK_CAP) cap = TK_CAP;
+    if (const char *e = tuning_env("SE_TOPK_J")) j = atoi(e);                // tests: a j of 1 sends every query to the exact fallback
+    if (const char *e = tuning_env("SE_TOPK_CAP")) cap = atoi(e);
+    if (cap > TK_CAP || j < 1 || j > G) return p;
+    p = {true, S, step, G, j, cap};
+    return p;
+}
+
+// tau[q] = j-th smallest of the G group minima of query q: one wave per query, 4 keys per lane, bitonic sort in registers.
+__global__ __launch_bounds__(256) void topk_tau_kernel(const float *__restrict__ gm, int64_t gm_ld, int64_t Q, int G, int j, float *__restrict__ tau)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= Q) return;
+    uint32_t v[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int e = lane * 4 + r;
+        v[r] = e < G ? canon_key(gm[q * gm_ld + e]) : 0xFFFFFFFFu;
+    }
+#pragma unroll 1
+    for (int k = 2; k <= 256; k <<= 1) {
+#pragma unroll 1
+        for (int jj = k >> 1; jj >= 4; jj >>= 1) {          // partner in another lane
+            const int lm = jj >> 2;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const uint32_t o = (uint32_t)__shfl_xor((int)v[r], lm, 64);
+                const int e = lane * 4 + r;
+                const bool take_min = (((e & k) == 0) == ((e & jj) == 0));
+                v[r] = take_min ? (o < v[r] ? o : v[r]) : (o > v[r] ? o : v[r]);
+            }
+        }
+#pragma unroll
+        for (int jj = 2; jj > 0; jj >>= 1) {                // partner register of the same lane
+            if (jj < k) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    if ((r & jj) == 0) {
+                        const bool up = (((lane * 4 + r) & k) == 0);
+                        const uint32_t a = v[r], b = v[r | jj];
+                        const bool sw = (a > b) == up;
+                        v[r] = sw ? b : a;
+                        v[r | jj] = sw ? a : b;
+                    }
+                }
+            }
+        }
+    }
+    const int want = j - 1;
+    if (lane == (want >> 2)) {
+        const uint32_t key = (want & 3) == 0 ? v[0] : ((want & 3) == 1 ? v[1] : ((want & 3) == 2 ? v[2] : v[3]));
+        tau[q] = key == 0xFFFFFFFFu ? __builtin_nanf("") : key_to_float(key);   // NaN: nothing passes, the query goes to the fallback
+    }
+}
+
+// candidates of every query -> canonical top-k; queries whose list missed [k, cap] are flagged for the exact kernel
+__global__ __launch_bounds__(TK_THREADS) void topk_lists_kernel(const uint2 *__restrict__ lists, const unsigned *__restrict__ rowcnt, int64_t cap,
+                                                                int64_t Q, int64_t col_offset, int k, float *__restrict__ out_d,
+                                                                int32_t *__restrict__ out_i)
+{
+    extern __shared__ __attribute__((aligned(16))) uint64_t tl_lds64[];
+    uint64_t *cand = tl_lds64;
+    const int tid = threadIdx.x;
+    for (int64_t row = blockIdx.x; row < Q; row += gridDim.x) {
+        const unsigned total = rowcnt[row];
+        if (total < (unsigned)k || total > (unsigned)cap) {
+            if (tid == 0) out_i[row * k] = TK_REDO;
+            continue;
+        }
+        const uint2 *lst = lists + row * cap;
+        __syncthreads();     // the previous row's output reads of cand are done
+#define TK_SORT_LIST(PER)                                                                     \
+    {                                                                                         \
+        uint64_t cv[PER];                                                                     \
+        _Pragma("unroll") for (int r = 0; r < PER; r++) {                                     \
+            const int e = tid * PER + r;                                                      \
+            cv[r] = ~0ull;                                                                    \
+            if (e < (int)total) { const uint2 c = lst[e]; cv[r] = ((uint64_t)canon_key(__uint_as_float(c.x)) << 32) | c.y; } \
+        }                                                                                     \
+        blocked_bitonic_sort<uint64_t, PER>(cv, cand);                                        \
+        __syncthreads();                                                                      \
+        _Pragma("unroll") for (int r = 0; r < PER; r++) if (tid * PER + r < k) cand[tid * PER + r] = cv[r]; \
+        __syncthreads();                                                                      \
+    }
+        if (total <= TK_THREADS) TK_SORT_LIST(1)
+        else if (total <= 2 * TK_THREADS) TK_SORT_LIST(2)
+        else if (total <= 4 * TK_THREADS) TK_SORT_LIST(4)
+        else if (total <= 8 * TK_THREADS) TK_SORT_LIST(8)
+        else TK_SORT_LIST(16)
+#undef TK_SORT_LIST
+        for (int r = tid; r < k; r += TK_THREADS) {
+            const uint64_t c = cand[r];
+            out_d[row * k + r] = key_to_float((uint32_t)(c >> 32));
+            out_i[row * k + r] = (int32_t)(col_offset + (int64_t)(uint32_t)c);
+        }
+    }
+}
+
+// Exact path for flagged queries: the query's whole distance row, recomputed with the canonical FMA chain on the vector
+// ALU (fmaf over k ascending, restarted per K-block, block sums added in order: what the MFMA tiles compute), into this
+// workgroup's scratch row; then the radix select of topk_rows_kernel on it.
+template <int METRIC>
+__global__ __launch_bounds__(TK_THREADS) void topk_fallback_kernel(const float *__restrict__ queries, int64_t ldq, const float *__restrict__ gallery,
+                                                                   int64_t ldg, const float *__restrict__ sqq, const float *__restrict__ sqg,
+                                                                   int64_t Q, int N, int D, KBlocks kbs, int64_t col_offset, int k, int P,
+                                                                   float *__restrict__ scratch, float *__restrict__ out_d,
+                                                                   int32_t *__restrict__ out_i)
+{
+    extern __shared__ __attribute__((aligned(16))) uint64_t tk_lds64[];
+    float *drow = scratch + (int64_t)blockIdx.x * N;
+    for (int64_t row = blockIdx.x; row < Q; row += gridDim.x) {
+        if (out_i[row * k] != TK_REDO) continue;       // uniform per workgroup
+        const float *qv = queries + row * ldq;
+        const float sq_q = METRIC == SE_METRIC_EUCLID ? sqq[row] : 0.f;
+        for (int c = threadIdx.x; c < N; c += TK_THREADS) {
+            const float *g = gallery + (int64_t)c * ldg;
+            float tot = 0.f;
+            int beg = 0;
+            for (int kb = 0; kb < kbs.n; kb++) {
+                float acc = 0.f;
+                for (int kk = beg; kk < beg + kbs.len[kb]; kk++) acc = __builtin_fmaf(g[kk], qv[kk], acc);
+                tot = kb == 0 ? acc : tot + acc;
+                beg += kbs.len[kb];
+            }
+            float v;
+            if (METRIC == SE_METRIC_COSINE) v = -tot;
+            else v = (sqg[c] + sq_q) - 2.0f * tot;
+            drow[c] = v;
+        }
+        __syncthreads();     // (global writes of this workgroup are visible to it after the barrier)
+        topk_select_row(drow, N, col_offset, k, P, out_d + row * k, out_i + row * k, tk_lds64);
+        __syncthreads();
+    }
+}
+
+}  // namespace se
+
+using namespace se;
+
+static int64_t align256(int64_t v) { return (v + 255) / 256 * 256; }
+
+// slab path: query rows per [rows, n] distance slab of <= 2 GiB
 static int64_t topk_qtile(int64_t q, int64_t n)
 {
-    // keep the slab <= 2 GiB and a multiple of 128 rows
     int64_t rows = ((int64_t)2 << 30) / (n * 4);
     rows = rows / 128 * 128;
     if (rows < 128) rows = 128;
@@ -427,31 +660,118 @@ static int64_t topk_qtile(int64_t q, int64_t n)
     return rows;
 }
 
-extern "C" int64_t se_retrieve_topk_workspace_bytes(int64_t q, int64_t n, int k)
+// fused path: query rows per pass (candidate lists + group minima of <= 4 GiB) and the workspace layout
+struct FusedLayout {
+    int64_t qt, off_tau, off_cnt, off_gm, off_lists, off_scratch, total;
+};
+static FusedLayout fused_layout(int64_t q, int64_t n, const FusedPlan &p)
 {
-    (void)k;
+    FusedLayout L;
+    const int64_t per_row = (int64_t)p.cap * 8 + (int64_t)p.G * 4 + 8;
+    int64_t qt = ((int64_t)4 << 30) / per_row / 128 * 128;
+    if (qt < 128) qt = 128;
+    if (qt > q) qt = q;
+    L.qt = qt;
+    L.off_tau = 0;
+    L.off_cnt = align256(qt * 4);
+    L.off_gm = L.off_cnt + align256(qt * 4);
+    L.off_lists = L.off_gm + align256(qt * p.G * 4);
+    L.off_scratch = L.off_lists + align256(qt * p.cap * 8);
+    L.total = L.off_scratch + align256((int64_t)FB_GRID * n * 4);
+    return L;
+}
+
+extern "C" int64_t se_retrieve_topk_workspace_bytes(int64_t q, int64_t n, int64_t ldg, int k)
+{
     if (q <= 0 || n <= 0) return 0;
+    const FusedPlan p = fused_plan(n, ldg, k);
+    if (p.ok) return fused_layout(q, n, p).total;
     return topk_qtile(q, n) * n * 4;
 }
 
 extern "C" int se_retrieve_topk(const float *queries, int64_t ldq, const float *gallery, int64_t ldg,
                                 const float *sqq, const float *sqg, int64_t q, int64_t n, int64_t d,
-                                int metric, int64_t col_offset, int k, float *out_d, int32_t *out_i,
-                                void *workspace, int64_t workspace_bytes, se_stream_t stream)
+                                int metric, const int32_t *kblocks, int nkb, int64_t col_offset, int k,
+                                float *out_d, int32_t *out_i, void *workspace, int64_t workspace_bytes, se_stream_t stream)
 {
-    if (q < 0 || n <= 0 || d <= 0) return fail(SE_ERR_INVALID, "se_retrieve_topk: bad shape");
+    if (q < 0 || n <= 0 || d <= 0 || n > 0x7FFFFFFFll) return fail(SE_ERR_INVALID, "se_retrieve_topk: bad shape");
+    if (k < 1 || k > SE_TOPK_MAX || k > n) return fail(SE_ERR_INVALID, "se_retrieve_topk: need 1 <= k <= min(n, %d), got k=%d n=%lld", SE_TOPK_MAX, k, (long long)n);
     if (q == 0) return SE_OK;
-    const int64_t need = se_retrieve_topk_workspace_bytes(q, n, k);
+    if (!queries || !gallery || !out_d || !out_i || ldq < d || ldg < d) return fail(SE_ERR_INVALID, "se_retrieve_topk: bad argument");
+    if (metric != SE_METRIC_COSINE && metric != SE_METRIC_EUCLID) return fail(SE_ERR_INVALID, "se_retrieve_topk: metric must be SE_METRIC_COSINE or SE_METRIC_EUCLID");
+    if (metric == SE_METRIC_EUCLID && (!sqq || !sqg)) return fail(SE_ERR_INVALID, "se_retrieve_topk: SE_METRIC_EUCLID needs sqq and sqg");
+    KBlocks kbs;
+    bool multi = false;
+    if (const int rc = make_kblocks("se_retrieve_topk", kblocks, nkb, d, kbs, multi)) return rc;
+    const int64_t need = se_retrieve_topk_workspace_bytes(q, n, ldg, k);
     if (!workspace || workspace_bytes < need) return fail(SE_ERR_WORKSPACE, "se_retrieve_topk: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)need);
-    const int64_t qt = topk_qtile(q, n);
-    float *slab = (float *)workspace;
-    for (int64_t q0 = 0; q0 < q; q0 += qt) {
-        const int64_t rows = (q - q0 < qt) ? (q - q0) : qt;
-        int rc = se_pairwise_dist(queries + q0 * ldq, ldq, gallery, ldg, sqq ? sqq + q0 : nullptr, sqg, rows, n, d,
-                                  metric, nullptr, 0, slab, n, stream);
+    hipStream_t s = (hipStream_t)stream;
+    const FusedPlan p = fused_plan(n, ldg, k);
+
+    if (!p.ok) {   // ---- small problems: [rows, n] distance slab -> se_topk_rows, query tile by query tile ----
+        const int64_t qt = topk_qtile(q, n);
+        float *slab = (float *)workspace;
+        for (int64_t q0 = 0; q0 < q; q0 += qt) {
+            const int64_t rows = (q - q0 < qt) ? (q - q0) : qt;
+            int rc = se_pairwise_dist(queries + q0 * ldq, ldq, gallery, ldg, sqq ? sqq + q0 : nullptr, sqg, rows, n, d,
+                                      metric, multi ? kblocks : nullptr, multi ? nkb : 0, slab, n, stream);
+            if (rc != SE_OK) return rc;
+            rc = se_topk_rows(slab, n, rows, n, col_offset, k, out_d + q0 * k, out_i + q0 * k, stream);
+            if (rc != SE_OK) return rc;
+        }
+        return SE_OK;
+    }
+
+    // ---- fused path ----
+    const FusedLayout L = fused_layout(q, n, p);
+    char *ws = (char *)workspace;
+    float *tau = (float *)(ws + L.off_tau);
+    unsigned *rowcnt = (unsigned *)(ws + L.off_cnt);
+    float *gm = (float *)(ws + L.off_gm);
+    uint2 *lists = (uint2 *)(ws + L.off_lists);
+    float *scratch = (float *)(ws + L.off_scratch);
+    int PER = 1;
+    while (PER * TK_THREADS < p.cap) PER <<= 1;
+    const size_t lds_lists = (size_t)PER * TK_THREADS * 8;
+    const int P = next_pow2(k);
+    const size_t lds_sel = (size_t)P * 8 + (TK_NB + TK_WAVES + 1 + 4) * sizeof(uint32_t);
+    SE_HIP_CHECK(hipFuncSetAttribute((const void *)topk_lists_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_lists));
+    for (int64_t q0 = 0; q0 < q; q0 += L.qt) {
+        const int64_t rows = (q - q0 < L.qt) ? (q - q0) : L.qt;
+        const float *qs = queries + q0 * ldq;
+        const float *sq = sqq ? sqq + q0 : nullptr;
+        SE_HIP_CHECK(hipMemsetAsync(rowcnt, 0, (size_t)rows * 4, s));
+        FusedArgs fa = {gm, p.G, tau, rowcnt, lists, p.cap, p.step};
+        int rc = launch_fused_pass(EPI_GROUPMIN, gallery, p.step * ldg, qs, ldq, sqg, sq, p.S, rows, d, metric, kbs, multi, fa, s);
         if (rc != SE_OK) return rc;
-        rc = se_topk_rows(slab, n, rows, n, col_offset, k, out_d + q0 * k, out_i + q0 * k, stream);
+        hipLaunchKernelGGL(topk_tau_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, gm, (int64_t)p.G, rows, p.G, p.j, tau);
+        SE_LAUNCH_CHECK();
+        fa.sqa_stride = 1;
+        rc = launch_fused_pass(EPI_FILTER, gallery, ldg, qs, ldq, sqg, sq, n, rows, d, metric, kbs, multi, fa, s);
         if (rc != SE_OK) return rc;
+        const int64_t grid = rows < 2048 ? rows : 2048;
+        hipLaunchKernelGGL(topk_lists_kernel, dim3((unsigned)grid), dim3(TK_THREADS), lds_lists, s, lists, rowcnt, (int64_t)p.cap, rows,
+                           col_offset, k, out_d + q0 * k, out_i + q0 * k);
+        SE_LAUNCH_CHECK();
+        if (kTuning && tuning_env("SE_TOPK_VERBOSE")) {   // -DSE_TUNING build only: synchronises and reports how the lists came out
+            SE_HIP_CHECK(hipStreamSynchronize(s));
+            unsigned *h = (unsigned *)malloc((size_t)rows * 4);
+            SE_HIP_CHECK(hipMemcpy(h, rowcnt, (size_t)rows * 4, hipMemcpyDeviceToHost));
+            int64_t flagged = 0;
+            double sum = 0;
+            for (int64_t i = 0; i < rows; i++) { flagged += (h[i] < (unsigned)k || h[i] > (unsigned)p.cap); sum += h[i]; }
+            free(h);
+            fprintf(stderr, "[se_retrieve_topk] fused: n=%lld k=%d S=%d step=%lld G=%d j=%d cap=%d rows=%lld flagged=%lld mean_candidates=%.1f\n",
+                    (long long)n, k, p.S, (long long)p.step, p.G, p.j, p.cap, (long long)rows, (long long)flagged, sum / (double)rows);
+        }
+        const int64_t fgrid = rows < FB_GRID ? rows : FB_GRID;
+        if (metric == SE_METRIC_COSINE)
+            hipLaunchKernelGGL(topk_fallback_kernel<SE_METRIC_COSINE>, dim3((unsigned)fgrid), dim3(TK_THREADS), lds_sel, s, qs, ldq, gallery, ldg, sq, sqg,
+                               rows, (int)n, (int)d, kbs, col_offset, k, P, scratch, out_d + q0 * k, out_i + q0 * k);
+        else
+            hipLaunchKernelGGL(topk_fallback_kernel<SE_METRIC_EUCLID>, dim3((unsigned)fgrid), dim3(TK_THREADS), lds_sel, s, qs, ldq, gallery, ldg, sq, sqg,
+                               rows, (int)n, (int)d, kbs, col_offset, k, P, scratch, out_d + q0 * k, out_i + q0 * k);
+        SE_LAUNCH_CHECK();
     }
     return SE_OK;
 }

@@ -79,6 +79,7 @@ class FlatState(object):
             self.offsets.append((off, n))
             off += n
         self.total = total
+        self.frozen_l2 = [(p, float(l2_of[id(p)])) for p in model.parameters() if not p.requires_grad and l2_of.get(id(p), 0.0)]
         self.has_l2 = bool((self.flat_l2 != 0).any().item())
         self.all_contiguous = all(p.is_contiguous() for p in params)
 
@@ -237,7 +238,7 @@ class Trainer(object):
 
     # ---------------------------------------------------------------- HIP-graph replay of the step
 
-    def enable_graphs(self, X, y, warmup=3, validate=4, tol=2e-3):
+    def enable_graphs(self, X, y, warmup=3, validate=4, tol=2e-3, max_noise=0.05):
         """Capture the training step into two HIP graphs (``torch.cuda.CUDAGraph``): A = zero grads + forward + fused
         loss/metric + backward, B = the whole-buffer SGD update; the RCCL all-reduce of the flat gradient buffer stays
         an eager call between them (one message per step), so 1-GPU and N-GPU runs replay identical graphs.
@@ -246,11 +247,18 @@ class Trainer(object):
 
         The model's state is untouched: parameters, velocity and BatchNorm buffers are snapshotted before the warm-up
         steps the capture needs (MIOpen / hipBLASLt algorithm searches) and restored afterwards.  Graph A is then
-        **validated**: ``validate`` replays must reproduce the eager gradient of the same batch (relative L2 error
-        below ``tol``, all finite).  On torch 2.10 + ROCm 7.0 the replayed bf16-autocast backward of these backbones
-        turns non-finite within a few replays (tools/graph_variants.py; fp32 replays are clean), which this check
-        catches: the trainer then stays eager, says so, and returns False."""
+        **validated**: ``validate`` replays must reproduce the eager gradient of the same batch -- relative L2 error and
+        norm ratio within ``max(tol, 2 x the eager step's own run-to-run spread)``, capped at ``2 max_noise``; the loss within
+        1e-3; everything finite.  A step whose eager gradients already differ by more than ``max_noise`` between two runs
+        cannot be validated and stays eager.  fp32 steps only (bf16-autocast replays are not offered).
+        On failure the trainer stays eager, says so, and returns False."""
         if not X.is_cuda:
+            return False
+        if self.autocast_dtype is not None:
+            # bf16-autocast replays of these backbones return non-finite conv-bias gradients inside this trainer's flat-buffer layout
+            # (DESIGN.md section 7.1; root cause not found) and would save nothing (the bf16 ResNet-50 step is GPU-bound in eager mode):
+            # the mode is not offered.
+            print('[engine] HIP-graph replay is offered for fp32 steps only; staying eager', flush=True)
             return False
         ys = y if isinstance(y, (tuple, list)) else (y,)
         hooks_were = self.reducer.enabled
@@ -300,18 +308,23 @@ class Trainer(object):
                 noise = float(torch.linalg.vector_norm(self.flat.flat_g - ref)) / max(ref_norm, 1e-30)
                 eager_loss = float(eager_logs['loss']) / max(float(eager_logs.get('_n', 1)), 1.0) if 'loss' in eager_logs else float(self._g_loss)
                 self.graph_validation = {'eager_noise': noise, 'replay_error': []}
+                if not noise < max_noise:
+                    # two eager gradients of the same batch differ by more than `max_noise` (relative L2): no tolerance derived from
+                    # that spread could tell a right replay from a wrong one (two unrelated gradients of equal norm differ by 1.41)
+                    raise RuntimeError('eager gradients of one batch differ by %g between two runs: a replay cannot be validated' % noise)
+                bound = min(max(tol, 2.0 * noise), 2.0 * max_noise)
                 for r in range(validate):
                     ga.replay()
                     g = self.flat.flat_g
                     err = float(torch.linalg.vector_norm(g - ref)) / max(ref_norm, 1e-30)
                     ratio = float(torch.linalg.vector_norm(g)) / max(ref_norm, 1e-30)
                     self.graph_validation['replay_error'].append(err)
-                    ok = (err < max(tol, 2.0 * noise)) and (abs(ratio - 1.0) < max(0.05, noise)) and bool(torch.isfinite(g).all()) \
-                        and bool(torch.isfinite(self._g_loss)) and abs(float(self._g_loss) - eager_loss) < 0.05 * max(1.0, abs(eager_loss))
+                    ok = (err < bound) and (abs(ratio - 1.0) < bound) and bool(torch.isfinite(g).all()) \
+                        and bool(torch.isfinite(self._g_loss)) and abs(float(self._g_loss) - eager_loss) < 1e-3 * max(1.0, abs(eager_loss))
                     if not ok:      # (NaN compares False)
-                        raise RuntimeError('replay %d of the captured step does not reproduce the eager gradient (relative L2 error %g '
-                                           'vs %g between two eager steps, norm ratio %g, loss %g vs %g)'
-                                           % (r, err, noise, ratio, float(self._g_loss), eager_loss))
+                        raise RuntimeError('replay %d of the captured step does not reproduce the eager gradient (relative L2 error %g, '
+                                           'bound %g; %g between two eager steps; norm ratio %g, loss %g vs %g)'
+                                           % (r, err, bound, noise, ratio, float(self._g_loss), eager_loss))
             restore()
             graphs, why = (ga, gb), None
         except Exception as e:
@@ -387,8 +400,9 @@ class Trainer(object):
         self._graph_steps += 1
         for k, v in self._g_logs.items():      # static device scalars written by graph A (sums over the batch) and its row count
             logs[k] = logs.get(k, 0) + (v.clone() if torch.is_tensor(v) else v)
-        if self._graph_steps % 256 == 0 and not bool(torch.isfinite(self._g_loss)):     # one host sync per 256 steps
-            raise FloatingPointError('non-finite loss in HIP-graph replay %d (diverged training, or a replay fault: '
+        if self._graph_steps % 256 == 0 and not (bool(torch.isfinite(self._g_loss)) and bool(torch.isfinite(self.flat.flat_p).all())):
+            # one host sync per 256 steps.  Weights and loss are checked (the gradient buffer was already consumed by graph B).
+            raise FloatingPointError('non-finite loss / weights in HIP-graph replay %d (diverged training, or a replay fault: '
                                      'rerun with SE_TRAIN_GRAPHS=0 to tell)' % self._graph_steps)
         return self._g_loss
 
@@ -428,9 +442,12 @@ class Trainer(object):
         """Sum of the L2 kernel penalties (``lam * |w|^2``) at the current weights -- Keras adds them to every reported ``loss`` /
         ``val_loss`` (what ReduceLROnPlateau and --snapshot_best observe)."""
         flat = self.flat
-        if not flat.has_l2:
-            return 0.0
-        return float(0.5 * torch.dot(flat.flat_l2, flat.flat_p * flat.flat_p))     # flat_l2 holds 2 lam
+        reg = 0.0
+        if flat.has_l2:
+            reg += float(0.5 * torch.dot(flat.flat_l2, flat.flat_p * flat.flat_p))     # flat_l2 holds 2 lam
+        for p, lam in flat.frozen_l2:      # layers frozen by --finetune_init keep their regularisers in Keras' loss
+            reg += lam * float((p.detach().float() ** 2).sum())
+        return reg
 
     def _reduce_logs(self, logs, n=None):
         """Per-sample means of the accumulated sums (``logs['_n']`` samples on this rank), summed over the ranks: every sample
@@ -485,7 +502,7 @@ class Trainer(object):
         # steps are replayed as HIP graphs unless SE_TRAIN_GRAPHS=0; a capture that fails its validation against the eager
         # gradient (enable_graphs) leaves the trainer eager and says so
         if (not self._graph_tried and len(train_seq) > 0 and os.environ.get('SE_TRAIN_GRAPHS', '1') != '0'
-                and (self.autocast_dtype is None or os.environ.get('SE_TRAIN_BF16_GRAPHS', '1') != '0')):
+                and self.autocast_dtype is None):
             self._graph_tried = True
             X0, y0 = train_seq[0]
             if X0.is_cuda:

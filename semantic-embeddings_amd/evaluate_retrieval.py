@@ -75,8 +75,16 @@ def host_blas_kblocks(d, q=448):
     return out
 
 
-def _resolve_kblocks(kblocks, d):
+def _resolve_kblocks(kblocks, d, warn=True):
+    if kblocks is not None and not isinstance(kblocks, str) and len(kblocks) == 0:
+        return None            # "already resolved to a single chain" (pairwise_retrieval -> ranking_tiles): no second warning
     if kblocks is None:
+        if warn and d > 448:
+            import warnings
+            warnings.warn("D = {} > 448: the reference's np.dot (evaluate_retrieval.py:59,62) restarts its float32 FMA chain per BLAS "
+                          "K block; with kblocks=None distances come from ONE chain and near-tie orders can differ from the "
+                          "reference's.  Pass kblocks='openblas' (CLI: --kblocks openblas) for bit-identical rankings."
+                          .format(d), stacklevel=3)
         return None
     if isinstance(kblocks, str):
         if kblocks.lower() != 'openblas':
@@ -88,12 +96,14 @@ def _resolve_kblocks(kblocks, d):
     return kblocks if len(kblocks) > 1 else None
 
 
-def ranking_tiles(features, normalize=False, tile_rows=None, idx64=False, queries=None, kblocks=None, whole_if_fits=False):
+def ranking_tiles(features, normalize=False, tile_rows=None, idx64=False, queries=None, kblocks=None, whole_if_fits=False,
+                  prenormalized=False):
     """Generator over ``(first_row, rank_tile)`` with ``rank_tile`` an int32 (int64 if ``idx64``)
     DEVICE tensor ``[rows, N]``: the canonical ranking of queries ``first_row .. first_row+rows``.
 
     ``features`` must already be a float32 device tensor ``[N, D]``; it is normalised in place when
     ``normalize`` is set (like the reference mutates its input, evaluate_retrieval.py:58).
+    (``prenormalized``: the caller already did that -- normalising twice would change bits.)
     ``queries`` optionally restricts the query rows to ``range(*queries)``; ``kblocks`` (None | 'openblas' | list) makes
     the FMA chain restart per K block like the host BLAS the reference ran on (see ``host_blas_kblocks``).
     ``whole_if_fits``: rank all queries as ONE tile when distances + ranks (8 N^2 bytes) fit into a third of the free device
@@ -106,7 +116,8 @@ def ranking_tiles(features, normalize=False, tile_rows=None, idx64=False, querie
     n, _ = features.shape
     kblocks = _resolve_kblocks(kblocks, features.shape[1])
     if normalize:
-        sehip.normalize_rows_(features)
+        if not prenormalized:
+            sehip.normalize_rows_(features)
         metric, sq = sehip.METRIC_COSINE, None
     else:
         metric, sq = sehip.METRIC_EUCLID, sehip.row_sqnorm(features)
@@ -143,14 +154,16 @@ def pairwise_retrieval(features, normalize=False, return_generator=True, kblocks
     feats_h = np.ascontiguousarray(features, dtype=np.float32)
     sehip._lib.require_gpu()
     dev = torch.from_numpy(feats_h).cuda()
+    kblocks = _resolve_kblocks(kblocks, feats_h.shape[1])
+    if normalize:
+        # like the reference (`features /= np.linalg.norm(...)`, evaluate_retrieval.py:58) the caller's array is normalised
+        # in place at CALL time, before the first ranking is drawn from the generator
+        sehip.normalize_rows_(dev)
+        if not owned and isinstance(features, np.ndarray) and features.dtype == np.float32:
+            np.copyto(features, dev.cpu().numpy())
 
     def gen():
-        first = True
-        for r0, tile in ranking_tiles(dev, normalize, kblocks=kblocks):
-            if first and normalize and not owned and isinstance(features, np.ndarray) and features.dtype == np.float32:
-                # the reference normalises the caller's array in place (`features /= ...`)
-                np.copyto(features, dev.cpu().numpy())
-            first = False
+        for r0, tile in ranking_tiles(dev, normalize, kblocks=kblocks or (), prenormalized=True):
             ranks = tile.cpu().numpy()
             for i in range(ranks.shape[0]):
                 ret = ranks[i]

@@ -221,11 +221,15 @@ class _DeviseLoss(torch.autograd.Function):
         require_gpu(y_pred, target, embedding)
         yp = _rows(y_pred.to(torch.float32), "y_pred")
         yp = yp if yp.stride(1) == 1 else yp.contiguous()
-        _rows(embedding, "embedding")
+        _f32_rows(embedding, "embedding")
         B, D = yp.shape
         C = embedding.shape[0]
+        if embedding.shape[1] != D or embedding.device != yp.device:
+            raise SehipError("embedding must be a float32 [C, %d] tensor on %s" % (D, yp.device))
         if target.dim() == 1 and not target.is_floating_point():
             labels, yt, ldt = target.long().contiguous(), None, 0
+            if labels.numel() != B:
+                raise SehipError("labels must be an integer [B] tensor")
         else:
             labels, yt = None, _rows(target.to(torch.float32).contiguous(), "y_true")
             ldt = yt.stride(0)
@@ -296,10 +300,7 @@ def pairwise_dist(a, b=None, metric=METRIC_COSINE, sqa=None, sqb=None, kblocks=N
             sqb = sqa if b is a else row_sqnorm(b)
     if out is None:
         out = torch.empty((q, n), dtype=torch.float32, device=a.device)
-    kb, nkb = None, 0
-    if kblocks is not None and len(kblocks) > 1:
-        kb = (ctypes.c_int32 * len(kblocks))(*[int(v) for v in kblocks])
-        nkb = len(kblocks)
+    kb, nkb = _kblocks_arg(kblocks)
     check(lib().se_pairwise_dist(ptr(a), a.stride(0), ptr(b), b.stride(0), ptr(sqa), ptr(sqb), q, n, d, int(metric),
                                  kb, nkb, ptr(out), out.stride(0), stream_ptr()), "se_pairwise_dist")
     return out
@@ -357,21 +358,31 @@ def topk_merge(d, idx):
     return od, oi
 
 
-def retrieve_topk(queries, gallery, k, metric=METRIC_COSINE, col_offset=0, sqq=None, sqg=None):
-    """Distances + top-k without materialising the full [q, n] matrix (query tiles of <= 2 GiB)."""
-    require_gpu(queries, gallery)
+def _kblocks_arg(kblocks):
+    if kblocks is None or len(kblocks) <= 1:
+        return None, 0
+    return (ctypes.c_int32 * len(kblocks))(*[int(v) for v in kblocks]), len(kblocks)
+
+
+def retrieve_topk(queries, gallery, k, metric=METRIC_COSINE, col_offset=0, sqq=None, sqg=None, kblocks=None):
+    """Fused distances + top-k (``se_retrieve_topk``): the first k entries of every query's canonical ranking against ``gallery``
+    without the [q, n] matrix; ``kblocks`` = the BLAS K-block list of ``pairwise_dist`` (D > 448)."""
+    require_gpu(queries, gallery, sqq, sqg)
     _f32_rows(queries, "queries"); _f32_rows(gallery, "gallery")
     q, d = queries.shape
     n = gallery.shape[0]
+    if gallery.shape[1] != d:
+        raise SehipError("queries and gallery must have the same number of columns")
     if metric == METRIC_EUCLID:
         sqq = row_sqnorm(queries) if sqq is None else sqq
         sqg = row_sqnorm(gallery) if sqg is None else sqg
     od = torch.empty((q, k), dtype=torch.float32, device=queries.device)
     oi = torch.empty((q, k), dtype=torch.int32, device=queries.device)
-    need = lib().se_retrieve_topk_workspace_bytes(q, n, int(k))
+    need = lib().se_retrieve_topk_workspace_bytes(q, n, gallery.stride(0), int(k))
     ws = _workspace(need, queries.device)
+    kb, nkb = _kblocks_arg(kblocks)
     check(lib().se_retrieve_topk(ptr(queries), queries.stride(0), ptr(gallery), gallery.stride(0), ptr(sqq), ptr(sqg),
-                                 q, n, d, int(metric), int(col_offset), int(k), ptr(od), ptr(oi), ptr(ws), ws.numel(),
+                                 q, n, d, int(metric), kb, nkb, int(col_offset), int(k), ptr(od), ptr(oi), ptr(ws), ws.numel(),
                                  stream_ptr()), "se_retrieve_topk")
     return od, oi
 

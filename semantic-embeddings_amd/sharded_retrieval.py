@@ -24,20 +24,26 @@ def shard_bounds(n, world):
     return bounds
 
 
-def sharded_topk(queries, gallery_shard, k, shard_offset, metric=None, group=None, local_topk=None, merge=None):
+def sharded_topk(queries, gallery_shard, k, shard_offset, metric=None, group=None, local_topk=None, merge=None, kblocks=None):
     """Global top-k of ``queries`` against the gallery whose local shard is ``gallery_shard``.
 
     Returns ``(dist [Q, k] f32, idx [Q, k] i32)`` identical on every rank.  ``local_topk`` /
     ``merge`` default to the HIP kernels (``sehip.retrieve_topk`` / ``sehip.topk_merge``); tests
-    inject CPU stand-ins to exercise the collective logic under gloo."""
+    inject CPU stand-ins to exercise the collective logic under gloo.  ``kblocks``: the BLAS K-block
+    list of the distance arithmetic (D > 448, see ``evaluate_retrieval.host_blas_kblocks``); it reaches
+    every rank's local kernel (and an injected ``local_topk`` as its fifth argument) so that the sharded
+    result equals the single-process one bit for bit."""
     if local_topk is None or merge is None:
         import sehip
         metric = sehip.METRIC_COSINE if metric is None else metric
-        local_topk = local_topk or (lambda q, g, kk, off: sehip.retrieve_topk(q, g, kk, metric=metric, col_offset=off))
+        local_topk = local_topk or (lambda q, g, kk, off, kb=None: sehip.retrieve_topk(q, g, kk, metric=metric, col_offset=off, kblocks=kb))
         merge = merge or sehip.topk_merge
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     k_local = min(k, gallery_shard.shape[0])
-    d, i = local_topk(queries, gallery_shard, k_local, shard_offset)
+    if kblocks is not None and len(kblocks) > 1:
+        d, i = local_topk(queries, gallery_shard, k_local, shard_offset, list(kblocks))
+    else:
+        d, i = local_topk(queries, gallery_shard, k_local, shard_offset)
     if k_local < k:   # tiny shard: pad with +inf so every rank contributes [Q, k]
         pad = k - k_local
         d = torch.cat([d, torch.full((d.shape[0], pad), float('inf'), dtype=d.dtype, device=d.device)], dim=1)

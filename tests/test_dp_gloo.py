@@ -106,6 +106,74 @@ def test_sharded_gallery_topk_equals_unsharded(tmp_path):
     assert np.array_equal(g["d"], wd)
 
 
+def _topk_kblocks_worker(rank, world, port, out):
+    """Sharded-gallery top-k on a D = 1000 problem WITH the BLAS K-block list (BASELINE configs[4] is D = 1000): the list
+    must reach every rank's local kernel, otherwise near-tie orders differ from the single-process / reference result."""
+    _setup(rank, world, port)
+    import sharded_retrieval as sr
+    from oracle import retrieval_oracle as ro
+    feat, norm, kb, head = ro.load_topk_fixture(os.path.join(ROOT, "tests", "golden", "topk_head_d1000_cos.npz"))
+    x = ro.canon_normalize_rows(feat)
+    lo, hi = sr.shard_bounds(len(x), world)[rank]
+    seen = []
+
+    def local_topk(q, g, k, off, kblocks=None):   # CPU stand-in for sehip.retrieve_topk(..., kblocks=)
+        seen.append(kblocks)
+        d, i = ro.canon_topk_rows(ro.canon_pdist(q.numpy(), g.numpy(), ro.METRIC_COSINE, kblocks=kblocks), k, col_offset=off)
+        return torch.from_numpy(d), torch.from_numpy(i)
+
+    def merge(d, i):
+        md, mi = ro.canon_topk_merge(d.numpy(), i.numpy())
+        return torch.from_numpy(md), torch.from_numpy(mi)
+
+    d, i = sr.sharded_topk(torch.from_numpy(x), torch.from_numpy(x[lo:hi]), 251, lo, local_topk=local_topk, merge=merge, kblocks=kb)
+    assert seen == [kb]
+    if rank == 0:
+        np.savez(out, d=d.numpy(), i=i.numpy())
+    dist.destroy_process_group()
+
+
+def test_sharded_gallery_topk_with_kblocks_equals_single_process_and_reference(tmp_path):
+    from oracle import retrieval_oracle as ro
+    out = str(tmp_path / "topk_kb.npz")
+    mp.spawn(_topk_kblocks_worker, args=(2, 29621, out), nprocs=2, join=True)
+    got = np.load(out)
+    feat, norm, kb, head = ro.load_topk_fixture(os.path.join(ROOT, "tests", "golden", "topk_head_d1000_cos.npz"))
+    pd = ro.canon_pdist(ro.canon_normalize_rows(feat), None, ro.METRIC_COSINE, kblocks=kb)
+    wd, wi = ro.canon_topk_rows(pd, 251)
+    assert np.array_equal(got["i"], wi) and np.array_equal(got["d"], wd)          # == one process with the same K-blocks
+    for r in np.nonzero((got["i"] != head[:, :251]).any(axis=1))[0]:                # == the reference's head outside exact ties
+        assert np.array_equal(pd[r][got["i"][r]], pd[r][head[r, :251]]), r
+    # without the list the arithmetic is a different one on this fixture (this is what used to be dropped silently)
+    _, wi1 = ro.canon_topk_rows(ro.canon_pdist(ro.canon_normalize_rows(feat), None, ro.METRIC_COSINE), 251)
+    assert not np.array_equal(wi1, wi)
+
+
+def test_hierarchical_precision_device_hands_kblocks_to_the_topk_path():
+    """`hierarchical_precision_device(..., kblocks=...)` with head-only metrics takes the top-L path and must pass the
+    K-block list on (it used to drop it whenever world > 1)."""
+    from class_hierarchy import ClassHierarchy
+    g = np.load(os.path.join(ROOT, "tests", "golden", "hierarchy_cifar.npz"))
+    parents, children = {}, {}
+    for p, c in g["edges"].tolist():
+        parents.setdefault(c, []).append(p)
+        children.setdefault(p, []).append(c)
+    hier = ClassHierarchy(parents, children)
+    labels, feats = g["labels"].tolist(), g["features"]
+    kern = _cpu_kernels()
+    seen = []
+    inner = kern["local_topk"]
+
+    def local_topk(q, g_, k, off, kblocks=None):
+        seen.append(kblocks)
+        return inner(q, g_, k, off)
+    kern["local_topk"] = local_topk
+    d = feats.shape[1]
+    hier.hierarchical_precision_device(feats.copy(), labels, [1, 10], compute_ahp=50, compute_ap=False, normalize=True,
+                                       kernels=kern, kblocks=[d - 40, 40])
+    assert seen == [[d - 40, 40]]
+
+
 def test_shard_bounds_cover_everything():
     import sharded_retrieval as sr
     for n, w in ((10, 3), (1281167, 8), (5, 8)):

@@ -311,3 +311,22 @@ def test_imagenet_mintree_embedding_fixture():
     assert np.abs(np.triu(E, 1)).max() == 0
     S = E @ E.T
     assert S.min() > -1e-6 and S.max() < 1 + 1e-6
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "topk_head_*.npz"))))
+def test_canonical_topk_reproduces_reference_heads_beyond_448(path):
+    """tests/golden/topk_head_*.npz: the first 256 entries of the imported reference's rankings
+    (evaluate_retrieval.py:57-67) on 640-item D = 555 / D = 1000 problems.  The oracle's top-251 with the fixture's
+    K-block list equals them outside exact-tie groups; the single-chain arithmetic does not (which is why the top-k /
+    sharded-gallery path has to carry the list)."""
+    feat, norm, kb, head = ro.load_topk_fixture(path)
+    x = ro.canon_normalize_rows(feat) if norm else feat
+    metric = ro.METRIC_COSINE if norm else ro.METRIC_EUCLID
+    pd = ro.canon_pdist(x, None, metric, kblocks=kb)
+    d, i = ro.canon_topk_rows(pd, 251)
+    assert np.array_equal(i, ro.canon_rank_rows(pd)[:, :251])
+    for r in np.nonzero((i != head[:, :251]).any(axis=1))[0]:
+        assert np.array_equal(pd[r][i[r]], pd[r][head[r, :251]]), "row %d differs outside a tie group" % r
+    pd1 = ro.canon_pdist(x, None, metric)
+    _, i1 = ro.canon_topk_rows(pd1, 251)
+    assert any(not np.array_equal(pd[r][i1[r]], pd[r][head[r, :251]]) for r in range(len(x)))

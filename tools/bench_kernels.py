@@ -27,7 +27,7 @@ def timeit(fn, reps):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["pdist", "rank", "loss", "topk", "hprec", "shard"])
+    ap.add_argument("what", choices=["pdist", "rank", "loss", "topk", "fused", "hprec", "shard"])
     ap.add_argument("--hp-mode", default="all", choices=["all", "whole", "sweep"], help="hprec: every configuration, or whole-list AHP + AP in class order only (profiling)")
     ap.add_argument("--n", type=int, default=50000)
     ap.add_argument("--q", type=int, default=None)
@@ -105,6 +105,13 @@ def main():
         dd = torch.stack([od + 1e-3 * r for r in range(8)]); ii = torch.stack([oi + NS * r for r in range(8)])
         med, mn = timeit(lambda: sehip.topk_merge(dd, ii), args.reps)
         print("topk_merge parts=8 q=%d k=%d: median %.3f ms  (all-gather payload %.1f MB per rank)" % (Q, K, med, Q * K * 8 / 1e6))
+    elif args.what == "fused":
+        # se_retrieve_topk, all-pairs (queries == gallery): distances + top-k with no [q, n] matrix
+        for metric, name in ((sehip.METRIC_COSINE, "cosine"), (sehip.METRIC_EUCLID, "Euclid")):
+            sq = sehip.row_sqnorm(x) if metric == sehip.METRIC_EUCLID else None
+            med, mn = timeit(lambda: sehip.retrieve_topk(x[:q], x, args.k, metric=metric, sqq=None if sq is None else sq[:q], sqg=sq), args.reps)
+            print("fused retrieve_topk %-6s q=%d n=%d d=%d k=%d: median %.3f ms (min %.3f)  %.1f Mpairs/s, %.1f TFLOP/s (fp32 MFMA), %.2f GB algorithmic" %
+                  (name, q, n, d, args.k, med, mn, q * n / med / 1e3, 2.0 * q * n * d / med / 1e9, (4.0 * (q + n) * d + 8.0 * q * args.k) / 1e9))
     elif args.what == "topk":
         pd = sehip.pairwise_dist(x[:q], x, metric=sehip.METRIC_COSINE)
         med, mn = timeit(lambda: sehip.topk_rows(pd, args.k), args.reps)

@@ -53,7 +53,7 @@ def main(variant, B=int(os.environ.get("B", "128"))):
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / 20 * 1e3
     print("%-22s capture %s  first non-finite replay %d  %.2f ms/step %.0f img/s  mean loss %.4f" % (
-        variant, ok, first_bad, ms, B / ms * 1e3, float(logs["loss"]) / 60), flush=True)
+        variant, ok, first_bad, ms, B / ms * 1e3, float(logs["loss"]) / max(float(logs.get("_n", 1)), 1.0)), flush=True)   # per-sample sums / sample count
 
 
 if __name__ == "__main__":

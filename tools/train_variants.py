@@ -53,7 +53,7 @@ def run(variant, B=int(os.environ.get("B", "128")), steps=20, warm=6):
     host = (time.perf_counter() - t0) / steps * 1e3
     torch.cuda.synchronize()
     print("%-18s %7.2f ms/step  %8.0f img/s   (host enqueue %.2f ms/step)  loss %.4f" % (variant, ms, B / ms * 1e3, host,
-          float(logs["loss"]) / (warm + 2 * steps)), flush=True)
+          float(logs["loss"]) / max(float(logs.get("_n", 1)), 1.0)), flush=True)      # logs hold per-sample sums, '_n' the sample count
 
 
 if __name__ == "__main__":
