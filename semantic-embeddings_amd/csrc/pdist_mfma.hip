@@ -156,27 +156,29 @@ __device__ __forceinline__ void pd_chunk(int c, const KBlocks &kbs, bool multi, 
 // panels from its L2 cut FETCH_SIZE 12x -- 2.7 M KB -> 0.22 M KB, the panels otherwise come from Infinity
 // Cache -- but measured SLOWER, 3.5 -> 3.7 ms: operand fetch is not what limits this kernel.)
 template <bool SYM>
-__device__ __forceinline__ void pd_tile_coords(int64_t t, int tiles_m, int tiles_n, int64_t &m0, int64_t &n0)
+__device__ __forceinline__ void pd_tile_coords(uint32_t t, int tiles_m, int tiles_n, int64_t &m0, int64_t &n0)
 {
+    // 32-bit arithmetic throughout (the launcher refuses tile counts >= 2^31): a 64-bit division is ~130 instructions here
     if (SYM) {
         const double T = (double)tiles_n;
-        int64_t tm = (int64_t)(((2.0 * T + 1.0) - sqrt((2.0 * T + 1.0) * (2.0 * T + 1.0) - 8.0 * (double)t)) * 0.5);
+        int32_t tm = (int32_t)(((2.0 * T + 1.0) - sqrt((2.0 * T + 1.0) * (2.0 * T + 1.0) - 8.0 * (double)t)) * 0.5);
         if (tm < 0) tm = 0;
         if (tm > tiles_m - 1) tm = tiles_m - 1;
-        // offset(tm) = tm*T - tm*(tm-1)/2 ; fix rounding
-        while (tm > 0 && tm * (int64_t)tiles_n - tm * (tm - 1) / 2 > t) tm--;
-        while ((tm + 1) * (int64_t)tiles_n - (tm + 1) * tm / 2 <= t) tm++;
-        const int64_t off = tm * (int64_t)tiles_n - tm * (tm - 1) / 2;
-        m0 = tm * PD_BM;
-        n0 = (tm + (t - off)) * PD_BN;
+        // offset(tm) = tm*T - tm*(tm-1)/2 ; fix rounding   (tiles_n <= 65535 in symmetric mode: the products fit 32 bits)
+        while (tm > 0 && (uint32_t)tm * (uint32_t)tiles_n - (uint32_t)tm * (uint32_t)(tm - 1) / 2u > t) tm--;
+        while ((uint32_t)(tm + 1) * (uint32_t)tiles_n - (uint32_t)(tm + 1) * (uint32_t)tm / 2u <= t) tm++;
+        const uint32_t off = (uint32_t)tm * (uint32_t)tiles_n - (uint32_t)tm * (uint32_t)(tm - 1) / 2u;
+        m0 = (int64_t)tm * PD_BM;
+        n0 = (int64_t)((uint32_t)tm + (t - off)) * PD_BN;
         return;
     }
-    const int64_t per_group = (int64_t)PD_GROUP_M * tiles_n;
-    const int64_t group = t / per_group, in_g = t % per_group;
-    const int64_t first_m = group * PD_GROUP_M;
-    const int64_t gsz = (tiles_m - first_m < PD_GROUP_M) ? (tiles_m - first_m) : PD_GROUP_M;
-    m0 = (first_m + in_g % gsz) * PD_BM;
-    n0 = (in_g / gsz) * PD_BN;
+    const uint32_t per_group = (uint32_t)PD_GROUP_M * (uint32_t)tiles_n;
+    const uint32_t group = t / per_group, in_g = t - group * per_group;
+    const uint32_t first_m = group * PD_GROUP_M;
+    const uint32_t gsz = ((uint32_t)tiles_m - first_m < (uint32_t)PD_GROUP_M) ? ((uint32_t)tiles_m - first_m) : (uint32_t)PD_GROUP_M;
+    const uint32_t col_t = in_g / gsz;
+    m0 = (int64_t)(first_m + (in_g - col_t * gsz)) * PD_BM;
+    n0 = (int64_t)col_t * PD_BN;
 }
 
 
@@ -244,6 +246,11 @@ __global__ __launch_bounds__(PD_THREADS, (PD_WAVES / 4) * PD_WGS_PER_CU) void pd
         for (int i = 0; i < slot * 2; i++) __builtin_amdgcn_s_sleep(127);
     }
 
+#ifdef SE_PD_PRIO
+    // experiment: static priority for the second workgroup slot of every CU, so that the two co-resident workgroups cannot
+    // phase-lock (both in their MFMA phase at half speed, then both staging with the matrix pipe idle)
+    if (b >= (G >> 1)) __builtin_amdgcn_s_setprio(SE_PD_PRIO);
+#endif
     const int lane = lane_id(), wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1;      // (PD_WAVES / 2) x 2 waves: PD_WROWS rows x 64 cols each
     const int col = lane & 31, hi = lane >> 5;
@@ -265,7 +272,7 @@ __global__ __launch_bounds__(PD_THREADS, (PD_WAVES / 4) * PD_WGS_PER_CU) void pd
     float4 ra[PD_NLOAD], rb[PD_NLOAD];
     int64_t m0, n0, k0, kend;
     bool closes_kb;
-    pd_tile_coords<SYM>(band_beg + wg_in_xcd, tiles_m, tiles_n, m0, n0);
+    pd_tile_coords<SYM>((uint32_t)(band_beg + wg_in_xcd), tiles_m, tiles_n, m0, n0);
     pd_chunk(0, kbs, MULTI_KB, D, k0, kend, closes_kb);
 #define PD_FETCH()                              \
     pd_load<VEC>(ra, A, lda, m0, Q, k0, kend);  \
@@ -280,33 +287,35 @@ __global__ __launch_bounds__(PD_THREADS, (PD_WAVES / 4) * PD_WGS_PER_CU) void pd
 #else
 #define PD_T(i)
 #endif
+    // The chunk loop is ROTATED: an iteration computes on the chunk that already sits in LDS while the loads of the next chunk
+    // (same tile, or first chunk of the next tile) are in flight, and stages that next chunk at its end.  Loads are thus issued and
+    // consumed inside ONE iteration: with the operand registers carried across the back-edge instead (stage at the loop top), hipcc
+    // re-arranged them right behind the loads -- `s_waitcnt vmcnt(4)` + two v_mov in front of every MFMA phase, i.e. every wave of
+    // the workgroup sat out a global-load round trip per chunk.
+    // (chunk / tile counters are carried, not derived from `it`: a 64-bit `it % nchunks`, `(it + 1) / nchunks` and the divisions of
+    //  pd_tile_coords cost ~130 scalar instructions EACH on this ISA -- eight of them per 2-chunk tile, on every wave, in front of a barrier)
     const int64_t total = my_tiles * nchunks;
+    int c = 0;                                     // chunk (of its tile) that sits in LDS
+    uint32_t tile_i = 0;                           // index of that tile in this workgroup's list
+    int64_t cur_m0 = m0, cur_n0 = n0;              // geometry of the chunk in LDS
+    int kc = (int)((kend - k0 < PD_BK) ? (kend - k0) : PD_BK);
+    bool cur_closes = closes_kb;
+    pd_store(sA, ra, (int)((Q - cur_m0 < PD_BM) ? (Q - cur_m0) : PD_BM), kc);
+    pd_store(sB, rb, (int)((N - cur_n0 < PD_BN) ? (N - cur_n0) : PD_BN), kc);
+    __syncthreads();
 #pragma unroll 1
     for (int64_t it = 0; it < total; it++) {
-        const int c = (int)(it % nchunks);
-        const int64_t cur_m0 = m0, cur_n0 = n0;       // geometry of the chunk held in ra/rb
-        const int kc = (int)((kend - k0 < PD_BK) ? (kend - k0) : PD_BK);
-        const bool cur_closes = closes_kb;
-
-        const int rows_a = (int)((Q - cur_m0 < PD_BM) ? (Q - cur_m0) : PD_BM);
-        const int rows_b = (int)((N - cur_n0 < PD_BN) ? (N - cur_n0) : PD_BN);
-
-        __syncthreads();  // LDS free: everyone finished the previous chunk's MFMAs
-        PD_T(0)
-        pd_store(sA, ra, rows_a, kc);
-        pd_store(sB, rb, rows_b, kc);
-        PD_T(1)
-        __syncthreads();
         PD_T(2)
-
-        // ---- prefetch the next chunk (same tile or first chunk of the next tile) ----
+        // ---- request the next chunk (same tile or first chunk of the next tile) ----
         // (Spreading these 8 loads over the first four MFMA groups instead -- the burst costs each wave ~3k cycles of
         // VMEM issue per chunk, SE_PD_PROFILE=1 -- was measured and is slower, 3.5 -> 3.75 ms: a load that blocks
         // inside the MFMA loop stalls the matrix pipe of its wave; so was a register double buffer of the LDS
         // operand reads, 3.5 -> 3.9 ms.)
-        if (it + 1 < total) {
-            const int nc = (c + 1 == nchunks) ? 0 : c + 1;
-            if (nc == 0) pd_tile_coords<SYM>(band_beg + wg_in_xcd + ((it + 1) / nchunks) * wgs_per_xcd, tiles_m, tiles_n, m0, n0);
+        const bool last_chunk = (c + 1 == nchunks);
+        const bool have_next = it + 1 < total;
+        if (have_next) {
+            const int nc = last_chunk ? 0 : c + 1;
+            if (nc == 0) pd_tile_coords<SYM>((uint32_t)(band_beg + wg_in_xcd) + (tile_i + 1u) * (uint32_t)wgs_per_xcd, tiles_m, tiles_n, m0, n0);
             pd_chunk(nc, kbs, MULTI_KB, D, k0, kend, closes_kb);
             PD_FETCH()
         }
@@ -339,6 +348,18 @@ __global__ __launch_bounds__(PD_THREADS, (PD_WAVES / 4) * PD_WGS_PER_CU) void pd
 #undef PD_STEP
 
         PD_T(4)
+        {
+            // The next chunk's operands (requested before this MFMA phase) are waited for HERE, through value barriers the compiler
+            // cannot move: (1) no use of a loaded register can be scheduled in front of the MFMA phase (hipcc otherwise re-arranges
+            // two of them right behind the loads: s_waitcnt vmcnt(4) + v_mov, a global-load round trip in front of every MFMA phase
+            // of every wave); (2) behind the stores of a tile epilogue, its vmcnt(N) for these loads would also wait for the stores
+            // to be acknowledged.
+#pragma unroll
+            for (int i = 0; i < PD_NLOAD; i++) {
+                asm volatile("" : "+v"(ra[i].x), "+v"(ra[i].y), "+v"(ra[i].z), "+v"(ra[i].w));
+                asm volatile("" : "+v"(rb[i].x), "+v"(rb[i].y), "+v"(rb[i].z), "+v"(rb[i].w));
+            }
+        }
         if (MULTI_KB && cur_closes) {
 #pragma unroll
             for (int j = 0; j < NB; j++)
@@ -351,7 +372,7 @@ __global__ __launch_bounds__(PD_THREADS, (PD_WAVES / 4) * PD_WGS_PER_CU) void pd
         }
 
         // ---- tile finished: accumulators (col = lane & 31, row = (r&3) + 8*(r>>2) + 4*hi) -> global ----
-        if (c + 1 == nchunks) {
+        if (last_chunk) {
             if (flags & PDF_NO_STORE) {
 #pragma unroll
                 for (int j = 0; j < NB; j++)
@@ -377,13 +398,13 @@ __global__ __launch_bounds__(PD_THREADS, (PD_WAVES / 4) * PD_WGS_PER_CU) void pd
                             fsa[r] = sqa[(cur_m0 + (lr < rows_here ? lr : rows_here - 1)) * fa.sqa_stride];
                         }
                     }
+                    if (EPI == EPI_GROUPMIN) {
 #pragma unroll
-                    for (int j = 0; j < 2; j++) {
-                        const int lc = wn * 64 + j * 32 + col;
-                        const bool qok = lc < cols_here;
-                        const int64_t qg = cur_n0 + (qok ? lc : cols_here - 1);
-                        const float sbq = METRIC == SE_METRIC_EUCLID ? sqb[qg] : 0.f;
-                        if (EPI == EPI_GROUPMIN) {
+                        for (int j = 0; j < 2; j++) {
+                            const int lc = wn * 64 + j * 32 + col;
+                            const bool qok = lc < cols_here;
+                            const int64_t qg = cur_n0 + (qok ? lc : cols_here - 1);
+                            const float sbq = METRIC == SE_METRIC_EUCLID ? sqb[qg] : 0.f;
                             float m = __builtin_inff();
                             bool any = false;
 #pragma unroll
@@ -396,22 +417,51 @@ __global__ __launch_bounds__(PD_THREADS, (PD_WAVES / 4) * PD_WGS_PER_CU) void pd
                             }
                             if (!any) m = __builtin_nanf("");     // a group of NaNs only: sorted last by the threshold kernel
                             if (qok) fa.gm[qg * fa.gm_ld + (cur_m0 / PD_BM) * (PD_WAVES * PD_MI) + (wm * PD_MI + mi) * 2 + hi] = m;
-                        } else {
-                            const float tau = fa.tau[qg];
+                        }
+                    } else {
+                        // both 32-column blocks: counts first, then BOTH slot reservations (returning atomics) in flight together, then the stores
+                        int64_t qgj[2];
+                        float tauj[2], sbqj[2];
+                        unsigned cntj[2], slotj[2];
+#pragma unroll
+                        for (int j = 0; j < 2; j++) {
+                            const int lc = wn * 64 + j * 32 + col;
+                            const bool qok = lc < cols_here;
+                            qgj[j] = cur_n0 + (qok ? lc : cols_here - 1);
+                            tauj[j] = qok ? fa.tau[qgj[j]] : __builtin_nanf("");       // NaN: nothing passes
+                            sbqj[j] = METRIC == SE_METRIC_EUCLID ? sqb[qgj[j]] : 0.f;
+                        }
+#pragma unroll
+                        for (int j = 0; j < 2; j++) {
+                            const float sbq = sbqj[j];
                             unsigned cnt = 0;
 #pragma unroll
                             for (int r = 0; r < 16; r++) {
                                 const int lr = lr0 + mi * 32 + (r & 3) + 8 * (r >> 2);
-                                cnt += ((PD_FVAL(mi, j, r) <= tau) && (full_rows || lr < rows_here)) ? 1u : 0u;
+                                cnt += ((PD_FVAL(mi, j, r) <= tauj[j]) && (full_rows || lr < rows_here)) ? 1u : 0u;
                             }
-                            if (qok && cnt) {
-                                unsigned slot = atomicAdd(&fa.rowcnt[qg], cnt);
-                                uint2 *lst = fa.lists + qg * fa.cap;
+                            cntj[j] = cnt;
+                        }
+#pragma unroll
+                        for (int j = 0; j < 2; j++) {
+                            slotj[j] = 0;
+                            if (cntj[j]) slotj[j] = atomicAdd(&fa.rowcnt[qgj[j]], cntj[j]);
+                        }
+                        // ONE wait for both reservations, in straight-line code: left to hipcc, every conditional store block below
+                        // re-waits with vmcnt(0) (merged control flow) -- which also waits for the previous block's STORE to be
+                        // acknowledged, i.e. serialises up to 32 store round trips per tile
+                        asm volatile("" : "+v"(slotj[0]), "+v"(slotj[1]));
+#pragma unroll
+                        for (int j = 0; j < 2; j++) {
+                            if (cntj[j]) {
+                                const float sbq = sbqj[j];
+                                unsigned slot = slotj[j];
+                                uint2 *lst = fa.lists + qgj[j] * fa.cap;
 #pragma unroll
                                 for (int r = 0; r < 16; r++) {
                                     const int lr = lr0 + mi * 32 + (r & 3) + 8 * (r >> 2);
                                     const float v = PD_FVAL(mi, j, r);
-                                    if ((v <= tau) && (full_rows || lr < rows_here)) {
+                                    if ((v <= tauj[j]) && (full_rows || lr < rows_here)) {
                                         if (slot < (unsigned)fa.cap) lst[slot] = make_uint2(__float_as_uint(v), (uint32_t)(cur_m0 + lr));
                                         slot++;
                                     }
@@ -497,7 +547,7 @@ __global__ __launch_bounds__(PD_THREADS, (PD_WAVES / 4) * PD_WGS_PER_CU) void pd
                         PD_T(9)
                     }
                 }
-                // (the barrier that opens the next chunk orders these LDS reads before the operands overwrite the stage)
+                // (the barrier behind the tile epilogue orders these LDS reads before the next chunk's operands overwrite the stage)
 #undef PD_VAL
             }
 #pragma unroll
@@ -507,6 +557,19 @@ __global__ __launch_bounds__(PD_THREADS, (PD_WAVES / 4) * PD_WGS_PER_CU) void pd
             first_kb = true;
             PD_T(5)
         }
+        __syncthreads();   // every wave has finished reading this chunk (and, EPI_STORE, the epilogue stage) out of LDS
+        PD_T(0)
+        if (have_next) {
+            cur_m0 = m0; cur_n0 = n0;
+            kc = (int)((kend - k0 < PD_BK) ? (kend - k0) : PD_BK);
+            cur_closes = closes_kb;
+            pd_store(sA, ra, (int)((Q - cur_m0 < PD_BM) ? (Q - cur_m0) : PD_BM), kc);
+            pd_store(sB, rb, (int)((N - cur_n0 < PD_BN) ? (N - cur_n0) : PD_BN), kc);
+        }
+        PD_T(1)
+        __syncthreads();
+        c = last_chunk ? 0 : c + 1;
+        tile_i += last_chunk ? 1u : 0u;
     }
 #ifdef SE_TUNING
     if (prof && threadIdx.x == 0)
@@ -535,6 +598,8 @@ static int launch_pdist3(const float *a, int64_t lda, const float *b, int64_t ld
     const int tiles_m = (int)((q + PD_BM - 1) / PD_BM), tiles_n = (int)((n + PD_BN - 1) / PD_BN);
     const int64_t ntiles = SYM ? ((int64_t)tiles_n * (tiles_n + 1) / 2) : ((int64_t)tiles_m * tiles_n);
     const size_t lds = (size_t)(PD_BM + PD_BN) * PD_LD * sizeof(float);
+    if (ntiles >= ((int64_t)1 << 31) || (int64_t)PD_GROUP_M * tiles_n >= ((int64_t)1 << 31) || (SYM && tiles_n > 65535))
+        return fail(SE_ERR_UNSUPPORTED, "se_pairwise_dist: %lld output tiles exceed the 32-bit tile counter -- split the call", (long long)ntiles);
     int flags = 0;
     if ((lda % 4 == 0) && ((((uintptr_t)a) & 15) == 0)) flags |= PDF_VEC_A;
     if ((ldb % 4 == 0) && ((((uintptr_t)b) & 15) == 0)) flags |= PDF_VEC_B;

@@ -516,6 +516,43 @@ static FusedPlan fused_plan(int64_t n, int64_t ldg, int k)
     return p;
 }
 
+// Bitonic sort of 64 * PER values held PER per lane by ONE wave (value e = lane * PER + r): partner registers of the same lane,
+// then lanes via shuffles -- no LDS, no barrier.
+template <typename T, int PER>
+__device__ __forceinline__ void wave_bitonic_sort(T (&v)[PER], int lane)
+{
+    constexpr int P = 64 * PER;
+#pragma unroll 1
+    for (int k = 2; k <= P; k <<= 1) {
+#pragma unroll 1
+        for (int jj = k >> 1; jj >= PER; jj >>= 1) {          // partner in another lane
+            const int lm = jj / PER;
+#pragma unroll
+            for (int r = 0; r < PER; r++) {
+                const T o = shfl_xor_any(v[r], lm);
+                const int e = lane * PER + r;
+                const bool take_min = (((e & k) == 0) == ((e & jj) == 0));
+                v[r] = take_min ? (o < v[r] ? o : v[r]) : (o > v[r] ? o : v[r]);
+            }
+        }
+#pragma unroll
+        for (int jj = PER >> 1; jj > 0; jj >>= 1) {            // partner register of the same lane (static indices)
+            if (jj < k) {
+#pragma unroll
+                for (int r = 0; r < PER; r++) {
+                    if ((r & jj) == 0) {
+                        const bool up = (((lane * PER + r) & k) == 0);
+                        const T a = v[r], b = v[r | jj];
+                        const bool sw = (a > b) == up;
+                        v[r] = sw ? b : a;
+                        v[r | jj] = sw ? a : b;
+                    }
+                }
+            }
+        }
+    }
+}
+
 // tau[q] = j-th smallest of the G group minima of query q: one wave per query, 4 keys per lane, bitonic sort in registers.
 __global__ __launch_bounds__(256) void topk_tau_kernel(const float *__restrict__ gm, int64_t gm_ld, int64_t Q, int G, int j, float *__restrict__ tau)
 {
@@ -528,35 +565,7 @@ __global__ __launch_bounds__(256) void topk_tau_kernel(const float *__restrict__
         const int e = lane * 4 + r;
         v[r] = e < G ? canon_key(gm[q * gm_ld + e]) : 0xFFFFFFFFu;
     }
-#pragma unroll 1
-    for (int k = 2; k <= 256; k <<= 1) {
-#pragma unroll 1
-        for (int jj = k >> 1; jj >= 4; jj >>= 1) {          // partner in another lane
-            const int lm = jj >> 2;
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const uint32_t o = (uint32_t)__shfl_xor((int)v[r], lm, 64);
-                const int e = lane * 4 + r;
-                const bool take_min = (((e & k) == 0) == ((e & jj) == 0));
-                v[r] = take_min ? (o < v[r] ? o : v[r]) : (o > v[r] ? o : v[r]);
-            }
-        }
-#pragma unroll
-        for (int jj = 2; jj > 0; jj >>= 1) {                // partner register of the same lane
-            if (jj < k) {
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    if ((r & jj) == 0) {
-                        const bool up = (((lane * 4 + r) & k) == 0);
-                        const uint32_t a = v[r], b = v[r | jj];
-                        const bool sw = (a > b) == up;
-                        v[r] = sw ? b : a;
-                        v[r | jj] = sw ? a : b;
-                    }
-                }
-            }
-        }
-    }
+    wave_bitonic_sort<uint32_t, 4>(v, lane);
     const int want = j - 1;
     if (lane == (want >> 2)) {
         const uint32_t key = (want & 3) == 0 ? v[0] : ((want & 3) == 1 ? v[1] : ((want & 3) == 2 ? v[2] : v[3]));
@@ -564,15 +573,142 @@ __global__ __launch_bounds__(256) void topk_tau_kernel(const float *__restrict__
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Candidate lists -> top-k, one WAVE per query (k <= 256, lists of <= 2048 candidates: the sizes the fused path produces):
+//   1. the candidates sit PER per lane in registers;
+//   2. radix SELECT of the k-th smallest key: 4 passes of 8 bits, a 256-bin histogram in wave-private LDS (one LDS add per key
+//      and pass), wave scan of the bins;
+//   3. every candidate with key <= that key (k plus the ties of the k-th key: a few hundred of ~760) is compacted into LDS,
+//   4. sorted on the canonical 64-bit (key, index) composite by an in-register wave bitonic sort, and the first k are written.
+// ~1.5k wave instructions per query instead of the ~13k of a full sort of the list.  Queries it cannot finish (k > 256, huge tie
+// groups) are marked TK_WIDE for the workgroup-wide kernel below; lists outside [k, cap] are marked TK_REDO for the exact kernel.
+constexpr int32_t TK_WIDE = -2;
+constexpr int TL_WAVES = 4;
+constexpr int TL_SEL = 512;             // compacted candidates per query the wave sort takes
+
+template <int PER>
+__device__ __forceinline__ bool topk_wave_select(const uint2 *__restrict__ lst, int total, int k, int64_t col_offset, uint32_t *hist,
+                                                 uint64_t *sel, float *__restrict__ od, int32_t *__restrict__ oi, int lane)
+{
+    uint32_t key[PER], idx[PER];
+#pragma unroll
+    for (int r = 0; r < PER; r++) {
+        const int e = r * 64 + lane;
+        const uint2 c = lst[e < total ? e : 0];
+        key[r] = e < total ? canon_key(__uint_as_float(c.x)) : 0xFFFFFFFFu;   // (list entries are never NaN: padding sorts behind everything)
+        idx[r] = e < total ? c.y : 0xFFFFFFFFu;
+    }
+    // ---- k-th smallest key ----
+    uint32_t prefix = 0, pmask = 0, remaining = (uint32_t)k, n_eq = 0;
+#pragma unroll 1
+    for (int shift = 24; shift >= 0; shift -= 8) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) hist[lane * 4 + i] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+        for (int r = 0; r < PER; r++)
+            if ((key[r] & pmask) == prefix && r * 64 + lane < total) atomicAdd(&hist[(key[r] >> shift) & 255u], 1u);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        uint32_t c[4], local = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) { c[i] = hist[lane * 4 + i]; local += c[i]; }
+        uint32_t incl = local;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t t = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += t;
+        }
+        uint32_t run = incl - local, digit = 0, rem = 0, cnt = 0;
+        const bool mine = remaining > run && remaining <= incl;             // exactly one lane
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const bool hit = mine && remaining > run && remaining <= run + c[i];
+            digit = hit ? (uint32_t)(lane * 4 + i) : digit;
+            rem = hit ? remaining - run : rem;
+            cnt = hit ? c[i] : cnt;
+            run += c[i];
+        }
+        const int src = __ffsll((long long)__ballot(mine)) - 1;
+        digit = (uint32_t)__shfl((int)digit, src, 64);
+        remaining = (uint32_t)__shfl((int)rem, src, 64);
+        n_eq = (uint32_t)__shfl((int)cnt, src, 64);
+        prefix |= digit << shift;
+        pmask |= 255u << shift;
+    }
+    const uint32_t kth = prefix;
+    const uint32_t n_le = (uint32_t)k - remaining + n_eq;                   // keys below the k-th key + ALL its ties
+    if (n_le > (uint32_t)TL_SEL) return false;
+    // ---- compact the candidates with key <= kth into LDS, sort them on (key, index), write the first k ----
+    uint32_t base = 0;
+#pragma unroll
+    for (int r = 0; r < PER; r++) {
+        const bool take = key[r] <= kth && r * 64 + lane < total;
+        const uint64_t m = __ballot(take);
+        if (take) sel[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = ((uint64_t)key[r] << 32) | idx[r];
+        base += (uint32_t)__popcll(m);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#define TL_SORT_OUT(P2)                                                                        \
+    {                                                                                          \
+        uint64_t sv[P2];                                                                       \
+        _Pragma("unroll") for (int r = 0; r < P2; r++) {                                       \
+            const int e = lane * P2 + r;                                                       \
+            sv[r] = e < (int)n_le ? sel[e] : ~0ull;                                            \
+        }                                                                                      \
+        wave_bitonic_sort<uint64_t, P2>(sv, lane);                                             \
+        _Pragma("unroll") for (int r = 0; r < P2; r++) {                                       \
+            const int e = lane * P2 + r;                                                       \
+            if (e < k) {                                                                       \
+                od[e] = key_to_float((uint32_t)(sv[r] >> 32));                                 \
+                oi[e] = (int32_t)(col_offset + (int64_t)(uint32_t)sv[r]);                      \
+            }                                                                                  \
+        }                                                                                      \
+    }
+    if (n_le <= 64) TL_SORT_OUT(1)
+    else if (n_le <= 128) TL_SORT_OUT(2)
+    else if (n_le <= 256) TL_SORT_OUT(4)
+    else TL_SORT_OUT(8)
+#undef TL_SORT_OUT
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");                  // sel / hist are reused by this wave's next query
+    return true;
+}
+
+__global__ __launch_bounds__(TL_WAVES * 64) void topk_lists_wave_kernel(const uint2 *__restrict__ lists, const unsigned *__restrict__ rowcnt, int64_t cap,
+                                                                       int64_t Q, int64_t col_offset, int k, float *__restrict__ out_d,
+                                                                       int32_t *__restrict__ out_i)
+{
+    __shared__ uint32_t hist_all[TL_WAVES][256];
+    __shared__ uint64_t sel_all[TL_WAVES][TL_SEL];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t *hist = hist_all[wave];
+    uint64_t *sel = sel_all[wave];
+    for (int64_t row = (int64_t)blockIdx.x * TL_WAVES + wave; row < Q; row += (int64_t)gridDim.x * TL_WAVES) {
+        const unsigned total = rowcnt[row];
+        if (total < (unsigned)k || total > (unsigned)cap) {
+            if (lane == 0) out_i[row * k] = TK_REDO;
+            continue;
+        }
+        const uint2 *lst = lists + row * cap;
+        bool done = false;
+        if (k <= 256 && total <= 2048u) {
+            if (total <= 512u) done = topk_wave_select<8>(lst, (int)total, k, col_offset, hist, sel, out_d + row * k, out_i + row * k, lane);
+            else if (total <= 1024u) done = topk_wave_select<16>(lst, (int)total, k, col_offset, hist, sel, out_d + row * k, out_i + row * k, lane);
+            else done = topk_wave_select<32>(lst, (int)total, k, col_offset, hist, sel, out_d + row * k, out_i + row * k, lane);
+        }
+        if (!done && lane == 0) out_i[row * k] = TK_WIDE;
+    }
+}
+
 // candidates of every query -> canonical top-k; queries whose list missed [k, cap] are flagged for the exact kernel
 __global__ __launch_bounds__(TK_THREADS) void topk_lists_kernel(const uint2 *__restrict__ lists, const unsigned *__restrict__ rowcnt, int64_t cap,
                                                                 int64_t Q, int64_t col_offset, int k, float *__restrict__ out_d,
-                                                                int32_t *__restrict__ out_i)
+                                                                int32_t *__restrict__ out_i, int only_wide)
 {
     extern __shared__ __attribute__((aligned(16))) uint64_t tl_lds64[];
     uint64_t *cand = tl_lds64;
     const int tid = threadIdx.x;
     for (int64_t row = blockIdx.x; row < Q; row += gridDim.x) {
+        if (only_wide && out_i[row * k] != TK_WIDE) continue;      // behind topk_lists_wave_kernel: only the queries it handed over (uniform)
         const unsigned total = rowcnt[row];
         if (total < (unsigned)k || total > (unsigned)cap) {
             if (tid == 0) out_i[row * k] = TK_REDO;
@@ -750,8 +886,16 @@ extern "C" int se_retrieve_topk(const float *queries, int64_t ldq, const float *
         rc = launch_fused_pass(EPI_FILTER, gallery, ldg, qs, ldq, sqg, sq, n, rows, d, metric, kbs, multi, fa, s);
         if (rc != SE_OK) return rc;
         const int64_t grid = rows < 2048 ? rows : 2048;
+        int only_wide = 0;
+        if (k <= 256 && !tuning_env("SE_TOPK_NOWAVE")) {     // one wave per query (radix select + small sort); hands the rest on
+            const int64_t wgrid = (rows + TL_WAVES - 1) / TL_WAVES < 4096 ? (rows + TL_WAVES - 1) / TL_WAVES : 4096;
+            hipLaunchKernelGGL(topk_lists_wave_kernel, dim3((unsigned)wgrid), dim3(TL_WAVES * 64), 0, s, lists, rowcnt, (int64_t)p.cap, rows,
+                               col_offset, k, out_d + q0 * k, out_i + q0 * k);
+            SE_LAUNCH_CHECK();
+            only_wide = 1;
+        }
         hipLaunchKernelGGL(topk_lists_kernel, dim3((unsigned)grid), dim3(TK_THREADS), lds_lists, s, lists, rowcnt, (int64_t)p.cap, rows,
-                           col_offset, k, out_d + q0 * k, out_i + q0 * k);
+                           col_offset, k, out_d + q0 * k, out_i + q0 * k, only_wide);
         SE_LAUNCH_CHECK();
         if (kTuning && tuning_env("SE_TOPK_VERBOSE")) {   // -DSE_TUNING build only: synchronises and reports how the lists came out
             SE_HIP_CHECK(hipStreamSynchronize(s));
