@@ -226,7 +226,7 @@ __global__ __launch_bounds__(PD_THREADS, (PD_WAVES / 4) * PD_WGS_PER_CU) void pd
     KBlocks kbs, int nchunks, float *__restrict__ out, uint32_t ldo, int tiles_m, int tiles_n, int64_t ntiles, int flags,
     unsigned long long *prof, FusedArgs fa)
 {
-    static_assert(EPI == EPI_STORE || !SYM, "the fused top-k epilogues walk the general tile order");
+    static_assert(EPI != EPI_GROUPMIN || !SYM, "the sample pass walks the general tile order");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *sA = smem;
     float *sB = smem + PD_BM * PD_LD;
@@ -388,17 +388,17 @@ __global__ __launch_bounds__(PD_THREADS, (PD_WAVES / 4) * PD_WGS_PER_CU) void pd
 #define PD_FVAL(MI_, J, R)                                                                                                   \
     pd_finish<METRIC>(MULTI_KB ? tot[(MI_) * 2 + (J)][R] : acc[(MI_) * 2 + (J)][R],                                            \
                       METRIC == SE_METRIC_EUCLID ? fsa[((R) & 3) + 4 * ((R) >> 2)] : 0.f, sbq)
+                if (EPI == EPI_GROUPMIN) {
 #pragma unroll
-                for (int mi = 0; mi < PD_MI; mi++) {
-                    float fsa[16];
-                    if (METRIC == SE_METRIC_EUCLID) {
+                    for (int mi = 0; mi < PD_MI; mi++) {
+                        float fsa[16];
+                        if (METRIC == SE_METRIC_EUCLID) {
 #pragma unroll
-                        for (int r = 0; r < 16; r++) {
-                            const int lr = lr0 + mi * 32 + (r & 3) + 8 * (r >> 2);
-                            fsa[r] = sqa[(cur_m0 + (lr < rows_here ? lr : rows_here - 1)) * fa.sqa_stride];
+                            for (int r = 0; r < 16; r++) {
+                                const int lr = lr0 + mi * 32 + (r & 3) + 8 * (r >> 2);
+                                fsa[r] = sqa[(cur_m0 + (lr < rows_here ? lr : rows_here - 1)) * fa.sqa_stride];
+                            }
                         }
-                    }
-                    if (EPI == EPI_GROUPMIN) {
 #pragma unroll
                         for (int j = 0; j < 2; j++) {
                             const int lc = wn * 64 + j * 32 + col;
@@ -418,57 +418,152 @@ __global__ __launch_bounds__(PD_THREADS, (PD_WAVES / 4) * PD_WGS_PER_CU) void pd
                             if (!any) m = __builtin_nanf("");     // a group of NaNs only: sorted last by the threshold kernel
                             if (qok) fa.gm[qg * fa.gm_ld + (cur_m0 / PD_BM) * (PD_WAVES * PD_MI) + (wm * PD_MI + mi) * 2 + hi] = m;
                         }
-                    } else {
-                        // both 32-column blocks: counts first, then BOTH slot reservations (returning atomics) in flight together, then the stores
-                        int64_t qgj[2];
-                        float tauj[2], sbqj[2];
-                        unsigned cntj[2], slotj[2];
+                    }
+                } else {
+                    // ---- EPI_FILTER.  Orientation 1: lanes = queries (tile columns), registers = gallery rows.  Orientation 2 (all-pairs
+                    //      calls, off-diagonal tiles): lanes = queries (tile ROWS), values read back from the staged tile.  Per orientation:
+                    //      counts of both 32-query blocks, then BOTH slot reservations (returning atomics) in flight together, one wait, stores. ----
+                    static_assert(PD_MI == 1 || EPI != EPI_FILTER, "the filter epilogue is written for 32-row wave slabs");
+                    constexpr int mi = 0;
+                    const bool mirror = SYM && (cur_m0 != cur_n0);
+                    {
+                    float fsa[16];
+                    if (METRIC == SE_METRIC_EUCLID) {
 #pragma unroll
-                        for (int j = 0; j < 2; j++) {
-                            const int lc = wn * 64 + j * 32 + col;
-                            const bool qok = lc < cols_here;
-                            qgj[j] = cur_n0 + (qok ? lc : cols_here - 1);
-                            tauj[j] = qok ? fa.tau[qgj[j]] : __builtin_nanf("");       // NaN: nothing passes
-                            sbqj[j] = METRIC == SE_METRIC_EUCLID ? sqb[qgj[j]] : 0.f;
+                        for (int r = 0; r < 16; r++) {
+                            const int lr = lr0 + (r & 3) + 8 * (r >> 2);
+                            fsa[r] = sqa[(cur_m0 + (lr < rows_here ? lr : rows_here - 1)) * fa.sqa_stride];
                         }
+                    }
+                    int64_t qgj[2];
+                    float tauj[2], sbqj[2];
+                    unsigned cntj[2], slotj[2];
 #pragma unroll
-                        for (int j = 0; j < 2; j++) {
+                    for (int j = 0; j < 2; j++) {
+                        const int lc = wn * 64 + j * 32 + col;
+                        const bool qok = lc < cols_here;
+                        qgj[j] = cur_n0 + (qok ? lc : cols_here - 1);
+                        tauj[j] = qok ? fa.tau[qgj[j]] : __builtin_nanf("");       // NaN: nothing passes
+                        sbqj[j] = METRIC == SE_METRIC_EUCLID ? sqb[qgj[j]] : 0.f;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 2; j++) {
+                        const float sbq = sbqj[j];
+                        unsigned cnt = 0;
+#pragma unroll
+                        for (int r = 0; r < 16; r++) {
+                            const int lr = lr0 + (r & 3) + 8 * (r >> 2);
+                            cnt += ((PD_FVAL(mi, j, r) <= tauj[j]) && (full_rows || lr < rows_here)) ? 1u : 0u;
+                        }
+                        cntj[j] = cnt;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 2; j++) {
+                        slotj[j] = 0;
+                        if (cntj[j]) slotj[j] = atomicAdd(&fa.rowcnt[qgj[j]], cntj[j]);
+                    }
+                    // ONE wait for both reservations, in straight-line code: left to hipcc, every conditional store block below re-waits with
+                    // vmcnt(0) (merged control flow) -- which also waits for the previous block's STORE to be acknowledged, i.e. serialises
+                    // up to 32 store round trips per tile.  (Keeping these reservations in flight across the mirrored part below, for ONE
+                    // atomic round trip per tile, was measured: the longer live ranges spill 140 B and the pass takes 5.4 instead of 3.9 ms.)
+                    asm volatile("" : "+v"(slotj[0]), "+v"(slotj[1]));
+#pragma unroll
+                    for (int j = 0; j < 2; j++) {
+                        if (cntj[j]) {
                             const float sbq = sbqj[j];
-                            unsigned cnt = 0;
+                            unsigned slot = slotj[j];
+                            uint2 *lst = fa.lists + qgj[j] * fa.cap;
 #pragma unroll
                             for (int r = 0; r < 16; r++) {
-                                const int lr = lr0 + mi * 32 + (r & 3) + 8 * (r >> 2);
-                                cnt += ((PD_FVAL(mi, j, r) <= tauj[j]) && (full_rows || lr < rows_here)) ? 1u : 0u;
-                            }
-                            cntj[j] = cnt;
-                        }
-#pragma unroll
-                        for (int j = 0; j < 2; j++) {
-                            slotj[j] = 0;
-                            if (cntj[j]) slotj[j] = atomicAdd(&fa.rowcnt[qgj[j]], cntj[j]);
-                        }
-                        // ONE wait for both reservations, in straight-line code: left to hipcc, every conditional store block below
-                        // re-waits with vmcnt(0) (merged control flow) -- which also waits for the previous block's STORE to be
-                        // acknowledged, i.e. serialises up to 32 store round trips per tile
-                        asm volatile("" : "+v"(slotj[0]), "+v"(slotj[1]));
-#pragma unroll
-                        for (int j = 0; j < 2; j++) {
-                            if (cntj[j]) {
-                                const float sbq = sbqj[j];
-                                unsigned slot = slotj[j];
-                                uint2 *lst = fa.lists + qgj[j] * fa.cap;
-#pragma unroll
-                                for (int r = 0; r < 16; r++) {
-                                    const int lr = lr0 + mi * 32 + (r & 3) + 8 * (r >> 2);
-                                    const float v = PD_FVAL(mi, j, r);
-                                    if ((v <= tauj[j]) && (full_rows || lr < rows_here)) {
-                                        if (slot < (unsigned)fa.cap) lst[slot] = make_uint2(__float_as_uint(v), (uint32_t)(cur_m0 + lr));
-                                        slot++;
-                                    }
+                                const int lr = lr0 + (r & 3) + 8 * (r >> 2);
+                                const float v = PD_FVAL(mi, j, r);
+                                if ((v <= tauj[j]) && (full_rows || lr < rows_here)) {
+                                    if (slot < (unsigned)fa.cap) lst[slot] = make_uint2(__float_as_uint(v), (uint32_t)(cur_m0 + lr));
+                                    slot++;
                                 }
                             }
                         }
                     }
+                    }
+#define PD_MVALS(J, G, E)                                                                                                    \
+    float E[4];                                                                                                              \
+    {                                                                                                                        \
+        const float4 raw_ = *(const float4 *)(strow[J] + 8 * (G));                                                           \
+        const float rv_[4] = {raw_.x, raw_.y, raw_.z, raw_.w};                                                               \
+        _Pragma("unroll") for (int cc = 0; cc < 4; cc++) {                                                                   \
+            const int gc_ = gl0 + 8 * (G) + cc;                                                                              \
+            const float sb_ = METRIC == SE_METRIC_EUCLID ? sqb[cur_n0 + (gc_ < cols_here ? gc_ : cols_here - 1)] : 0.f;      \
+            E[cc] = pd_finish<METRIC>(rv_[cc], saq2[J], sb_);                                                                \
+        }                                                                                                                    \
+    }
+                    if (mirror) {
+                        // ---- orientation 2: stage the RAW dot products (finished after the read-back: the Euclidean epilogue then needs a
+                        //      lane's 16 column norms only four at a time), count, reserve, store ----
+                        int64_t qg2[2];
+                        float tau2[2], saq2[2];
+                        unsigned cnt2[2], slot2[2];
+                        const float *strow[2];
+                        const int gl0 = wm * PD_WROWS + 4 * hi;            // this lane's gallery columns of the tile: gl0 + 8 g + c
+                        const bool full_cols = cols_here == PD_BN;
+                        // all-pairs call (queries == gallery): only tiles on or above the diagonal are computed; an off-diagonal tile also
+                        // serves the MIRRORED pairs -- queries = its rows, gallery items = its columns (the transposed element is the same
+                        // FMA chain with commuted factors: bit-identical).  The tile goes through the idle operand LDS so that a lane again
+                        // owns ONE query (a tile row) and reads 16 of its gallery values as 4 x 16 bytes.
+                        static_assert(PD_SR == PD_BM || EPI != EPI_FILTER || !SYM, "the mirrored filter stages a whole tile");
+                        __syncthreads();   // every wave has finished this chunk's MFMA reads of the operand LDS
+#pragma unroll
+                        for (int j = 0; j < 2; j++)
+#pragma unroll
+                            for (int r = 0; r < 16; r++)
+                                smem[(lr0 + (r & 3) + 8 * (r >> 2)) * PD_SP + wn * 64 + j * 32 + col] = MULTI_KB ? tot[j][r] : acc[j][r];
+                        __syncthreads();
+#pragma unroll
+                        for (int j = 0; j < 2; j++) {
+                            const int ql = wn * 64 + j * 32 + col;                    // this lane's query = tile row ql
+                            const bool qok = ql < rows_here;
+                            qg2[j] = cur_m0 + (qok ? ql : rows_here - 1);
+                            tau2[j] = qok ? fa.tau[qg2[j]] : __builtin_nanf("");
+                            saq2[j] = METRIC == SE_METRIC_EUCLID ? sqa[qg2[j] * fa.sqa_stride] : 0.f;
+                            strow[j] = smem + ql * PD_SP + gl0;
+                        }
+#pragma unroll
+                        for (int j = 0; j < 2; j++) {
+                            unsigned cnt = 0;
+#pragma unroll
+                            for (int g = 0; g < 4; g++) {
+                                PD_MVALS(j, g, e)
+#pragma unroll
+                                for (int cc = 0; cc < 4; cc++) cnt += ((e[cc] <= tau2[j]) && (full_cols || gl0 + 8 * g + cc < cols_here)) ? 1u : 0u;
+                            }
+                            cnt2[j] = cnt;
+                        }
+#pragma unroll
+                        for (int j = 0; j < 2; j++) {
+                            slot2[j] = 0;
+                            if (cnt2[j]) slot2[j] = atomicAdd(&fa.rowcnt[qg2[j]], cnt2[j]);
+                        }
+                        asm volatile("" : "+v"(slot2[0]), "+v"(slot2[1]));   // one wait for the mirrored reservations
+#pragma unroll
+                        for (int j = 0; j < 2; j++) {
+                            if (cnt2[j]) {
+                                unsigned slot = slot2[j];
+                                uint2 *lst = fa.lists + qg2[j] * fa.cap;
+#pragma unroll
+                                for (int g = 0; g < 4; g++) {
+                                    PD_MVALS(j, g, e)
+#pragma unroll
+                                    for (int cc = 0; cc < 4; cc++) {
+                                        if ((e[cc] <= tau2[j]) && (full_cols || gl0 + 8 * g + cc < cols_here)) {
+                                            if (slot < (unsigned)fa.cap) lst[slot] = make_uint2(__float_as_uint(e[cc]), (uint32_t)(cur_n0 + gl0 + 8 * g + cc));
+                                            slot++;
+                                        }
+                                    }
+                                }
+                            }
+                        }
+                        // (the barrier behind the tile epilogue orders these LDS reads before the next chunk's operands overwrite the stage)
+                    }
+#undef PD_MVALS
                 }
 #undef PD_FVAL
             } else {
@@ -683,6 +778,18 @@ static int launch_fused2(const float *g, int64_t ldg, const float *qs, int64_t l
     bool vec = (ldg % 4 == 0) && ((((uintptr_t)g) & 15) == 0) && (ldq % 4 == 0) && ((((uintptr_t)qs) & 15) == 0);
     int64_t beg = 0;
     for (int i = 0; i < kbs.n; i++) { if (beg & 3) vec = false; beg += kbs.len[i]; }
+    if constexpr (EPI == EPI_FILTER) {
+        // all-pairs call (every item is query and gallery item, the evaluate_retrieval.py case): upper-triangle tile walk, every
+        // off-diagonal tile filtered in both orientations -- half the MFMA work
+        const bool sym = (g == qs) && (ldg == ldq) && (n_a == n_q) && (METRIC != SE_METRIC_EUCLID || sqg == sqq) && n_a > PD_BN &&
+                         !tuning_env("SE_TOPK_NOSYM");
+        if (sym) {
+            if (multi) return vec ? launch_pdist3<METRIC, true, true, true, EPI>(g, ldg, qs, ldq, sqg, sqq, n_a, n_q, d, kbs, nullptr, n_q, s, fa)
+                                  : launch_pdist3<METRIC, true, true, false, EPI>(g, ldg, qs, ldq, sqg, sqq, n_a, n_q, d, kbs, nullptr, n_q, s, fa);
+            return vec ? launch_pdist3<METRIC, false, true, true, EPI>(g, ldg, qs, ldq, sqg, sqq, n_a, n_q, d, kbs, nullptr, n_q, s, fa)
+                       : launch_pdist3<METRIC, false, true, false, EPI>(g, ldg, qs, ldq, sqg, sqq, n_a, n_q, d, kbs, nullptr, n_q, s, fa);
+        }
+    }
     if (multi) return vec ? launch_pdist3<METRIC, true, false, true, EPI>(g, ldg, qs, ldq, sqg, sqq, n_a, n_q, d, kbs, nullptr, n_q, s, fa)
                           : launch_pdist3<METRIC, true, false, false, EPI>(g, ldg, qs, ldq, sqg, sqq, n_a, n_q, d, kbs, nullptr, n_q, s, fa);
     return vec ? launch_pdist3<METRIC, false, false, true, EPI>(g, ldg, qs, ldq, sqg, sqq, n_a, n_q, d, kbs, nullptr, n_q, s, fa)
