@@ -77,6 +77,9 @@ def parse(argv=None):
     ap.add_argument("--shard-queries", type=int, default=50000)
     ap.add_argument("--shard-dim", type=int, default=1000)
     ap.add_argument("--shard-k", type=int, default=251)
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: fixed work per GPU (50k queries / 128 images per rank); strong: ONE problem split over the ranks -- the "
+                         "reference's multi_gpu_model semantics for training (global batch 128), query rows sharded for retrieval")
     ap.add_argument("--dry", action="store_true",
                     help="CPU plumbing test: gloo process group, tiny shapes, CPU stand-ins for the kernels (no measurement)")
     return ap.parse_args(argv)
@@ -187,10 +190,18 @@ def bench_retrieval(args, rank, world):
     metric = sehip.METRIC_COSINE if args.metric == "cosine" else sehip.METRIC_EUCLID
     # SURVEY.md 8d synthetic features.  Weak scaling: every rank evaluates its OWN feature file of the same shape
     # (rank r: seed r), i.e. N independent `evaluate_retrieval` jobs -- identical work per rank, no data-path collective.
-    rng = np.random.default_rng(rank)
+    strong = args.scaling == "strong" and world > 1
+    rng = np.random.default_rng(0 if strong else rank)
     feats_h = rng.standard_normal((n, d)).astype(np.float32)
     gallery0 = torch.from_numpy(feats_h).cuda()
-    if q == n:
+    qrows = None
+    if strong:
+        # ONE feature set: rank r ranks its shard of the query rows against the whole (replicated) gallery -- SURVEY.md 8e row 2
+        from sharded_retrieval import shard_bounds
+        qrows = shard_bounds(n, world)[rank]
+        q = qrows[1] - qrows[0]
+        queries0 = gallery0[qrows[0]:qrows[1]].clone()
+    elif q == n:
         queries0 = None        # all-pairs within the feature set (the reference's only mode): symmetric kernel
     else:
         qrng = np.random.default_rng(100 + rank)
@@ -228,7 +239,7 @@ def bench_retrieval(args, rank, world):
     elapsed = max_over_ranks(time.perf_counter() - t0, world, "cuda")
     kms = timer.avg_ms()
 
-    pairs_per_step = float(q) * n * world
+    pairs_per_step = float(n) * n if strong else float(q) * n * world
     value = pairs_per_step * args.steps / elapsed / 1e6
     # algorithmic bytes / flops per launch
     pd_bytes, pd_full, pd_exec, pd_floor = pdist_cost_model(q, n, d, symmetric=queries0 is None)
@@ -265,11 +276,12 @@ def bench_retrieval(args, rank, world):
     out = {
         "metric": "retrieval_Mpairs_per_sec", "value": value, "unit": "Mpairs/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "CIFAR-100-sized retrieval: %d queries/GPU x %d gallery, D=%d, %s, "
                                "normalise + all-pairs distance + full canonical ranking" % (q, n, d, args.metric),
                    "queries_per_gpu": q, "gallery": n, "dim": d,
-                   "parallelism": "%d independent feature sets, one per GPU (no collective)" % world},
+                   "parallelism": ("query rows of ONE feature set sharded %d ways, gallery replicated (no collective)" % world) if strong
+                                  else "%d independent feature sets, one per GPU (no collective)" % world},
         "roofline": roofline, "kernels": kernels,
     }
     if args.verify:
@@ -310,6 +322,38 @@ def bench_metrics(args, rk, reps=3):
     ms = float(np.median(ts))
     return {"ms": ms, "queries": int(q), "ranks_per_query": int(n), "Mranks_per_sec": q * n / ms / 1e3, "rank_GBps": 4.0 * q * n / ms / 1e6,
             "metrics": "P@1..250 (WUP, LCS), whole-list AHP (WUP, LCS), AP; 100 classes", "finite": bool(torch.isfinite(res).all().item())}
+
+
+def bench_topk_all_pairs(args, feats_h, reps=3, k=251):
+    """The fused distance + top-k on the headline problem (se_retrieve_topk, all-pairs: every item query and gallery item): what
+    `evaluate_retrieval.py --clip_ahp K --skip_ap` runs instead of distance matrix + full ranking.  No [Q, N] matrix exists:
+    algorithmic bytes = 4 (Q + N) D + 8 Q k.  Checked against the head of this step's full ranking by the GPU tests
+    (tests/test_gpu_topk.py); here only timed."""
+    import sehip
+    x = torch.from_numpy(feats_h).cuda()
+    if args.metric == "cosine":
+        sehip.normalize_rows_(x)
+        metric, sq = sehip.METRIC_COSINE, None
+    else:
+        metric, sq = sehip.METRIC_EUCLID, sehip.row_sqnorm(x)
+    run = lambda: sehip.retrieve_topk(x, x, k, metric=metric, sqq=sq, sqg=sq)   # noqa: E731
+    d, i = run()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); run(); b.record()
+        torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b))
+    ms = float(np.median(ts))
+    n, dd = feats_h.shape
+    tiles = (n + 127) // 128
+    executed = (tiles * (tiles + 1) // 2) * 128.0 * 128.0 * 2.0 * dd          # upper-triangle tiles, filtered in both orientations
+    self_first = bool((i[:, 0] == torch.arange(n, device="cuda", dtype=torch.int32)).all().item()) if args.metric == "cosine" else None
+    return {"ms": ms, "k": k, "Mpairs_per_sec": float(n) * n / ms / 1e3, "algorithmic_GB": (8.0 * n * dd + 8.0 * n * k) / 1e9,
+            "flops_executed": executed, "TFLOPs_executed": executed / 1e9 / ms, "frac_mfma_f32": executed / 1e9 / ms / MFMA_F32_PEAK_TFLOPS,
+            "vs_distance_plus_ranking": "replaces pairwise_dist + rank_rows of the step above when only the first k ranks are consumed",
+            "every_query_finds_itself_first": self_first}
 
 
 def verify_last_step(last, pd, rk, metric, world):
@@ -437,15 +481,19 @@ def bench_sharded_gallery(args, rank, world, reps=2):
 # ---------------------------------------------------------------------------------------------
 
 def bench_dry(args, rank, world):
+    """Every leg of the real line on CPU / gloo with oracle stand-ins for the kernels and tiny shapes: the launcher, the process
+    group, the sharding arithmetic and the collectives of `sharded_gallery` (gallery shards + all-gather + merge), the
+    query-sharded full ranking, and the DP training step (bucketed all-reduce of the flat gradient) -- no measurement."""
     from oracle import retrieval_oracle as ro
     import sharded_retrieval as sr
+    import engine
     rng = np.random.default_rng(0)
     gallery = rng.standard_normal((64 * world, 16)).astype(np.float32)
     queries = torch.from_numpy(gallery[:8].copy())
     lo, hi = sr.shard_bounds(len(gallery), world)[rank]
 
-    def local_topk(q, g, k, off):
-        d, i = ro.canon_topk_rows(ro.canon_pdist(q.numpy(), g.numpy(), ro.METRIC_COSINE), k, col_offset=off)
+    def local_topk(q, g, k, off, kblocks=None):
+        d, i = ro.canon_topk_rows(ro.canon_pdist(q.numpy(), g.numpy(), ro.METRIC_COSINE, kblocks=kblocks), k, col_offset=off)
         return torch.from_numpy(d), torch.from_numpy(i)
 
     def merge(d, i):
@@ -454,12 +502,42 @@ def bench_dry(args, rank, world):
 
     barrier_sync(world, dry=True)
     t0 = time.perf_counter()
+    # ---- sharded_gallery: every rank holds 1 / world of the gallery; per-shard top-k -> all-gather -> merge ----
     d, i = sr.sharded_topk(queries, torch.from_numpy(gallery[lo:hi]), 5, lo, local_topk=local_topk, merge=merge)
+    want = ro.canon_topk_rows(ro.canon_pdist(gallery[:8], gallery, ro.METRIC_COSINE), 5)[1]
+    sharded = {"parts": world, "matches_unsharded": bool(np.array_equal(i.numpy(), want))}
+    # ---- retrieval, strong scaling: the query rows of ONE feature set sharded, gallery replicated, no data-path collective ----
+    q0, q1 = sr.shard_bounds(len(gallery), world)[rank]
+    mine = ro.canon_rank_rows(ro.canon_pdist(gallery[q0:q1], gallery, ro.METRIC_COSINE)) if q1 > q0 else np.zeros((0, len(gallery)), np.int32)
+    sums = torch.tensor([float(mine.astype(np.int64).sum()), float(mine.shape[0])], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(sums)
+    full = ro.canon_rank_rows(ro.canon_pdist(gallery, gallery, ro.METRIC_COSINE))
+    retrieval = {"query_shards": world, "rows_ranked": int(sums[1].item()),
+                 "matches_unsharded": bool(np.array_equal(mine, full[q0:q1])) and int(sums[1].item()) == len(gallery)
+                 and float(sums[0].item()) == float(full.astype(np.int64).sum())}
+    # ---- train: DP step (one process per rank, flat gradient buffer, bucketed all-reduce, update); strong scaling splits ONE batch ----
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.Tanh(), torch.nn.Linear(16, 4))
+    tr = engine.Trainer(model, {"o": (lambda y, x: ((x - y) ** 2).sum(-1), 1.0)}, {}, lr=0.05, momentum=0.9, clipnorm=10.0,
+                        autocast_dtype=None, bucket_bytes=256)
+    g = torch.Generator().manual_seed(1)
+    per = 4
+    X, Y = torch.randn(per * world, 6, generator=g), torch.randn(per * world, 4, generator=g)
+    logs = {}
+    for _ in range(2):
+        tr.train_step(X[rank * per:(rank + 1) * per], Y[rank * per:(rank + 1) * per], logs)
+    csum = torch.tensor([float(tr.flat.flat_p.double().sum())], dtype=torch.float64)
+    lo_hi = torch.stack([csum, -csum])
+    if world > 1:
+        dist.all_reduce(lo_hi, op=dist.ReduceOp.MAX)
+    train = {"ranks": world, "global_batch": per * world, "replicas_identical": bool(abs(float(lo_hi[0]) + float(lo_hi[1])) < 1e-9),
+             "loss_finite": bool(np.isfinite(float(torch.as_tensor(logs["loss"]))))}
     barrier_sync(world, dry=True)
     dt = max_over_ranks(time.perf_counter() - t0, world, "cpu")
-    want = ro.canon_topk_rows(ro.canon_pdist(gallery[:8], gallery, ro.METRIC_COSINE), 5)[1]
-    return {"metric": "dry_run", "value": 0.0, "unit": "none", "n_gpus": world, "dry": True, "steps": 1, "warmup": 0,
-            "ms_per_step": dt * 1e3, "sharded_topk_matches_unsharded": bool(np.array_equal(i.numpy(), want)), "data": "synthetic"}
+    return {"metric": "dry_run", "value": 0.0, "unit": "none", "n_gpus": world, "dry": True, "steps": 1, "warmup": 0, "scaling": args.scaling,
+            "ms_per_step": dt * 1e3, "sharded_topk_matches_unsharded": sharded["matches_unsharded"], "sharded_gallery": sharded,
+            "retrieval": retrieval, "train": train, "data": "synthetic"}
 
 
 # ---------------------------------------------------------------------------------------------
@@ -475,7 +553,7 @@ def main(argv=None):
         out = bench_dry(args, rank, world)
     elif args.workload == "train":
         from train_bench import bench_train
-        out = bench_train(args, rank, world)
+        out = bench_train(args, rank, world, scaling=args.scaling)
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             from train_bench import cpu_baseline_train
             out["cpu_baseline"] = cpu_baseline_train(args)
@@ -491,14 +569,23 @@ def main(argv=None):
         leg("hierarchical_precision", lambda: bench_metrics(args, rk))
         del rk
         torch.cuda.empty_cache()
+        leg("retrieve_topk", lambda: bench_topk_all_pairs(args, feats_h))
+        torch.cuda.empty_cache()
         if args.with_sharded:
             leg("sharded_gallery", lambda: bench_sharded_gallery(args, rank, world))
             torch.cuda.empty_cache()
         if args.with_train:
             from train_bench import bench_train
-            leg("train", lambda: bench_train(args, rank, world))
+            sc = args.scaling
+            # configs[1]: ResNet-110-fc, batch 128.  The product default for the CIFAR nets is fp32 + HIP-graph replay (bf16 autocast only
+            # adds cast launches to 16-64-channel convolutions); BASELINE says bf16, so that number stands beside it.
+            leg("train", lambda: bench_train(args, rank, world, scaling=sc))
+            leg("train_bf16", lambda: bench_train(args, rank, world, dtype="bf16", scaling=sc))
+            if "error" not in out["train"] and "error" not in out["train_bf16"]:
+                out["train"]["bf16_images_per_sec"] = out["train_bf16"]["value"]
             r50 = argparse.Namespace(**dict(vars(args), arch="resnet-50", batch=64))
-            leg("train_r50", lambda: bench_train(r50, rank, world))
+            leg("train_r50", lambda: bench_train(r50, rank, world, scaling=sc))                            # configs[3]: CUB, 200 classes
+            leg("train_r50_ilsvrc", lambda: bench_train(r50, rank, world, classes=1000, scaling=sc))    # configs[4]: C = D = 1000
         if rank == 0 and world == 1 and not args.no_cpu_baseline:      # reported baselines: rank 0 at N = 1 only, bounded samples
             out["cpu_baseline"] = cpu_baseline_retrieval(args, feats_h)
             if args.with_train and "error" not in out["train"]:

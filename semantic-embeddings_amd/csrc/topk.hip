@@ -675,7 +675,7 @@ __device__ __forceinline__ bool topk_wave_select(const uint2 *__restrict__ lst, 
 
 __global__ __launch_bounds__(TL_WAVES * 64) void topk_lists_wave_kernel(const uint2 *__restrict__ lists, const unsigned *__restrict__ rowcnt, int64_t cap,
                                                                        int64_t Q, int64_t col_offset, int k, float *__restrict__ out_d,
-                                                                       int32_t *__restrict__ out_i)
+                                                                       int32_t *__restrict__ out_i, unsigned *__restrict__ nflag)
 {
     __shared__ uint32_t hist_all[TL_WAVES][256];
     __shared__ uint64_t sel_all[TL_WAVES][TL_SEL];
@@ -685,7 +685,7 @@ __global__ __launch_bounds__(TL_WAVES * 64) void topk_lists_wave_kernel(const ui
     for (int64_t row = (int64_t)blockIdx.x * TL_WAVES + wave; row < Q; row += (int64_t)gridDim.x * TL_WAVES) {
         const unsigned total = rowcnt[row];
         if (total < (unsigned)k || total > (unsigned)cap) {
-            if (lane == 0) out_i[row * k] = TK_REDO;
+            if (lane == 0) { out_i[row * k] = TK_REDO; atomicAdd(&nflag[1], 1u); }
             continue;
         }
         const uint2 *lst = lists + row * cap;
@@ -695,23 +695,24 @@ __global__ __launch_bounds__(TL_WAVES * 64) void topk_lists_wave_kernel(const ui
             else if (total <= 1024u) done = topk_wave_select<16>(lst, (int)total, k, col_offset, hist, sel, out_d + row * k, out_i + row * k, lane);
             else done = topk_wave_select<32>(lst, (int)total, k, col_offset, hist, sel, out_d + row * k, out_i + row * k, lane);
         }
-        if (!done && lane == 0) out_i[row * k] = TK_WIDE;
+        if (!done && lane == 0) { out_i[row * k] = TK_WIDE; atomicAdd(&nflag[0], 1u); }
     }
 }
 
 // candidates of every query -> canonical top-k; queries whose list missed [k, cap] are flagged for the exact kernel
 __global__ __launch_bounds__(TK_THREADS) void topk_lists_kernel(const uint2 *__restrict__ lists, const unsigned *__restrict__ rowcnt, int64_t cap,
                                                                 int64_t Q, int64_t col_offset, int k, float *__restrict__ out_d,
-                                                                int32_t *__restrict__ out_i, int only_wide)
+                                                                int32_t *__restrict__ out_i, int only_wide, unsigned *__restrict__ nflag)
 {
     extern __shared__ __attribute__((aligned(16))) uint64_t tl_lds64[];
     uint64_t *cand = tl_lds64;
     const int tid = threadIdx.x;
+    if (only_wide && nflag[0] == 0) return;                        // nothing was handed over: the usual case
     for (int64_t row = blockIdx.x; row < Q; row += gridDim.x) {
         if (only_wide && out_i[row * k] != TK_WIDE) continue;      // behind topk_lists_wave_kernel: only the queries it handed over (uniform)
         const unsigned total = rowcnt[row];
         if (total < (unsigned)k || total > (unsigned)cap) {
-            if (tid == 0) out_i[row * k] = TK_REDO;
+            if (tid == 0) { out_i[row * k] = TK_REDO; atomicAdd(&nflag[1], 1u); }
             continue;
         }
         const uint2 *lst = lists + row * cap;
@@ -751,9 +752,10 @@ __global__ __launch_bounds__(TK_THREADS) void topk_fallback_kernel(const float *
                                                                    int64_t ldg, const float *__restrict__ sqq, const float *__restrict__ sqg,
                                                                    int64_t Q, int N, int D, KBlocks kbs, int64_t col_offset, int k, int P,
                                                                    float *__restrict__ scratch, float *__restrict__ out_d,
-                                                                   int32_t *__restrict__ out_i)
+                                                                   int32_t *__restrict__ out_i, const unsigned *__restrict__ nflag)
 {
     extern __shared__ __attribute__((aligned(16))) uint64_t tk_lds64[];
+    if (nflag[1] == 0) return;                                     // no query was flagged: the usual case
     float *drow = scratch + (int64_t)blockIdx.x * N;
     for (int64_t row = blockIdx.x; row < Q; row += gridDim.x) {
         if (out_i[row * k] != TK_REDO) continue;       // uniform per workgroup
@@ -810,7 +812,7 @@ static FusedLayout fused_layout(int64_t q, int64_t n, const FusedPlan &p)
     L.qt = qt;
     L.off_tau = 0;
     L.off_cnt = align256(qt * 4);
-    L.off_gm = L.off_cnt + align256(qt * 4);
+    L.off_gm = L.off_cnt + align256(qt * 4 + 16);       // [qt] candidate counts + 4 control words (flagged-query counters)
     L.off_lists = L.off_gm + align256(qt * p.G * 4);
     L.off_scratch = L.off_lists + align256(qt * p.cap * 8);
     L.total = L.off_scratch + align256((int64_t)FB_GRID * n * 4);
@@ -876,7 +878,8 @@ extern "C" int se_retrieve_topk(const float *queries, int64_t ldq, const float *
         const int64_t rows = (q - q0 < L.qt) ? (q - q0) : L.qt;
         const float *qs = queries + q0 * ldq;
         const float *sq = sqq ? sqq + q0 : nullptr;
-        SE_HIP_CHECK(hipMemsetAsync(rowcnt, 0, (size_t)rows * 4, s));
+        unsigned *nflag = rowcnt + rows;                               // [0] queries handed to the workgroup-wide sort, [1] to the exact kernel
+        SE_HIP_CHECK(hipMemsetAsync(rowcnt, 0, (size_t)rows * 4 + 16, s));
         FusedArgs fa = {gm, p.G, tau, rowcnt, lists, p.cap, p.step};
         int rc = launch_fused_pass(EPI_GROUPMIN, gallery, p.step * ldg, qs, ldq, sqg, sq, p.S, rows, d, metric, kbs, multi, fa, s);
         if (rc != SE_OK) return rc;
@@ -890,12 +893,12 @@ extern "C" int se_retrieve_topk(const float *queries, int64_t ldq, const float *
         if (k <= 256 && !tuning_env("SE_TOPK_NOWAVE")) {     // one wave per query (radix select + small sort); hands the rest on
             const int64_t wgrid = (rows + TL_WAVES - 1) / TL_WAVES < 4096 ? (rows + TL_WAVES - 1) / TL_WAVES : 4096;
             hipLaunchKernelGGL(topk_lists_wave_kernel, dim3((unsigned)wgrid), dim3(TL_WAVES * 64), 0, s, lists, rowcnt, (int64_t)p.cap, rows,
-                               col_offset, k, out_d + q0 * k, out_i + q0 * k);
+                               col_offset, k, out_d + q0 * k, out_i + q0 * k, nflag);
             SE_LAUNCH_CHECK();
             only_wide = 1;
         }
         hipLaunchKernelGGL(topk_lists_kernel, dim3((unsigned)grid), dim3(TK_THREADS), lds_lists, s, lists, rowcnt, (int64_t)p.cap, rows,
-                           col_offset, k, out_d + q0 * k, out_i + q0 * k, only_wide);
+                           col_offset, k, out_d + q0 * k, out_i + q0 * k, only_wide, nflag);
         SE_LAUNCH_CHECK();
         if (kTuning && tuning_env("SE_TOPK_VERBOSE")) {   // -DSE_TUNING build only: synchronises and reports how the lists came out
             SE_HIP_CHECK(hipStreamSynchronize(s));
@@ -911,10 +914,10 @@ extern "C" int se_retrieve_topk(const float *queries, int64_t ldq, const float *
         const int64_t fgrid = rows < FB_GRID ? rows : FB_GRID;
         if (metric == SE_METRIC_COSINE)
             hipLaunchKernelGGL(topk_fallback_kernel<SE_METRIC_COSINE>, dim3((unsigned)fgrid), dim3(TK_THREADS), lds_sel, s, qs, ldq, gallery, ldg, sq, sqg,
-                               rows, (int)n, (int)d, kbs, col_offset, k, P, scratch, out_d + q0 * k, out_i + q0 * k);
+                               rows, (int)n, (int)d, kbs, col_offset, k, P, scratch, out_d + q0 * k, out_i + q0 * k, nflag);
         else
             hipLaunchKernelGGL(topk_fallback_kernel<SE_METRIC_EUCLID>, dim3((unsigned)fgrid), dim3(TK_THREADS), lds_sel, s, qs, ldq, gallery, ldg, sq, sqg,
-                               rows, (int)n, (int)d, kbs, col_offset, k, P, scratch, out_d + q0 * k, out_i + q0 * k);
+                               rows, (int)n, (int)d, kbs, col_offset, k, P, scratch, out_d + q0 * k, out_i + q0 * k, nflag);
         SE_LAUNCH_CHECK();
     }
     return SE_OK;

@@ -309,6 +309,26 @@ def test_bench_gpus_flag_spawns_that_many_ranks():
     assert rec["n_gpus"] == 2 and rec["dry"] is True and rec["sharded_topk_matches_unsharded"] is True
 
 
+def test_bench_dry_run_with_8_ranks_completes_every_leg():
+    """`bench.py --gpus 8 --dry --scaling strong` (gloo, 8 ranks on CPU): the launcher, the 8-way gallery shards + all-gather + merge
+    of the `sharded_gallery` leg, the query-sharded ranking and the DP training step all complete and agree with one process."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry", "--scaling", "strong"], env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 8 and rec["dry"] is True and rec["scaling"] == "strong"
+    assert rec["sharded_gallery"] == {"parts": 8, "matches_unsharded": True}
+    assert rec["retrieval"]["query_shards"] == 8 and rec["retrieval"]["rows_ranked"] == 64 * 8 and rec["retrieval"]["matches_unsharded"] is True
+    assert rec["train"]["ranks"] == 8 and rec["train"]["replicas_identical"] is True and rec["train"]["loss_finite"] is True
+
+
 def test_bench_refuses_more_gpus_than_visible():
     import subprocess
     import sys
