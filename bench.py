@@ -366,6 +366,9 @@ def verify_last_step(last, pd, rk, metric, world):
         feats = last["g"].cpu().numpy()
         queries = None if last["q"] is None else last["q"].cpu().numpy()
         ok, detail = verify.verify_retrieval_step(feats, pd, rk, metric, queries=queries)
+        import sehip
+        detail["rank_order_guard_violations"] = sehip.rank_rows_check(pd, rk)       # the library's own audit (se_rank_rows_check), all rows
+        ok = ok and detail["rank_order_guard_violations"] == 0
         detail["seconds"] = time.perf_counter() - t0
     except Exception as e:       # a checker failure must not lose the measurement, but it must show
         ok, detail = False, {"error": "%s: %s" % (type(e).__name__, e)}

@@ -112,10 +112,14 @@ int se_l2norm_bwd(const float *grad, int64_t ldg, const float *xhat, int64_t ldx
  *   acc     [B] f32 out (0/1)
  *   scores  [B, C] f32 out, the similarity / distance matrix           (may be NULL)
  *   best    [B] int32 out, argmax / argmin class (lowest index on ties) (may be NULL)
+ *   workspace: se_nn_accuracy_workspace_bytes(B, C) bytes, 8-byte aligned (0 for small class sets: one workgroup then walks
+ *           all class tiles of its 32 samples; large sets -- C = 1000 -- are cut into class slices whose partial counts meet there)
  */
+int64_t se_nn_accuracy_workspace_bytes(int64_t B, int64_t C);
 int se_nn_accuracy(const float *y_pred, int64_t ldp, const int64_t *labels, const float *emb,
                    int64_t lde, int64_t B, int64_t D, int64_t C, int dot_prod_sim, int k,
-                   float *acc, float *scores, int64_t lds, int32_t *best, se_stream_t stream);
+                   float *acc, float *scores, int64_t lds, int32_t *best, void *workspace,
+                   int64_t workspace_bytes, se_stream_t stream);
 
 /*
  * Label-embedding baseline loss (Sun et al.), forward and backward.
@@ -198,6 +202,20 @@ int se_pairwise_dist(const float *a, int64_t lda, const float *b, int64_t ldb, c
 int64_t se_rank_rows_workspace_bytes(int64_t q, int64_t n);
 int se_rank_rows(const float *pdist, int64_t ldp, int64_t q, int64_t n, void *rank, int idx64,
                  int64_t ldr, void *workspace, int64_t workspace_bytes, se_stream_t stream);
+
+/*
+ * Order guard of se_rank_rows: counts the rows of a finished ranking that violate the canonical order -- along every row
+ * (pdist[rank[r]], rank[r]) must precede (pdist[rank[r + 1]], rank[r + 1]), every index lies in [0, n).  One gather of the
+ * distances through the ranks (~2 ms at 50k x 50k).  se_rank_rows runs the same check by itself behind the first ranking a
+ * process does with its fastest kernel (whose stable order rests on a hardware property the library can probe but the ISA
+ * does not promise) and on every call when SE_RANK_CHECK=1 is set, and re-ranks offending rows with the guaranteed-order
+ * kernel; this entry point lets a caller audit any ranking (np.argsort(pdist, axis=-1, kind='stable') passes it).
+ *   workspace: se_rank_rows_check_workspace_bytes() bytes; *bad_rows_host (HOST pointer) receives the count; synchronises.
+ */
+int64_t se_rank_rows_check_workspace_bytes(void);
+int se_rank_rows_check(const float *pdist, int64_t ldp, int64_t q, int64_t n, const void *rank, int idx64,
+                       int64_t ldr, void *workspace, int64_t workspace_bytes, int64_t *bad_rows_host,
+                       se_stream_t stream);
 
 /*
  * The k nearest columns of every row of a distance matrix, canonical order, with a global

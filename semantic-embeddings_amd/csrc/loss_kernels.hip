@@ -237,8 +237,12 @@ __device__ __forceinline__ void stage_tile32(float *lds, const float *src, int64
 __global__ __launch_bounds__(64) void nn_accuracy_kernel(
     const float *__restrict__ yp, int64_t ldp, const int64_t *__restrict__ labels,
     const float *__restrict__ emb, int64_t lde, int64_t B, int64_t D, int64_t C, int dot_prod_sim, int k,
-    float *__restrict__ acc_out, float *__restrict__ scores, int64_t lds_, int32_t *__restrict__ best_out)
+    float *__restrict__ acc_out, float *__restrict__ scores, int64_t lds_, int32_t *__restrict__ best_out,
+    int tiles_per_block, uint32_t *__restrict__ part_cnt, unsigned long long *__restrict__ part_best)
 {
+    // grid = (32-sample blocks, class slices of tiles_per_block x 32 classes).  One slice: results are written directly; several
+    // (large class sets -- at ILSVRC size, C = D = 1000, a batch of 64 was TWO waves walking 32 class tiles each: 2.6 ms): every
+    // slice adds its counts / proposes its best class into part_cnt / part_best and nn_accuracy_finish_kernel closes the metric.
     __shared__ __attribute__((aligned(16))) float sA[32 * ACC_LD];
     __shared__ __attribute__((aligned(16))) float sB[32 * ACC_LD];
     __shared__ float sTrue[32], sPn[32], sCn[32];
@@ -292,7 +296,9 @@ __global__ __launch_bounds__(64) void nn_accuracy_kernel(
         best_c[r] = 0x7FFFFFFF;
     }
 
-    for (int64_t c0 = 0; c0 < C; c0 += 32) {
+    const int64_t c_beg = (int64_t)blockIdx.y * tiles_per_block * 32;
+    const int64_t c_end = (c_beg + (int64_t)tiles_per_block * 32 < C) ? c_beg + (int64_t)tiles_per_block * 32 : C;
+    for (int64_t c0 = c_beg; c0 < c_end; c0 += 32) {
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[r] = 0.f;
@@ -360,10 +366,33 @@ __global__ __launch_bounds__(64) void nn_accuracy_kernel(
         }
         const int lr = (r & 3) + 8 * (r >> 2) + 4 * hi;
         if (col == 0 && row0 + lr < B) {
-            acc_out[row0 + lr] = (n_within[r] >= 1 && n_better[r] < k) ? 1.0f : 0.0f;
-            if (best_out) best_out[row0 + lr] = best_c[r];
+            if (gridDim.y == 1) {
+                acc_out[row0 + lr] = (n_within[r] >= 1 && n_better[r] < k) ? 1.0f : 0.0f;
+                if (best_out) best_out[row0 + lr] = best_c[r];
+            } else {
+                atomicAdd(&part_cnt[2 * (row0 + lr)], (uint32_t)n_better[r]);
+                atomicAdd(&part_cnt[2 * (row0 + lr) + 1], (uint32_t)n_within[r]);
+                if (best_c[r] != 0x7FFFFFFF) {
+                    // best class of this slice as one ordered word: score (larger = better), then LOWER class index
+                    float v = best_v[r];
+                    if (v == 0.f) v = 0.f;                                     // -0 ties with +0
+                    uint32_t u = __float_as_uint(v);
+                    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);            // ascending with the value
+                    if (!dot_prod_sim) u = ~u;                                 // distances: smaller is better
+                    atomicMax(&part_best[row0 + lr], ((unsigned long long)u << 32) | (uint32_t)(0x7FFFFFFF - best_c[r]));
+                }
+            }
         }
     }
+}
+
+__global__ __launch_bounds__(256) void nn_accuracy_finish_kernel(const uint32_t *__restrict__ part_cnt, const unsigned long long *__restrict__ part_best,
+                                                                int64_t B, int k, float *__restrict__ acc_out, int32_t *__restrict__ best_out)
+{
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= B) return;
+    acc_out[r] = (part_cnt[2 * r + 1] >= 1u && part_cnt[2 * r] < (uint32_t)k) ? 1.0f : 0.0f;
+    if (best_out) best_out[r] = 0x7FFFFFFF - (int32_t)(uint32_t)(part_best[r] & 0xFFFFFFFFull);
 }
 
 static inline bool aligned16(const void *p) { return (((uintptr_t)p) & 15) == 0; }
@@ -425,18 +454,48 @@ extern "C" int se_cosine_loss_bwd(const void *x, int x_dtype, int64_t ldx, const
     return SE_OK;
 }
 
+// class tiles (of 32) one workgroup walks: all of them while that still fills the chip or the class set is small, else slices
+static int nn_acc_tiles_per_block(int64_t B, int64_t C)
+{
+    const int64_t tiles = (C + 31) / 32, sample_blocks = (B + 31) / 32;
+    if (tiles <= 4 || sample_blocks * 1 >= 1024) return (int)tiles;
+    int64_t slices = 1024 / sample_blocks;                  // aim for ~1024 waves
+    if (slices > tiles) slices = tiles;
+    return (int)((tiles + slices - 1) / slices);
+}
+
+extern "C" int64_t se_nn_accuracy_workspace_bytes(int64_t B, int64_t C)
+{
+    if (B <= 0 || C <= 0) return 0;
+    return nn_acc_tiles_per_block(B, C) * 32 >= C ? 0 : B * 16;      // per sample: two counters + one ordered word
+}
+
 extern "C" int se_nn_accuracy(const float *y_pred, int64_t ldp, const int64_t *labels, const float *emb,
                               int64_t lde, int64_t B, int64_t D, int64_t C, int dot_prod_sim, int k,
-                              float *acc, float *scores, int64_t lds, int32_t *best, se_stream_t stream)
+                              float *acc, float *scores, int64_t lds, int32_t *best, void *workspace, int64_t workspace_bytes,
+                              se_stream_t stream)
 {
     if (B < 0 || D <= 0 || C <= 0) return fail(SE_ERR_INVALID, "se_nn_accuracy: bad shape");
     if (B == 0) return SE_OK;
     if (!y_pred || !labels || !emb || !acc) return fail(SE_ERR_INVALID, "se_nn_accuracy: null pointer");
     if (ldp < D || lde < D || (scores && lds < C)) return fail(SE_ERR_INVALID, "se_nn_accuracy: leading dimension too small");
     if (k < 1) k = 1;
-    hipLaunchKernelGGL(nn_accuracy_kernel, dim3((unsigned)((B + 31) / 32)), dim3(64), 0, (hipStream_t)stream,
-                       y_pred, ldp, labels, emb, lde, B, D, C, dot_prod_sim, k, acc, scores, lds, best);
+    const int64_t need = se_nn_accuracy_workspace_bytes(B, C);
+    if (need > 0 && (!workspace || workspace_bytes < need || (((uintptr_t)workspace) & 7)))
+        return fail(SE_ERR_WORKSPACE, "se_nn_accuracy: needs %lld bytes of 8-byte aligned workspace (se_nn_accuracy_workspace_bytes)", (long long)need);
+    hipStream_t s = (hipStream_t)stream;
+    const int tpb = nn_acc_tiles_per_block(B, C);
+    const int64_t slices = ((C + 31) / 32 + tpb - 1) / tpb;
+    unsigned long long *part_best = (unsigned long long *)workspace;
+    uint32_t *part_cnt = need > 0 ? (uint32_t *)((char *)workspace + B * 8) : nullptr;
+    if (need > 0) SE_HIP_CHECK(hipMemsetAsync(workspace, 0, (size_t)need, s));
+    hipLaunchKernelGGL(nn_accuracy_kernel, dim3((unsigned)((B + 31) / 32), (unsigned)slices), dim3(64), 0, s,
+                       y_pred, ldp, labels, emb, lde, B, D, C, dot_prod_sim, k, acc, scores, lds, best, tpb, part_cnt, part_best);
     SE_LAUNCH_CHECK();
+    if (slices > 1) {
+        hipLaunchKernelGGL(nn_accuracy_finish_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, s, part_cnt, part_best, B, k, acc, best);
+        SE_LAUNCH_CHECK();
+    }
     return SE_OK;
 }
 

@@ -1086,14 +1086,85 @@ __global__ __launch_bounds__(RR_THREADS) void rank_order_probe_kernel(uint32_t *
     if (lane == 0) { atomicAdd(&res[0], bad); atomicAdd(&res[1], 1u); }
 }
 
+// ---- order guard for the hardware-ordered ranking ---------------------------------------------------------
+// The probe above is evidence, not a guarantee (the ISA does not promise the lane order of same-address returning adds).  The
+// guard checks a finished ranking directly: along every row (key[rank[r]], rank[r]) < (key[rank[r + 1]], rank[r + 1]) under the
+// canonical order, every index in range.  A ranking produced by a stable sort that lost its stability is still a permutation,
+// so this one pass (one gather of the distances through the ranks) detects exactly the failure mode.  Offending rows are listed
+// (bad[0] = count, bad[1 + i] = row); se_rank_rows re-ranks them with the ballot kernel and stops using the hardware-ordered
+// kernel on that device.  Cost at 50k x 50k: ~2 ms next to the 9.5 ms ranking -- run on the first hardware-ordered call of a
+// process and on every call under SE_RANK_CHECK=1; se_rank_rows_check exposes it (bench.py reports its verdict).
+constexpr int RC_THREADS = 512, RC_PER = 8;
+template <bool IDX64>
+__global__ __launch_bounds__(RC_THREADS) void rank_check_kernel(const float *__restrict__ pdist, int64_t ldp, int64_t Q, int N, const void *rank,
+                                                               int64_t ldr, uint32_t *__restrict__ bad, int cap)
+{
+    __shared__ uint32_t wg_bad;
+    for (int64_t row = blockIdx.x; row < Q; row += gridDim.x) {
+        const float *drow = pdist + row * ldp;
+        if (threadIdx.x == 0) wg_bad = 0;
+        __syncthreads();
+        uint32_t mine = 0;
+        for (int r0 = threadIdx.x * RC_PER; r0 < N; r0 += RC_THREADS * RC_PER) {
+            uint32_t pk = 0, pi = 0;
+#pragma unroll
+            for (int e = 0; e <= RC_PER; e++) {            // RC_PER consecutive ranks + the first of the next thread's
+                const int r = r0 + e;
+                if (r >= N) break;
+                const int64_t iv = IDX64 ? ((const int64_t *)rank)[row * ldr + r] : (int64_t)((const int32_t *)rank)[row * ldr + r];
+                const bool in = iv >= 0 && iv < N;
+                const uint32_t i = in ? (uint32_t)iv : 0u;
+                const uint32_t k = canon_key(drow[i]);
+                if (!in) mine = 1;
+                if (e > 0 && !(pk < k || (pk == k && pi < i))) mine = 1;
+                pk = k; pi = i;
+            }
+        }
+        if (mine) atomicOr(&wg_bad, 1u);
+        __syncthreads();
+        if (threadIdx.x == 0 && wg_bad) {
+            const uint32_t slot = atomicAdd(&bad[0], 1u);
+            if ((int)slot < cap) bad[1 + slot] = (uint32_t)row;
+        }
+        __syncthreads();
+    }
+}
+
+// -DSE_TUNING build, SE_RANK_INJECT=1: swap two adjacent ranks in every 7th row (what a lost stability would look like) so that
+// the guard's detection and repair can be tested
+__global__ void rank_inject_kernel(void *rank, int idx64, int64_t ldr, int64_t Q, int N)
+{
+    const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 7 + 3;
+    if (row >= Q || N < 4) return;
+    const int r = (int)((row * 37) % (N - 1));
+    if (idx64) { int64_t *p = (int64_t *)rank + row * ldr + r; const int64_t t = p[0]; p[0] = p[1]; p[1] = t; }
+    else { int32_t *p = (int32_t *)rank + row * ldr + r; const int32_t t = p[0]; p[0] = p[1]; p[1] = t; }
+}
+
+constexpr int RC_CAP = 1022;   // listed rows (workspace: 256 B of probe / detector words + 4 KB of list)
+
+static int rank_check_launch(const float *pdist, int64_t ldp, int64_t q, int n, const void *rank, int idx64, int64_t ldr, uint32_t *bad, int cap,
+                             hipStream_t s)
+{
+    SE_HIP_CHECK(hipMemsetAsync(bad, 0, 4, s));
+    const int64_t grid = q < 2048 ? q : 2048;
+    if (idx64) hipLaunchKernelGGL(rank_check_kernel<true>, dim3((unsigned)grid), dim3(RC_THREADS), 0, s, pdist, ldp, q, n, rank, ldr, bad, cap);
+    else hipLaunchKernelGGL(rank_check_kernel<false>, dim3((unsigned)grid), dim3(RC_THREADS), 0, s, pdist, ldp, q, n, rank, ldr, bad, cap);
+    SE_LAUNCH_CHECK();
+    return SE_OK;
+}
+
+static std::atomic<int> rr_hw_state[64];   // per device: 0 unknown, 1 verified, -1 refuted (zero-initialised; two threads racing on the
+                                           // probe both run it on their own workspace and store the same verdict)
+static std::atomic<int> rr_checked[64];    // per device: the guard has run once behind a hardware-ordered ranking
+
 // 1 = the hardware-ordered kernel may be used on the current device, 0 = it may not.  The first call per device
 // runs the probe (needs 256 bytes of caller workspace, synchronises the stream once); SE_RANK_SAFE=1 forces 0.
 static int rank_hw_order_ok(void *workspace, int64_t workspace_bytes, hipStream_t s)
 {
     static const bool forced_safe = getenv("SE_RANK_SAFE") != nullptr;
     if (forced_safe) return 0;
-    static std::atomic<int> state[64];   // per device: 0 unknown, 1 verified, -1 refuted (zero-initialised; two threads racing here
-                                         // both run the probe on their own workspace and store the same verdict)
+    std::atomic<int> *state = rr_hw_state;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
     if (state[dev].load(std::memory_order_acquire) == 0) {
@@ -1116,7 +1187,7 @@ static int rank_hw_order_ok(void *workspace, int64_t workspace_bytes, hipStream_
 extern "C" int64_t se_rank_rows_workspace_bytes(int64_t q, int64_t n)
 {
     if (q <= 0 || n <= 0) return 0;
-    if (!rank_use_tiled(n)) return 256;   // register-resident kernel: only the first-use capability probe writes here
+    if (!rank_use_tiled(n)) return 256 + 4 * (RC_CAP + 2);   // register-resident kernel: capability probe / detector words + the order guard's row list
     return (int64_t)rank_grid(q) * 4 * rank_npad(n) * (int64_t)sizeof(uint32_t);
 }
 
@@ -1131,13 +1202,62 @@ extern "C" int se_rank_rows(const float *pdist, int64_t ldp, int64_t q, int64_t 
         const int items = (int)((n + RR_THREADS - 1) / RR_THREADS);
         const bool hw = rank_hw_order_ok(workspace, workspace_bytes, s) != 0;
         void *scratch = (workspace && workspace_bytes >= 256) ? workspace : nullptr;
-#define SE_RR_CASE(I) if (items <= I) return launch_rank_reg<I>(pdist, ldp, q, (int)n, rank, idx64, ldr, hw, scratch, s);
+        // order guard (see rank_check_kernel): behind the first hardware-ordered ranking of a process and under SE_RANK_CHECK=1
+        int dev = 0;
+        const bool have_dev = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64;
+        static const bool check_always = getenv("SE_RANK_CHECK") != nullptr && getenv("SE_RANK_CHECK")[0] != '0';
+        const bool guard = hw && have_dev && workspace && workspace_bytes >= 256 + 4 * (RC_CAP + 2) &&
+                           (check_always || rr_checked[dev].load(std::memory_order_acquire) == 0);
+        int rc = SE_ERR_INVALID;
+#define SE_RR_CASE(I) if (rc == SE_ERR_INVALID && items <= I) rc = launch_rank_reg<I>(pdist, ldp, q, (int)n, rank, idx64, ldr, hw, scratch, s);
 #if SE_RR_THREADS == 512
         SE_RR_CASE(2) SE_RR_CASE(8) SE_RR_CASE(20) SE_RR_CASE(40) SE_RR_CASE(64) SE_RR_CASE(80) SE_RR_CASE(98) SE_RR_CASE(104)
 #else
         SE_RR_CASE(2) SE_RR_CASE(6) SE_RR_CASE(14) SE_RR_CASE(28) SE_RR_CASE(44) SE_RR_CASE(56) SE_RR_CASE(66) SE_RR_CASE(70)
 #endif
 #undef SE_RR_CASE
+        if (rc != SE_OK || !guard) return rc;
+        if (kTuning && tuning_env("SE_RANK_INJECT")) {
+            hipLaunchKernelGGL(rank_inject_kernel, dim3((unsigned)((q / 7 + 256) / 256)), dim3(256), 0, s, rank, idx64, ldr, q, (int)n);
+            SE_LAUNCH_CHECK();
+        }
+        uint32_t *bad = (uint32_t *)((char *)workspace + 256);
+        if (const int rc2 = rank_check_launch(pdist, ldp, q, (int)n, rank, idx64, ldr, bad, RC_CAP, s)) return rc2;
+        uint32_t h[RC_CAP + 1];
+        SE_HIP_CHECK(hipStreamSynchronize(s));
+        SE_HIP_CHECK(hipMemcpy(h, bad, sizeof(uint32_t), hipMemcpyDeviceToHost));
+        rr_checked[dev].store(1, std::memory_order_release);
+        if (h[0] == 0) return SE_OK;
+        // the hardware-ordered ranking broke its own invariant: never use it again on this device, repair with the ballot kernel
+        rr_hw_state[dev].store(-1, std::memory_order_release);
+        fprintf(stderr, "[se_rank_rows] order guard: %u of %lld rows out of canonical order behind the hardware-ordered kernel -- re-ranking them "
+                        "with the ballot kernel; device %d uses the ballot kernel from now on\n", h[0], (long long)q, dev);
+        const uint32_t nbad = h[0];
+        if (nbad > (uint32_t)RC_CAP) {   // more than the list holds: redo the whole call
+#define SE_RR_CASE(I) if (items <= I) return launch_rank_reg<I>(pdist, ldp, q, (int)n, rank, idx64, ldr, false, scratch, s);
+#if SE_RR_THREADS == 512
+            SE_RR_CASE(2) SE_RR_CASE(8) SE_RR_CASE(20) SE_RR_CASE(40) SE_RR_CASE(64) SE_RR_CASE(80) SE_RR_CASE(98) SE_RR_CASE(104)
+#else
+            SE_RR_CASE(2) SE_RR_CASE(6) SE_RR_CASE(14) SE_RR_CASE(28) SE_RR_CASE(44) SE_RR_CASE(56) SE_RR_CASE(66) SE_RR_CASE(70)
+#endif
+#undef SE_RR_CASE
+        }
+        SE_HIP_CHECK(hipMemcpy(h + 1, bad + 1, nbad * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        const size_t esz = idx64 ? 8 : 4;
+        for (uint32_t i = 0; i < nbad; i++) {
+            const int64_t row = h[1 + i];
+            void *rrow = (char *)rank + (size_t)row * (size_t)ldr * esz;
+            int rc3 = SE_ERR_INVALID;
+#define SE_RR_CASE(I) if (rc3 == SE_ERR_INVALID && items <= I) rc3 = launch_rank_reg<I>(pdist + row * ldp, ldp, 1, (int)n, rrow, idx64, ldr, false, nullptr, s);
+#if SE_RR_THREADS == 512
+            SE_RR_CASE(2) SE_RR_CASE(8) SE_RR_CASE(20) SE_RR_CASE(40) SE_RR_CASE(64) SE_RR_CASE(80) SE_RR_CASE(98) SE_RR_CASE(104)
+#else
+            SE_RR_CASE(2) SE_RR_CASE(6) SE_RR_CASE(14) SE_RR_CASE(28) SE_RR_CASE(44) SE_RR_CASE(56) SE_RR_CASE(66) SE_RR_CASE(70)
+#endif
+#undef SE_RR_CASE
+            if (rc3 != SE_OK) return rc3;
+        }
+        return SE_OK;
     }
     const int64_t need = (int64_t)rank_grid(q) * 4 * rank_npad(n) * (int64_t)sizeof(uint32_t);
     if (!workspace || workspace_bytes < need) return fail(SE_ERR_WORKSPACE, "se_rank_rows: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)need);
@@ -1150,5 +1270,25 @@ extern "C" int se_rank_rows(const float *pdist, int64_t ldp, int64_t q, int64_t 
         hipLaunchKernelGGL(rank_rows_kernel<false>, dim3((unsigned)rank_grid(q)), dim3(RK_THREADS), lds, s, pdist, ldp, q, (int)n, rank, ldr, (uint32_t *)workspace, rank_npad(n));
     }
     SE_LAUNCH_CHECK();
+    return SE_OK;
+}
+
+extern "C" int64_t se_rank_rows_check_workspace_bytes(void) { return 4 * (RC_CAP + 2); }
+
+extern "C" int se_rank_rows_check(const float *pdist, int64_t ldp, int64_t q, int64_t n, const void *rank, int idx64, int64_t ldr,
+                                  void *workspace, int64_t workspace_bytes, int64_t *bad_rows_host, se_stream_t stream)
+{
+    if (q < 0 || n < 0 || n > 0x7FFFFFFFll) return fail(SE_ERR_INVALID, "se_rank_rows_check: bad shape");
+    if (bad_rows_host) *bad_rows_host = 0;
+    if (q == 0 || n == 0) return SE_OK;
+    if (!pdist || !rank || ldp < n || ldr < n || !bad_rows_host) return fail(SE_ERR_INVALID, "se_rank_rows_check: bad argument");
+    if (!workspace || workspace_bytes < se_rank_rows_check_workspace_bytes()) return fail(SE_ERR_WORKSPACE, "se_rank_rows_check: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    uint32_t *bad = (uint32_t *)workspace;
+    if (const int rc = rank_check_launch(pdist, ldp, q, (int)n, rank, idx64, ldr, bad, RC_CAP, s)) return rc;
+    uint32_t h = 0;
+    SE_HIP_CHECK(hipStreamSynchronize(s));
+    SE_HIP_CHECK(hipMemcpy(&h, bad, sizeof(h), hipMemcpyDeviceToHost));
+    *bad_rows_host = (int64_t)h;
     return SE_OK;
 }

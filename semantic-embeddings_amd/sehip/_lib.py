@@ -21,11 +21,11 @@ TOPK_MAX = 2048
 # every symbol include/sehip.h declares (checked by tests/test_abi.py)
 EXPORTS = (
     "se_version", "se_last_error", "se_build_arch",
-    "se_cosine_loss_fwd", "se_cosine_loss_bwd", "se_l2norm_fwd", "se_l2norm_bwd", "se_nn_accuracy",
+    "se_cosine_loss_fwd", "se_cosine_loss_bwd", "se_l2norm_fwd", "se_l2norm_bwd", "se_nn_accuracy_workspace_bytes", "se_nn_accuracy",
     "se_labelembed_aux_floats", "se_labelembed_loss_fwd", "se_labelembed_loss_bwd",
     "se_devise_aux_floats", "se_devise_loss_fwd", "se_devise_loss_bwd",
     "se_row_sqnorm", "se_normalize_rows", "se_pairwise_dist",
-    "se_rank_rows_workspace_bytes", "se_rank_rows",
+    "se_rank_rows_workspace_bytes", "se_rank_rows", "se_rank_rows_check_workspace_bytes", "se_rank_rows_check",
     "se_topk_rows", "se_topk_merge",
     "se_retrieve_topk_workspace_bytes", "se_retrieve_topk", "se_hierarchical_precision",
     "se_hprec_order_workspace_bytes", "se_hprec_curve_len", "se_hprec_reciprocal_curves",
@@ -75,7 +75,9 @@ def lib():
     L.se_cosine_loss_bwd.argtypes = [vp, c_int, c_i64, vp, vp, c_i64, vp, c_f, c_i64, c_i64, c_i64, vp, c_int, c_i64, vp]
     L.se_l2norm_fwd.argtypes = [vp, c_int, c_i64, c_i64, c_i64, vp, c_i64, vp, vp]
     L.se_l2norm_bwd.argtypes = [vp, c_i64, vp, c_i64, vp, c_i64, c_i64, vp, c_i64, vp]
-    L.se_nn_accuracy.argtypes = [vp, c_i64, vp, vp, c_i64, c_i64, c_i64, c_i64, c_int, c_int, vp, vp, c_i64, vp, vp]
+    L.se_nn_accuracy_workspace_bytes.argtypes = [c_i64, c_i64]
+    L.se_nn_accuracy_workspace_bytes.restype = c_i64
+    L.se_nn_accuracy.argtypes = [vp, c_i64, vp, vp, c_i64, c_i64, c_i64, c_i64, c_int, c_int, vp, vp, c_i64, vp, vp, c_i64, vp]
     L.se_labelembed_aux_floats.argtypes = [c_i64]
     L.se_labelembed_aux_floats.restype = c_i64
     L.se_labelembed_loss_fwd.argtypes = [vp, c_i64, vp, c_i64, vp, c_i64, vp, c_i64, c_i64, c_f, c_f, c_f, vp, vp, vp]
@@ -99,6 +101,9 @@ def lib():
     L.se_rank_rows_workspace_bytes.argtypes = [c_i64, c_i64]
     L.se_rank_rows_workspace_bytes.restype = c_i64
     L.se_rank_rows.argtypes = [vp, c_i64, c_i64, c_i64, vp, c_int, c_i64, vp, c_i64, vp]
+    L.se_rank_rows_check_workspace_bytes.argtypes = []
+    L.se_rank_rows_check_workspace_bytes.restype = c_i64
+    L.se_rank_rows_check.argtypes = [vp, c_i64, c_i64, c_i64, vp, c_int, c_i64, vp, c_i64, ctypes.POINTER(c_i64), vp]
     L.se_topk_rows.argtypes = [vp, c_i64, c_i64, c_i64, c_i64, c_int, vp, vp, vp]
     L.se_topk_merge.argtypes = [vp, vp, c_int, c_i64, c_int, vp, vp, vp]
     L.se_retrieve_topk_workspace_bytes.argtypes = [c_i64, c_i64, c_i64, c_int]

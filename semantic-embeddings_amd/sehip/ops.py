@@ -15,7 +15,7 @@ from ._lib import (DTYPE_BF16, DTYPE_F32, METRIC_COSINE, METRIC_DOT, METRIC_EUCL
 __all__ = [
     "cosine_embedding_loss", "cosine_loss_forward", "cosine_loss_backward", "l2norm", "nn_accuracy", "labelembed_loss",
     "devise_ranking_loss",
-    "row_sqnorm", "normalize_rows_", "pairwise_dist", "rank_rows", "topk_rows", "topk_merge", "retrieve_topk",
+    "row_sqnorm", "normalize_rows_", "pairwise_dist", "rank_rows", "rank_rows_check", "topk_rows", "topk_merge", "retrieve_topk",
     "hierarchical_precision", "hprec_reciprocal_curves",
     "METRIC_COSINE", "METRIC_EUCLID", "METRIC_DOT",
 ]
@@ -157,9 +157,11 @@ def nn_accuracy(y_pred, labels, embedding, dot_prod_sim=False, k=1, want_scores=
     acc = torch.empty((B,), dtype=torch.float32, device=y_pred.device)
     scores = torch.empty((B, C), dtype=torch.float32, device=y_pred.device) if want_scores else None
     best = torch.empty((B,), dtype=torch.int32, device=y_pred.device) if want_best else None
+    need = int(lib().se_nn_accuracy_workspace_bytes(B, C))
+    ws = torch.empty((need // 8,), dtype=torch.int64, device=y_pred.device) if need else None     # (fresh: the call may be captured in a HIP graph)
     check(lib().se_nn_accuracy(ptr(y_pred), y_pred.stride(0), ptr(labels), ptr(embedding), embedding.stride(0),
                                B, D, C, int(bool(dot_prod_sim)), int(k), ptr(acc), ptr(scores), C, ptr(best),
-                               stream_ptr()), "se_nn_accuracy")
+                               ptr(ws), need, stream_ptr()), "se_nn_accuracy")
     out = (acc,)
     if want_scores:
         out += (scores,)
@@ -333,6 +335,21 @@ def rank_rows(pdist, idx64=False, out=None):
     check(lib().se_rank_rows(ptr(pdist), pdist.stride(0), q, n, ptr(out), int(out.dtype == torch.int64),
                              out.stride(0), ptr(ws), ws.numel(), stream_ptr()), "se_rank_rows")
     return out
+
+
+def rank_rows_check(pdist, rank):
+    """Order guard (``se_rank_rows_check``): number of rows of ``rank`` that are not the canonical ranking of ``pdist`` as far as
+    adjacent entries can tell -- 0 for every output of ``rank_rows``.  Synchronises the stream."""
+    require_gpu(pdist, rank)
+    _f32_rows(pdist, "pdist")
+    if rank.dtype not in (torch.int32, torch.int64) or rank.stride(1) != 1 or rank.shape != pdist.shape:
+        raise SehipError("rank must be an int32 / int64 matrix of pdist's shape with contiguous rows")
+    q, n = pdist.shape
+    ws = torch.empty((int(lib().se_rank_rows_check_workspace_bytes()),), dtype=torch.uint8, device=pdist.device)
+    bad = ctypes.c_int64(0)
+    check(lib().se_rank_rows_check(ptr(pdist), pdist.stride(0), q, n, ptr(rank), int(rank.dtype == torch.int64), rank.stride(0),
+                                   ptr(ws), ws.numel(), ctypes.byref(bad), stream_ptr()), "se_rank_rows_check")
+    return int(bad.value)
 
 
 def topk_rows(pdist, k, col_offset=0):

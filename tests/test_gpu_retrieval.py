@@ -255,6 +255,60 @@ def test_rank_rows_pinned_peel_variants_in_subprocess(peel):
     assert out.returncode == 0 and "peel-ok" in out.stdout, out.stdout
 
 
+def test_rank_order_guard_accepts_rankings_and_counts_violations(sehip):
+    """se_rank_rows_check: 0 for rank_rows' output (int32 and int64, ties / NaN / -0 included), the exact number of rows once
+    adjacent ranks are swapped, out-of-range indices counted too."""
+    rng = np.random.default_rng(12)
+    pd = rng.standard_normal((40, 3000)).astype(np.float32)
+    pd[3] = rng.integers(0, 4, size=3000).astype(np.float32)
+    pd[4, ::5] = np.nan
+    pd[5, ::3] = -0.0
+    pd[5, 1::3] = 0.0
+    pdd = dev(pd)
+    for idx64 in (False, True):
+        rk = sehip.rank_rows(pdd, idx64=idx64)
+        assert sehip.rank_rows_check(pdd, rk) == 0
+        bad = rk.clone()
+        for row, r in ((0, 0), (7, 1499), (39, 2998)):
+            bad[row, r], bad[row, r + 1] = rk[row, r + 1], rk[row, r]
+        bad[20, 100] = 3000                                 # out of range
+        assert sehip.rank_rows_check(pdd, bad) == 4
+    # ties must be in index order: swapping two equal-distance neighbours is a violation as well
+    rk = sehip.rank_rows(pdd)
+    keys = torch.gather(pdd[3:4], 1, rk[3:4].long())[0]
+    r = int(torch.nonzero(keys[1:] == keys[:-1])[0])
+    bad = rk.clone()
+    bad[3, r], bad[3, r + 1] = rk[3, r + 1], rk[3, r]
+    assert sehip.rank_rows_check(pdd, bad) == 1
+
+
+@pytest.mark.parametrize("q", [40, 9000])
+def test_rank_order_guard_repairs_injected_violations_in_subprocess(q):
+    """SE_RANK_INJECT=1 (tuning build) swaps two adjacent ranks in every 7th row behind the hardware-ordered kernel -- what a lost
+    stability would look like.  The guard behind the first ranking of the process must find those rows, re-rank them with the
+    ballot kernel (row list: q = 40; more rows than the list holds -> whole call redone: q = 9000), say so, and leave the
+    canonical ranking; the device then stays on the ballot kernel."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np, torch\n"
+        "sys.path[:0] = %r\n"
+        "import sehip\n"
+        "from oracle import retrieval_oracle as ro\n"
+        "rng = np.random.default_rng(9)\n"
+        "pd = rng.standard_normal((%d, 2500)).astype(np.float32)\n"
+        "got = sehip.rank_rows(torch.from_numpy(pd).cuda()).cpu().numpy()\n"
+        "assert np.array_equal(got, ro.canon_rank_rows(pd))\n"
+        "got = sehip.rank_rows(torch.from_numpy(pd[:50]).cuda(), idx64=True).cpu().numpy()\n"     # second call: ballot kernel, no injection left to repair
+        "assert np.array_equal(got, ro.canon_rank_rows(pd[:50]))\n"
+        "print('guard-ok')\n"
+    ) % ([PKG_DIR, ROOT_DIR], q)
+    env = dict(os.environ, SE_RANK_INJECT="1", SE_RANK_VERBOSE="1", SEHIP_LIB=os.path.join(PKG_DIR, "sehip", "libsehip_tuning.so"))
+    out = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert out.returncode == 0 and "guard-ok" in out.stdout, out.stdout
+    assert "order guard" in out.stdout and "ballot kernel from now on" in out.stdout, out.stdout
+
+
 @pytest.mark.parametrize("n", [300, 5000, 50000])
 def test_rank_rows_special_values(sehip, n):
     """-0.0 ties with +0.0, denormals keep their order, infinities sit at the ends, every NaN (either sign, any payload) is last --
