@@ -149,4 +149,65 @@ def make_keras(floatx="float32"):
         setattr(keras, sub, m)
     keras.backend = K
     keras.callbacks = callbacks
+
+    # ---- keras.utils.Sequence + keras.preprocessing.image.ImageDataGenerator, as far as the reference's datasets/common.py uses
+    #      them for in-memory datasets (TinyDatasetGenerator, datasets/common.py:635-844) [third party: Keras 2.2 = keras_preprocessing
+    #      1.0.x, restated from its documented behaviour: featurewise statistics over (samples, rows, columns); standardize =
+    #      (x - mean) / (std + 1e-6), in place; random_transform = random height / width shift (uniform in +-range * size, bilinear
+    #      scipy.ndimage.affine_transform, mode 'nearest') then random horizontal flip; np.random draws in that order] ----
+    class Sequence(object):
+        def on_epoch_end(self):
+            pass
+
+    mods["keras.utils"].Sequence = Sequence
+    mods["keras.utils"].to_categorical = lambda y, num_classes=None: np.eye(num_classes or int(np.max(y)) + 1, dtype=fx)[np.asarray(y, dtype=np.int64)]
+
+    class ImageDataGenerator(object):
+        def __init__(self, featurewise_center=False, featurewise_std_normalization=False, horizontal_flip=False,
+                     width_shift_range=0.0, height_shift_range=0.0, **unsupported):
+            if unsupported:
+                raise NotImplementedError("ImageDataGenerator stand-in: %s" % sorted(unsupported))
+            self.featurewise_center, self.featurewise_std_normalization = featurewise_center, featurewise_std_normalization
+            self.horizontal_flip, self.width_shift_range, self.height_shift_range = horizontal_flip, width_shift_range, height_shift_range
+            self.mean = self.std = None
+            self.last_transform = None      # (tx rows, ty columns, flip) of the last random_transform (fixture generation reads it)
+
+        def fit(self, x, augment=False, rounds=1, seed=None):
+            x = np.array(x, dtype=fx, copy=True)
+            if self.featurewise_center:
+                self.mean = np.mean(x, axis=(0, 1, 2)).reshape(1, 1, x.shape[3])
+                x -= self.mean
+            if self.featurewise_std_normalization:
+                self.std = np.std(x, axis=(0, 1, 2)).reshape(1, 1, x.shape[3])
+                x /= (self.std + 1e-6)
+
+        def standardize(self, x):
+            if self.featurewise_center:
+                x -= self.mean
+            if self.featurewise_std_normalization:
+                x /= (self.std + 1e-6)
+            return x
+
+        def random_transform(self, x, seed=None):
+            import scipy.ndimage
+            tx = ty = 0.0
+            if self.height_shift_range:
+                tx = np.random.uniform(-self.height_shift_range, self.height_shift_range) * x.shape[0]
+            if self.width_shift_range:
+                ty = np.random.uniform(-self.width_shift_range, self.width_shift_range) * x.shape[1]
+            flip = bool((np.random.random() < 0.5) * self.horizontal_flip)
+            self.last_transform = (tx, ty, flip)
+            if tx != 0 or ty != 0:
+                # translation about the image centre == plain translation: out[r, c] = in[r + tx, c + ty]
+                x = np.stack([scipy.ndimage.affine_transform(x[..., ch], np.eye(2), offset=(tx, ty), order=1, mode="nearest", cval=0.0)
+                              for ch in range(x.shape[2])], axis=-1)
+            if flip:
+                x = x[:, ::-1, :]
+            return x
+
+    image = types.ModuleType("keras.preprocessing.image")
+    image.ImageDataGenerator = ImageDataGenerator
+    image.load_img = image.img_to_array = image.list_pictures = None      # the file-based generators import these names; never called here
+    mods["keras.preprocessing.image"] = image
+    mods["keras.preprocessing"].image = image
     return mods

@@ -23,6 +23,8 @@ from /root/reference (see oracle/ref_import.py), on seeded inputs:
                       K block; the probed block list travels in the fixture (``kblocks``)
 * topk_head_*.npz   heads (first 256 entries) of the reference's rankings on 640-item D = 555 / D = 1000 problems, for
                       the top-k / sharded-gallery path (features rebuilt from a seed, SHA-1 checked)
+* cifar_pipeline.npz   the reference's in-memory data path (datasets/cifar.py, datasets/common.py TinyDatasetGenerator /
+                      DataSequence) on a synthetic CIFAR-100 pickle pair: statistics, batches, augmented images + drawn parameters
 * imagenet_mintree_unitsphere.npz   the class embedding missing from the reference checkout, regenerated
                       by the reference's compute_class_embedding.py:14-40,176-250 in JSON class order
 
@@ -250,7 +252,71 @@ def topk_goldens(er):
         print("topk", name, feat.shape, norm, "kblocks", kb)
 
 
+def cifar_pipeline_goldens():
+    """cifar_pipeline.npz: the reference's OWN in-memory data path -- datasets/cifar.py:9-84 (pickle parsing, class restriction /
+    re-enumeration, NHWC reshape) and datasets/common.py:635-796 (TinyDatasetGenerator: featurewise statistics of the training set,
+    DataSequence batches, compose_batch = random_transform + standardize per image) -- imported unmodified and run on a small
+    synthetic CIFAR-100 pickle pair.  Only keras.preprocessing.image.ImageDataGenerator is a stand-in (oracle/keras_stub.py).
+    Stored: the pickles' contents, the statistics, every un-augmented test / train batch (all classes, and restricted to 7
+    re-enumerated classes), and augmented training images together with the (row shift, column shift, flip) the generator drew,
+    so that the device augmentation can be checked on the SAME parameters."""
+    import tempfile
+    ds = ref_import.import_reference_datasets()
+    rng = np.random.default_rng(31)
+    n_train, n_test = 240, 64
+    raw_train = rng.integers(0, 256, size=(n_train, 3072), dtype=np.uint8)
+    raw_test = rng.integers(0, 256, size=(n_test, 3072), dtype=np.uint8)
+    # smooth images (augmentation with bilinear shifts is only meaningful on non-noise content): low-pass the noise
+    def smooth(raw):
+        img = raw.reshape(-1, 3, 32, 32).astype(np.float32)
+        for _ in range(3):
+            img = (img + np.roll(img, 1, 2) + np.roll(img, -1, 2) + np.roll(img, 1, 3) + np.roll(img, -1, 3)) / 5.0
+        return np.clip(np.round((img - img.min()) / (img.max() - img.min()) * 255.0), 0, 255).astype(np.uint8).reshape(-1, 3072)
+    raw_train, raw_test = smooth(raw_train), smooth(raw_test)
+    y_train = rng.integers(0, 100, size=n_train).tolist()
+    y_train[:100] = list(range(100))                     # every class present (the reference takes max(y_train) + 1 classes)
+    y_test = rng.integers(0, 100, size=n_test).tolist()
+    out = dict(raw_train=raw_train, raw_test=raw_test, y_train=np.array(y_train), y_test=np.array(y_test))
+    with tempfile.TemporaryDirectory() as tmp:
+        for name, raw, lab in (("train", raw_train, y_train), ("test", raw_test, y_test)):
+            with open(os.path.join(tmp, name), "wb") as f:
+                pickle.dump({b"data": raw, b"fine_labels": lab}, f)
+        gen = ds.CifarGenerator(tmp)
+        out["mean"], out["std"] = gen.image_generator.mean, gen.image_generator.std
+        out["num_classes"], out["num_train"], out["num_test"] = gen.num_classes, gen.num_train, gen.num_test
+        for split, seq in (("test", gen.test_sequence(batch_size=24)), ("train", gen.train_sequence(batch_size=50, shuffle=False, augment=False))):
+            xs, ys = zip(*[seq[i] for i in range(len(seq))])
+            X_all = np.concatenate(xs)
+            keep = len(X_all) if split == "test" else 50         # the training split: first batch in full, per-image checksums for the rest
+            out[split + "_X"], out[split + "_y"] = X_all[:keep], np.concatenate(ys)
+            out[split + "_image_sums"] = X_all.astype(np.float64).sum(axis=(1, 2, 3))
+            out[split + "_batches"] = len(seq)
+        # batch_transform hook (learn_image_embeddings.transform_inputs' place)
+        seq = gen.test_sequence(batch_size=24, batch_transform=lambda X, y, scale: (X * scale, y + 1), batch_transform_kwargs={"scale": 2.0})
+        out["transformed_X0"], out["transformed_y0"] = seq[0]
+        # augmented training images with the drawn parameters
+        np.random.seed(5)
+        aug, params = [], []
+        for j in range(16):
+            x = gen.image_generator.random_transform(gen.X_train[j].astype("float32"))
+            params.append(gen.image_generator.last_transform)
+            aug.append(gen.image_generator.standardize(x))
+        out["aug_X"], out["aug_params"] = np.stack(aug), np.array(params, dtype=np.float64)
+        # class restriction + re-enumeration (datasets/cifar.py:57-72)
+        classes = [3, 17, 20, 42, 56, 77, 99]
+        gen_r = ds.CifarGenerator(tmp, classes=classes, reenumerate=True)
+        seq = gen_r.test_sequence(batch_size=1000)
+        out["restricted_classes"] = np.array(classes)
+        out["restricted_test_X"], out["restricted_test_y"] = seq[0] if len(seq) else (np.zeros((0, 32, 32, 3), np.float32), np.zeros((0,), np.int64))
+        out["restricted_mean"], out["restricted_num_train"] = gen_r.image_generator.mean, gen_r.num_train
+    np.savez_compressed(os.path.join(OUT, "cifar_pipeline.npz"), **out)
+    print("cifar_pipeline", out["test_X"].shape, out["train_X"].shape, "mean", out["mean"].ravel(), "restricted", out["restricted_test_X"].shape)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "cifar":     # only the round-3 data-pipeline fixture
+        cifar_pipeline_goldens()
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "topk":      # only the round-3 top-k fixtures (everything else untouched)
         topk_goldens(ref_import.import_reference("evaluate_retrieval"))
         return
@@ -364,6 +430,7 @@ def main():
     loss_reference_goldens(emb)
     lr_schedule_goldens()
     topk_goldens(er)
+    cifar_pipeline_goldens()
     print("done ->", OUT)
 
 

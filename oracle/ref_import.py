@@ -61,6 +61,32 @@ _SHADOWED = ("numexpr", "datasets", "keras", "keras.backend", "keras.callbacks",
              "keras_applications", "keras_resnet", "models", "densenet", "clr_callback", "sgdr_callback", "utils", "class_hierarchy")
 
 
+def import_reference_datasets(floatx="float32"):
+    """The reference's own ``datasets`` package (datasets/__init__.py, common.py, cifar.py ...), unmodified, with ``keras``
+    resolving to the stand-in (oracle/keras_stub.py: ``keras.utils.Sequence`` and the ``ImageDataGenerator`` subset the in-memory
+    generators use).  Returns the package; ``datasets.cifar.CifarGenerator`` etc. are the reference's classes."""
+    if not available():
+        raise ImportError("reference tree not present at " + REFERENCE_ROOT)
+    from oracle import keras_stub
+    sys.dont_write_bytecode = True
+    saved = {k: v for k, v in sys.modules.items() if k == "datasets" or k.startswith("datasets.") or k == "keras" or k.startswith("keras.")}
+    saved_path = list(sys.path)
+    try:
+        for k in saved:
+            sys.modules.pop(k, None)
+        sys.modules.update(keras_stub.make_keras(floatx))
+        sys.path.insert(0, REFERENCE_ROOT)
+        mod = importlib.import_module("datasets")
+        subs = {k: v for k, v in sys.modules.items() if k.startswith("datasets.")}
+    finally:
+        sys.path[:] = saved_path
+        for k in [k for k in sys.modules if k == "datasets" or k.startswith("datasets.") or k == "keras" or k.startswith("keras.")]:
+            sys.modules.pop(k, None)
+        sys.modules.update(saved)
+    mod._submodules = subs
+    return mod
+
+
 def import_reference(name, floatx="float32"):
     """Import module ``name`` (e.g. 'evaluate_retrieval', 'class_hierarchy', 'utils', 'learn_labelembedding') from the
     reference tree, unmodified.  ``keras`` resolves to the NumPy stand-in of oracle/keras_stub.py evaluated in ``floatx``

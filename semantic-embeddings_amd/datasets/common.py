@@ -141,23 +141,37 @@ class InMemoryDatasetGenerator(_GeneratorBase):
             self._dev_data = (prep(self.X_train_h), prep(self.X_test_h))
         return self._dev_data
 
-    def compose_batch(self, indices, train=True, augment=False):
+    @staticmethod
+    def apply_transform(x, row_shift, col_shift, flip):
+        """The reference's per-image augmentation with GIVEN parameters, batched on the device: Keras' ``random_transform`` shifts
+        first -- ``out[r, c] = in[r + row_shift, c + col_shift]``, bilinear (``order = 1``), edges replicated (``fill_mode =
+        'nearest'``) -- and flips horizontally afterwards (datasets/common.py:786-787 -> ImageDataGenerator.random_transform).
+        x [B, C, H, W]; row_shift / col_shift [B] float pixels; flip [B] bool."""
+        b, _, h, w = x.shape
+        rr = torch.arange(h, device=x.device, dtype=torch.float32)[None, :] + row_shift.to(torch.float32)[:, None]   # source row of every output row
+        cc = torch.arange(w, device=x.device, dtype=torch.float32)[None, :] + col_shift.to(torch.float32)[:, None]
+        gy = (rr / max(h - 1, 1) * 2 - 1)[:, :, None].expand(b, h, w)
+        gx = (cc / max(w - 1, 1) * 2 - 1)[:, None, :].expand(b, h, w)
+        x = torch.nn.functional.grid_sample(x, torch.stack((gx, gy), dim=-1), mode='bilinear', padding_mode='border', align_corners=True)
+        return torch.where(flip[:, None, None, None], x.flip(3), x)
+
+    def draw_transform(self, b, h, w, device):
+        """(row_shift, col_shift, flip) like ImageDataGenerator.get_random_transform: shifts uniform in +-shift_range x size, flip
+        with probability 1/2 -- from torch's device generator (same distribution as the reference's np.random draws, other numbers)."""
+        zero = torch.zeros(b, device=device)
+        row = (torch.rand(b, device=device) * 2 - 1) * (self.shift_range * h) if self.shift_range else zero
+        col = (torch.rand(b, device=device) * 2 - 1) * (self.shift_range * w) if self.shift_range else zero
+        flip = (torch.rand(b, device=device) < 0.5) if self.horizontal_flip else torch.zeros(b, dtype=torch.bool, device=device)
+        return row, col, flip
+
+    def compose_batch(self, indices, train=True, augment=False, return_params=False):
         data = self._data()[0 if train else 1]
         idx = torch.from_numpy(np.asarray(indices, dtype=np.int64)).to(data.device)
         x = data.index_select(0, idx)
+        params = None
         if augment:
             b, _, h, w = x.shape
-            if self.horizontal_flip:
-                flip = torch.rand(b, device=x.device) < 0.5
-                x = torch.where(flip[:, None, None, None], x.flip(3), x)
-            if self.shift_range:
-                # per-sample continuous shifts, bilinear, edges replicated: out[r, c] = in[r + ty, c + tx]
-                ty = (torch.rand(b, device=x.device) * 2 - 1) * (self.shift_range * h)
-                tx = (torch.rand(b, device=x.device) * 2 - 1) * (self.shift_range * w)
-                rr = torch.arange(h, device=x.device, dtype=torch.float32)[None, :] + ty[:, None]       # source row of every output row
-                cc = torch.arange(w, device=x.device, dtype=torch.float32)[None, :] + tx[:, None]
-                gy = (rr / max(h - 1, 1) * 2 - 1)[:, :, None].expand(b, h, w)
-                gx = (cc / max(w - 1, 1) * 2 - 1)[:, None, :].expand(b, h, w)
-                x = torch.nn.functional.grid_sample(x, torch.stack((gx, gy), dim=-1), mode='bilinear', padding_mode='border',
-                                                    align_corners=True)
-        return x.contiguous(memory_format=torch.channels_last)
+            params = self.draw_transform(b, h, w, x.device)
+            x = self.apply_transform(x, *params)
+        x = x.contiguous(memory_format=torch.channels_last)
+        return (x, params) if return_params else x

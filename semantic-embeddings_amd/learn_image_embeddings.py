@@ -39,12 +39,36 @@ class ClsModel(nn.Module):
 
     def __init__(self, embed_model, num_classes, cls_base=None, head=None, width=None):
         super().__init__()
-        if cls_base is not None:
-            raise NotImplementedError('--cls_base: tapping an intermediate layer is not supported in this build')
         if head not in (None, 'l2norm', 'softmax'):
             raise ValueError('head must be None, "l2norm" or "softmax"')
         self.embed_model = embed_model
         self.head = head
+        self._tap = None
+        self.cls_base = None
+        if cls_base is not None and str(cls_base) not in ('l2norm', 'softmax'):
+            # reference: `embed_model.layers[int(cls_base)].output` / `embed_model.get_layer(cls_base).output`
+            # (learn_image_embeddings.py:34-40).  Names are module names of the embedding model ('avg_pool' = the pooled backbone
+            # features, 'embedding' = the dense layer in front of l2norm, dotted names for anything deeper); an integer indexes its
+            # leaf modules in definition order (Keras numbers its own layer list: indices are not portable between the two).
+            named = [(n, m) for n, m in embed_model.named_modules() if n]
+            try:
+                leaves = [(n, m) for n, m in named if not list(m.children())]
+                name, tap = leaves[int(cls_base)]
+            except ValueError:
+                found = dict(named)
+                if str(cls_base) not in found:
+                    raise ValueError('--cls_base {!r}: no such layer; the embedding model has {}'.format(cls_base, ', '.join(n for n, _ in named)))
+                name, tap = str(cls_base), found[str(cls_base)]
+            if isinstance(tap, nn.Linear):
+                width = tap.out_features
+            elif isinstance(tap, (nn.BatchNorm1d, nn.BatchNorm2d)):
+                width = tap.num_features
+            elif name == 'avg_pool' or name.endswith('.avg_pool'):
+                width = embed_model.num_features
+            elif width is None:
+                raise ValueError('--cls_base {!r}: cannot tell the width of that layer\'s output (dense, batch-norm and avg_pool layers are supported)'.format(cls_base))
+            self.cls_base = name
+            tap.register_forward_hook(self._remember)
         if width is None:       # width of what the embedding model emits (resnet-32 / -110 without -fc: the pooled features)
             width = embed_model.head.out_features if getattr(embed_model, 'head', None) is not None else None
         if width is None:
@@ -52,6 +76,9 @@ class ClsModel(nn.Module):
         self.bn = nn.BatchNorm1d(width, eps=1e-3, momentum=0.01)
         self.prob = keras_dense(width, num_classes)
         self.cls_l2 = 5e-4
+
+    def _remember(self, module, inputs, output):
+        self._tap = output
 
     def forward(self, x):
         emb = self.embed_model(x)
@@ -61,7 +88,13 @@ class ClsModel(nn.Module):
             base = torch.softmax(emb.float(), -1)
         else:
             base = emb.float()
-        return base, self.prob(self.bn(torch.relu(base)))
+        cls_in = base
+        if self.cls_base is not None:                   # the classifier hangs off an inner layer; the first output stays the embedding
+            cls_in, self._tap = self._tap, None
+            if cls_in is None or cls_in.dim() != 2:
+                raise ValueError('--cls_base {!r} does not produce a [batch, features] tensor'.format(self.cls_base))
+            cls_in = cls_in.float()
+        return base, self.prob(self.bn(torch.relu(cls_in)))
 
 
 def transform_inputs(X, y, embedding=None, num_classes=None):
@@ -95,7 +128,7 @@ def build_parser():
                    help='"inv_corr": cosine loss on L2-normalised outputs (fused HIP kernel); "mse": squared distance; '
                         '"unnorm_corr"/"softmax_corr": negated dot product without normalisation / after softmax.')
     g.add_argument('--cls_weight', type=float, default=0.0, help='Weight of an additional softmax classification loss (0 = off).')
-    g.add_argument('--cls_base', type=str, default=None, help='Layer feeding the classifier (only the embedding output is supported).')
+    g.add_argument('--cls_base', type=str, default=None, help='Name or index of the layer that the classification layer should be based on. If not specified, the final embedding layer will be used.')
     g.add_argument('--lr_schedule', type=str, default='SGDR', choices=utils.LR_SCHEDULES, help='Learning-rate schedule.')
     g.add_argument('--clipgrad', type=float, default=10.0, help='Global gradient-norm clip.')
     g.add_argument('--max_decay', type=float, default=0.0, help='Learning-rate decay reached at the end of training.')

@@ -138,6 +138,7 @@ class SmallResNet(nn.Module):
                 prev = width
         self.blocks = nn.Sequential(*blocks)
         self.num_features = prev
+        self.avg_pool = nn.Identity()      # named tap on the pooled features (the reference's GlobalAveragePooling2D 'avg_pool': --cls_base avg_pool)
         if include_top:
             head = keras_dense(prev, classes)
             # the head is called 'embedding' when it has no activation and 'prob' otherwise
@@ -155,7 +156,7 @@ class SmallResNet(nn.Module):
         x = self.act(self.bn0(self.conv0(x)))
         x = self.blocks(x)
         if self.pooling == "avg":
-            x = x.mean(dim=(2, 3))
+            x = self.avg_pool(x.mean(dim=(2, 3)))
         elif self.pooling == "max":
             x = x.amax(dim=(2, 3))
         return x

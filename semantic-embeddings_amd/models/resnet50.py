@@ -54,6 +54,7 @@ class ResNet50(nn.Module):
                 cin = widths[2]
         self.stages = nn.Sequential(*layers)
         self.num_features = cin
+        self.avg_pool = nn.Identity()      # named tap on the pooled features (keras.applications.ResNet50's 'avg_pool': --cls_base avg_pool)
         head = keras_dense(cin, num_outputs)
         self.softmax = bool(classification and not no_softmax)
         if classification:
@@ -68,7 +69,7 @@ class ResNet50(nn.Module):
 
     def features(self, x):
         x = self.pool(self.relu(self.bn_conv1(self.conv1(x))))
-        return self.stages(x).mean(dim=(2, 3))          # 'avg_pool'
+        return self.avg_pool(self.stages(x).mean(dim=(2, 3)))
 
     def forward(self, x):
         x = self.head(self.features(x))

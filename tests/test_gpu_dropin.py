@@ -628,3 +628,33 @@ def test_bench_line_schema_on_a_small_problem():
     sg = d["sharded_gallery"]
     assert "error" not in sg and sg["merged_lists_sorted_with_index_tiebreak"] and sg["merged_indices_in_range"]
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
+
+
+def test_cifar_pipeline_on_the_device_matches_reference_and_augmentation_statistics(tmp_path):
+    """The in-memory data path on the GPU: un-augmented batches == the reference generator's (tests/golden/cifar_pipeline.npz,
+    produced by the reference's unmodified datasets/cifar.py + datasets/common.py), and the device augmentation draws what
+    ImageDataGenerator(horizontal_flip, width/height_shift_range = 0.15) draws -- flips with probability 1/2, shifts uniform in
+    +-4.8 pixels -- and applies them like Keras (replaying the drawn parameters through apply_transform reproduces the batch)."""
+    import pickle
+    from datasets.cifar import CifarGenerator
+    g = np.load(os.path.join(ROOT, "tests", "golden", "cifar_pipeline.npz"))
+    for name, raw, lab in (("train", g["raw_train"], g["y_train"]), ("test", g["raw_test"], g["y_test"])):
+        with open(os.path.join(str(tmp_path), name), "wb") as f:
+            pickle.dump({b"data": raw, b"fine_labels": lab.tolist()}, f)
+    gen = CifarGenerator(str(tmp_path))
+    X, y = gen.test_sequence(batch_size=64)[0]
+    assert X.is_cuda and np.array_equal(y.cpu().numpy(), g["test_y"])
+    assert np.abs(X.permute(0, 2, 3, 1).cpu().numpy() - g["test_X"]).max() < 2e-6
+    idx = np.arange(240).repeat(40)                                   # 9600 draws
+    xb, (row, col, flip) = gen.compose_batch(idx, train=True, augment=True, return_params=True)
+    assert abs(float(flip.float().mean()) - 0.5) < 0.03
+    for t in (row, col):
+        assert float(t.abs().max()) <= 0.15 * 32 + 1e-4 and abs(float(t.mean())) < 0.15 and abs(float(t.var()) - (9.6 ** 2) / 12.0) < 0.5
+    plain = gen.compose_batch(idx, train=True, augment=False)
+    assert torch.equal(gen.apply_transform(plain.contiguous(), row, col, flip).contiguous(memory_format=torch.channels_last), xb)
+    # replaying the reference's drawn parameters on the device
+    p = g["aug_params"]
+    n = len(g["aug_X"])
+    got = gen.apply_transform(gen.compose_batch(np.arange(n), train=True, augment=False).contiguous(), torch.from_numpy(p[:, 0]).float().cuda(),
+                              torch.from_numpy(p[:, 1]).float().cuda(), torch.from_numpy(p[:, 2] != 0).cuda())
+    assert np.abs(got.permute(0, 2, 3, 1).cpu().numpy() - g["aug_X"]).max() < 2e-4

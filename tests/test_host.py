@@ -418,3 +418,95 @@ def test_cifar_reader_augmentation_is_flip_plus_bilinear_shift(tmp_path):
     mirrored = np.isclose(f[:, 1, 0, 0], 31.0)
     assert 5 < mirrored.sum() < 35
     assert np.allclose(f[mirrored][:, 1], cc[:, ::-1][None]) and np.allclose(f[~mirrored][:, 1], cc[None])
+
+
+def test_cls_base_taps_named_or_indexed_layers():
+    """--cls_base (reference: cls_model, learn_image_embeddings.py:16-45): the classifier head hangs off a named layer ('avg_pool':
+    the pooled backbone features, 'embedding': the dense layer in front of l2norm) or a leaf-module index of the embedding model,
+    while the first output stays the embedding; unknown names are rejected with the list of layers."""
+    import torch
+    import utils
+    import learn_image_embeddings as lie
+    torch.manual_seed(0)
+    net = utils.build_network(10, 'resnet-110-fc', input_channels=3)         # CIFAR ResNet with the 'embedding' dense layer
+    x = torch.randn(4, 3, 32, 32)
+    net.eval()
+    feats = net.features(x)
+    emb = net(x)
+    for base, want_in in (('avg_pool', feats), ('embedding', emb)):
+        m = lie.ClsModel(net, 7, cls_base=base).eval()
+        first, logits = m(x)
+        assert torch.allclose(first, emb.float())
+        assert logits.shape == (4, 7)
+        assert torch.allclose(logits, m.prob(m.bn(torch.relu(want_in.float()))), atol=1e-6)
+        assert m.bn.num_features == want_in.shape[1]
+    leaves = [n for n, mod in net.named_modules() if n and not list(mod.children())]
+    m = lie.ClsModel(net, 7, cls_base=str(leaves.index('avg_pool'))).eval()       # by index
+    assert m.cls_base == 'avg_pool' and m(x)[1].shape == (4, 7)
+    with pytest.raises(ValueError, match='no such layer'):
+        lie.ClsModel(net, 7, cls_base='does_not_exist')
+    with pytest.raises(ValueError):                                           # a convolution's 4-d output cannot feed the dense classifier
+        lie.ClsModel(net, 7, cls_base='conv0')
+
+
+# ---------------------------------------------------------------- in-memory data path pinned to the reference's own classes
+
+def _cifar_fixture(tmp_path):
+    """tests/golden/cifar_pipeline.npz (oracle/make_golden.py cifar_pipeline_goldens: outputs of the reference's unmodified
+    datasets/cifar.py + datasets/common.py on a synthetic CIFAR-100 pickle pair) and the same pickles written to tmp_path."""
+    import pickle
+    g = np.load(os.path.join(ROOT, "tests", "golden", "cifar_pipeline.npz"))
+    for name, raw, lab in (("train", g["raw_train"], g["y_train"]), ("test", g["raw_test"], g["y_test"])):
+        with open(os.path.join(str(tmp_path), name), "wb") as f:
+            pickle.dump({b"data": raw, b"fine_labels": lab.tolist()}, f)
+    return g
+
+
+def _nhwc(t):
+    return t.permute(0, 2, 3, 1).cpu().numpy()
+
+
+def test_cifar_pipeline_equals_the_reference_generator(tmp_path):
+    """CifarGenerator / InMemoryDatasetGenerator / DeviceBatchSequence against what the reference's CifarGenerator /
+    TinyDatasetGenerator / DataSequence produced (datasets/cifar.py:9-84, datasets/common.py:26-122,635-796): training-set
+    statistics, every un-augmented batch and its labels, the batch_transform hook, class restriction with re-enumeration."""
+    import torch
+    from datasets.cifar import CifarGenerator
+    g = _cifar_fixture(tmp_path)
+    gen = CifarGenerator(str(tmp_path))
+    gen.device = torch.device("cpu")
+    assert (gen.num_classes, gen.num_train, gen.num_test) == (int(g["num_classes"]), int(g["num_train"]), int(g["num_test"]))
+    assert np.allclose(gen.mean.reshape(-1), g["mean"].reshape(-1), rtol=1e-6)
+    assert np.allclose(gen.std.reshape(-1), g["std"].reshape(-1) + 1e-6, rtol=1e-6)
+    for split, seq, bs in (("test", gen.test_sequence(batch_size=24), 24), ("train", gen.train_sequence(batch_size=50, shuffle=False, augment=False), 50)):
+        assert len(seq) == int(g[split + "_batches"])
+        xs, ys = zip(*[seq[i] for i in range(len(seq))])
+        X, y = _nhwc(torch.cat(xs)), torch.cat(ys).numpy()
+        assert np.array_equal(y, g[split + "_y"])
+        keep = len(g[split + "_X"])
+        assert np.abs(X[:keep] - g[split + "_X"]).max() < 2e-6                      # (x - mean) / (std + 1e-6) in float32, like Keras
+        assert np.allclose(X.astype(np.float64).sum(axis=(1, 2, 3)), g[split + "_image_sums"], atol=2e-3)
+    seq = gen.test_sequence(batch_size=24, batch_transform=lambda X, y, scale: (X * scale, y + 1), batch_transform_kwargs={"scale": 2.0})
+    X0, y0 = seq[0]
+    assert np.abs(_nhwc(X0) - g["transformed_X0"]).max() < 4e-6 and np.array_equal(y0.numpy(), g["transformed_y0"])
+    gen_r = CifarGenerator(str(tmp_path), classes=g["restricted_classes"].tolist(), reenumerate=True)
+    gen_r.device = torch.device("cpu")
+    assert gen_r.num_train == int(g["restricted_num_train"]) and np.allclose(gen_r.mean.reshape(-1), g["restricted_mean"].reshape(-1), rtol=1e-6)
+    Xr, yr = gen_r.test_sequence(batch_size=1000)[0]
+    assert np.array_equal(yr.numpy(), g["restricted_test_y"]) and np.abs(_nhwc(Xr) - g["restricted_test_X"]).max() < 2e-6
+
+
+def test_device_augmentation_equals_keras_transform_on_the_same_parameters(tmp_path):
+    """The (row shift, column shift, flip) the reference's generator drew, replayed through InMemoryDatasetGenerator.apply_transform:
+    shift (bilinear, edges replicated) then flip, then -- commuting with it -- the standardisation."""
+    import torch
+    from datasets.cifar import CifarGenerator
+    g = _cifar_fixture(tmp_path)
+    gen = CifarGenerator(str(tmp_path))
+    gen.device = torch.device("cpu")
+    n = len(g["aug_X"])
+    x = gen.compose_batch(np.arange(n), train=True, augment=False)
+    p = g["aug_params"]
+    got = gen.apply_transform(x.contiguous(), torch.from_numpy(p[:, 0]).float(), torch.from_numpy(p[:, 1]).float(), torch.from_numpy(p[:, 2] != 0))
+    assert (p[:, 2] != 0).any() and (p[:, 2] == 0).any() and np.abs(p[:, :2]).max() <= 0.15 * 32 + 1e-9
+    assert np.abs(_nhwc(got) - g["aug_X"]).max() < 2e-4
