@@ -1092,15 +1092,18 @@ __global__ __launch_bounds__(RR_THREADS) void rank_order_probe_kernel(uint32_t *
 // canonical order, every index in range.  A ranking produced by a stable sort that lost its stability is still a permutation,
 // so this one pass (one gather of the distances through the ranks) detects exactly the failure mode.  Offending rows are listed
 // (bad[0] = count, bad[1 + i] = row); se_rank_rows re-ranks them with the ballot kernel and stops using the hardware-ordered
-// kernel on that device.  Cost at 50k x 50k: ~2 ms next to the 9.5 ms ranking -- run on the first hardware-ordered call of a
-// process and on every call under SE_RANK_CHECK=1; se_rank_rows_check exposes it (bench.py reports its verdict).
+// kernel on that device.  The gather is random 4-byte reads: 50 ms for all of 50k x 50k (1 us per row of 50k), five times the
+// ranking itself.  So: behind the FIRST hardware-ordered call of a process 512 evenly spaced rows are checked (0.5 ms; a broken
+// lane order is systematic -- every wave step with two equal digits is affected -- not a property of single rows) and any
+// violation makes the whole call fall back; under SE_RANK_CHECK=1 every row of every call is checked and only the offending
+// rows are redone; se_rank_rows_check audits any ranking in full (bench.py reports its verdict outside the timed region).
 constexpr int RC_THREADS = 512, RC_PER = 8;
 template <bool IDX64>
 __global__ __launch_bounds__(RC_THREADS) void rank_check_kernel(const float *__restrict__ pdist, int64_t ldp, int64_t Q, int N, const void *rank,
-                                                               int64_t ldr, uint32_t *__restrict__ bad, int cap)
+                                                               int64_t ldr, uint32_t *__restrict__ bad, int cap, int64_t row_stride)
 {
     __shared__ uint32_t wg_bad;
-    for (int64_t row = blockIdx.x; row < Q; row += gridDim.x) {
+    for (int64_t row = (int64_t)blockIdx.x * row_stride; row < Q; row += (int64_t)gridDim.x * row_stride) {
         const float *drow = pdist + row * ldp;
         if (threadIdx.x == 0) wg_bad = 0;
         __syncthreads();
@@ -1144,12 +1147,13 @@ __global__ void rank_inject_kernel(void *rank, int idx64, int64_t ldr, int64_t Q
 constexpr int RC_CAP = 1022;   // listed rows (workspace: 256 B of probe / detector words + 4 KB of list)
 
 static int rank_check_launch(const float *pdist, int64_t ldp, int64_t q, int n, const void *rank, int idx64, int64_t ldr, uint32_t *bad, int cap,
-                             hipStream_t s)
+                             int64_t row_stride, hipStream_t s)
 {
     SE_HIP_CHECK(hipMemsetAsync(bad, 0, 4, s));
-    const int64_t grid = q < 2048 ? q : 2048;
-    if (idx64) hipLaunchKernelGGL(rank_check_kernel<true>, dim3((unsigned)grid), dim3(RC_THREADS), 0, s, pdist, ldp, q, n, rank, ldr, bad, cap);
-    else hipLaunchKernelGGL(rank_check_kernel<false>, dim3((unsigned)grid), dim3(RC_THREADS), 0, s, pdist, ldp, q, n, rank, ldr, bad, cap);
+    const int64_t nrows = (q + row_stride - 1) / row_stride;
+    const int64_t grid = nrows < 2048 ? nrows : 2048;
+    if (idx64) hipLaunchKernelGGL(rank_check_kernel<true>, dim3((unsigned)grid), dim3(RC_THREADS), 0, s, pdist, ldp, q, n, rank, ldr, bad, cap, row_stride);
+    else hipLaunchKernelGGL(rank_check_kernel<false>, dim3((unsigned)grid), dim3(RC_THREADS), 0, s, pdist, ldp, q, n, rank, ldr, bad, cap, row_stride);
     SE_LAUNCH_CHECK();
     return SE_OK;
 }
@@ -1222,7 +1226,8 @@ extern "C" int se_rank_rows(const float *pdist, int64_t ldp, int64_t q, int64_t 
             SE_LAUNCH_CHECK();
         }
         uint32_t *bad = (uint32_t *)((char *)workspace + 256);
-        if (const int rc2 = rank_check_launch(pdist, ldp, q, (int)n, rank, idx64, ldr, bad, RC_CAP, s)) return rc2;
+        const int64_t row_stride = check_always ? 1 : (q > 512 ? q / 512 : 1);      // first call: a sample of the rows
+        if (const int rc2 = rank_check_launch(pdist, ldp, q, (int)n, rank, idx64, ldr, bad, RC_CAP, row_stride, s)) return rc2;
         uint32_t h[RC_CAP + 1];
         SE_HIP_CHECK(hipStreamSynchronize(s));
         SE_HIP_CHECK(hipMemcpy(h, bad, sizeof(uint32_t), hipMemcpyDeviceToHost));
@@ -1233,7 +1238,7 @@ extern "C" int se_rank_rows(const float *pdist, int64_t ldp, int64_t q, int64_t 
         fprintf(stderr, "[se_rank_rows] order guard: %u of %lld rows out of canonical order behind the hardware-ordered kernel -- re-ranking them "
                         "with the ballot kernel; device %d uses the ballot kernel from now on\n", h[0], (long long)q, dev);
         const uint32_t nbad = h[0];
-        if (nbad > (uint32_t)RC_CAP) {   // more than the list holds: redo the whole call
+        if (nbad > (uint32_t)RC_CAP || row_stride > 1) {   // more than the list holds, or only a sample was looked at: redo the whole call
 #define SE_RR_CASE(I) if (items <= I) return launch_rank_reg<I>(pdist, ldp, q, (int)n, rank, idx64, ldr, false, scratch, s);
 #if SE_RR_THREADS == 512
             SE_RR_CASE(2) SE_RR_CASE(8) SE_RR_CASE(20) SE_RR_CASE(40) SE_RR_CASE(64) SE_RR_CASE(80) SE_RR_CASE(98) SE_RR_CASE(104)
@@ -1285,7 +1290,7 @@ extern "C" int se_rank_rows_check(const float *pdist, int64_t ldp, int64_t q, in
     if (!workspace || workspace_bytes < se_rank_rows_check_workspace_bytes()) return fail(SE_ERR_WORKSPACE, "se_rank_rows_check: workspace too small");
     hipStream_t s = (hipStream_t)stream;
     uint32_t *bad = (uint32_t *)workspace;
-    if (const int rc = rank_check_launch(pdist, ldp, q, (int)n, rank, idx64, ldr, bad, RC_CAP, s)) return rc;
+    if (const int rc = rank_check_launch(pdist, ldp, q, (int)n, rank, idx64, ldr, bad, RC_CAP, 1, s)) return rc;
     uint32_t h = 0;
     SE_HIP_CHECK(hipStreamSynchronize(s));
     SE_HIP_CHECK(hipMemcpy(&h, bad, sizeof(h), hipMemcpyDeviceToHost));

@@ -303,10 +303,15 @@ def test_rank_order_guard_repairs_injected_violations_in_subprocess(q):
         "assert np.array_equal(got, ro.canon_rank_rows(pd[:50]))\n"
         "print('guard-ok')\n"
     ) % ([PKG_DIR, ROOT_DIR], q)
-    env = dict(os.environ, SE_RANK_INJECT="1", SE_RANK_VERBOSE="1", SEHIP_LIB=os.path.join(PKG_DIR, "sehip", "libsehip_tuning.so"))
+    # SE_RANK_CHECK=1: every row is checked (the first-call guard of a process looks at 512 evenly spaced rows only)
+    env = dict(os.environ, SE_RANK_INJECT="1", SE_RANK_CHECK="1", SE_RANK_VERBOSE="1", SEHIP_LIB=os.path.join(PKG_DIR, "sehip", "libsehip_tuning.so"))
     out = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert out.returncode == 0 and "guard-ok" in out.stdout, out.stdout
     assert "order guard" in out.stdout and "ballot kernel from now on" in out.stdout, out.stdout
+    if q == 40:     # the same without the switch: the sampled first-call guard (all 40 rows are in its sample) finds the injected rows too
+        env.pop("SE_RANK_CHECK")
+        out = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+        assert out.returncode == 0 and "guard-ok" in out.stdout and "order guard" in out.stdout, out.stdout
 
 
 @pytest.mark.parametrize("n", [300, 5000, 50000])
