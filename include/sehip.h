@@ -153,7 +153,8 @@ int se_labelembed_loss_bwd(const float *out1, int64_t ld1, const float *out2, in
  *   learn_image_embeddings.py:48-50 done on the device) or the explicit matrix y_true [B, D] (the reference's convention);
  *   emb [C, D] f32; loss_i [B] out.
  *   aux: se_devise_aux_floats(B, C) floats, caller-owned: true_sim [B], active-hinge count [B] and the 0 / 1 hinge mask [B, C]
- *        written by the forward pass and consumed by the backward pass (d y_pred = g_i (mask . E - count_i y_true_i)).
+ *        written by the forward pass and consumed by the backward pass (d y_pred = g_i (mask . E - count_i y_true_i)), followed by
+ *        scratch for the forward pass's per-class-slice partial sums when C is large (always ask se_devise_aux_floats for the size).
  *   grad_loss_i [B] or NULL (then every sample uses grad_scale).
  */
 int64_t se_devise_aux_floats(int64_t B, int64_t C);

@@ -22,27 +22,71 @@ typedef float dv_f32x16 __attribute__((ext_vector_type(16)));
 constexpr int DV_BK = 64;            // k per staged chunk
 constexpr int DV_LD = DV_BK + 4;     // padded row pitch (floats): conflict-free ds_read_b128
 
-// 32 rows x 64 k of a row-major [rows, K] matrix -> LDS, even k to [0, 32), odd k to [32, 64) of each row; zero outside
-__device__ __forceinline__ void dv_stage(float *lds, const float *src, int64_t ld, int64_t row0, int64_t nrows, int64_t k0, int64_t K)
+// Staging loads are UNCONDITIONAL (out-of-range rows / k read a valid in-range address and are zeroed afterwards): with a branch per
+// element the compiler waited for every load before issuing the next one, which was most of these kernels' time.
+__device__ __forceinline__ void dv_put(float *lds, int r, int kq, const float v[4])
+{
+    float *o = lds + r * DV_LD;                      // even k to [0, 32), odd k to [32, 64) of the row
+    o[(kq >> 1)] = v[0];
+    o[(kq >> 1) + 1] = v[2];
+    o[32 + (kq >> 1)] = v[1];
+    o[32 + (kq >> 1) + 1] = v[3];
+}
+
+// 8 x (one row's 4 consecutive k) per lane; rowp(r) = pointer to LDS row r's source row, or nullptr outside the matrix
+template <class RowPtr>
+__device__ __forceinline__ void dv_stage_rows(float *lds, RowPtr rowp, const float *any_valid_row, int64_t ld, int64_t k0, int64_t K)
 {
     const int lane = lane_id();
+    float v[8][4];
+    const bool vec = ((ld | K) & 3) == 0 && (((uintptr_t)any_valid_row) & 15) == 0;          // wave-uniform
 #pragma unroll
     for (int it = 0; it < 8; it++) {
         const int idx = it * 64 + lane;
         const int r = idx >> 4, kq = (idx & 15) * 4;
-        float v[4] = {0.f, 0.f, 0.f, 0.f};
-        if (row0 + r < nrows) {
-            const float *p = src + (row0 + r) * ld + k0 + kq;
+        const float *p = rowp(r);
+        const bool rok = p != nullptr;
+        if (!rok) p = any_valid_row;
+        if (vec) {
+            const bool ok = rok && k0 + kq < K;
+            const float4 t = *(const float4 *)(p + (k0 + kq < K ? k0 + kq : 0));
+            v[it][0] = ok ? t.x : 0.f; v[it][1] = ok ? t.y : 0.f; v[it][2] = ok ? t.z : 0.f; v[it][3] = ok ? t.w : 0.f;
+        } else {
 #pragma unroll
-            for (int j = 0; j < 4; j++)
-                if (k0 + kq + j < K) v[j] = p[j];
+            for (int j = 0; j < 4; j++) {
+                const bool kok = k0 + kq + j < K;
+                const float t = p[kok ? k0 + kq + j : 0];
+                v[it][j] = (rok && kok) ? t : 0.f;
+            }
         }
-        float *o = lds + r * DV_LD;
-        o[(kq >> 1)] = v[0];
-        o[(kq >> 1) + 1] = v[2];
-        o[32 + (kq >> 1)] = v[1];
-        o[32 + (kq >> 1) + 1] = v[3];
     }
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+        const int idx = it * 64 + lane;
+        dv_put(lds, idx >> 4, (idx & 15) * 4, v[it]);
+    }
+}
+
+// 32 rows x 64 k of a row-major [rows, K] matrix -> LDS; zero outside
+__device__ __forceinline__ void dv_stage(float *lds, const float *src, int64_t ld, int64_t row0, int64_t nrows, int64_t k0, int64_t K)
+{
+    dv_stage_rows(lds, [=](int r) -> const float * { return row0 + r < nrows ? src + (row0 + r) * ld : nullptr; }, src, ld, k0, K);
+}
+
+// 32 TARGET rows x 64 k: row r is y_true[row0 + r] or, with labels, embedding[labels[row0 + r]] (clamped like the reference's gather)
+__device__ __forceinline__ void dv_stage_target(float *lds, const float *yt, int64_t ldt, const int64_t *labels, const float *emb, int64_t lde,
+                                                int64_t row0, int64_t B, int64_t C, int64_t k0, int64_t K)
+{
+    if (yt) {
+        dv_stage(lds, yt, ldt, row0, B, k0, K);
+        return;
+    }
+    dv_stage_rows(lds, [=](int r) -> const float * {
+        if (row0 + r >= B) return nullptr;
+        int64_t y = labels[row0 + r];
+        y = y < 0 ? 0 : (y >= C ? C - 1 : y);
+        return emb + y * lde;
+    }, emb, lde, k0, K);
 }
 
 // the same tile of the TRANSPOSE of a row-major [K, cols] matrix: LDS row r = column col0 + r of `src`, k = its row index
@@ -50,12 +94,20 @@ __device__ __forceinline__ void dv_stage_t(float *lds, const float *src, int64_t
 {
     const int lane = lane_id();
     const int r = lane & 31;
+    const bool cok = col0 + r < ncols;
+    const float *p = src + (cok ? col0 + r : col0);
+    float v[32];
 #pragma unroll
     for (int it = 0; it < 32; it++) {
         const int k = it * 2 + (lane >> 5);                                 // 32 consecutive columns of one source row per half-wave
-        float v = 0.f;
-        if (k0 + k < K && col0 + r < ncols) v = src[(k0 + k) * ld + col0 + r];
-        lds[r * DV_LD + ((k & 1) ? 32 : 0) + (k >> 1)] = v;
+        const bool kok = k0 + k < K;
+        const float t = p[(kok ? k0 + k : 0) * ld];
+        v[it] = (cok && kok) ? t : 0.f;
+    }
+#pragma unroll
+    for (int it = 0; it < 32; it++) {
+        const int k = it * 2 + (lane >> 5);
+        lds[r * DV_LD + ((k & 1) ? 32 : 0) + (k >> 1)] = v[it];
     }
 }
 
@@ -79,8 +131,12 @@ __device__ __forceinline__ dv_f32x16 dv_mma_chunk(dv_f32x16 acc, const float *sA
 __global__ __launch_bounds__(64) void devise_fwd_kernel(const float *__restrict__ yp, int64_t ldp, const int64_t *__restrict__ labels,
                                                         const float *__restrict__ yt, int64_t ldt, const float *__restrict__ emb, int64_t lde,
                                                         int64_t B, int64_t D, int64_t C, float margin, float *__restrict__ loss_i,
-                                                        float *__restrict__ aux)
+                                                        float *__restrict__ aux, int tiles_per_block)
 {
+    // grid = (32-sample blocks, class slices of tiles_per_block x 32 classes).  One slice: results are written directly.  Several (large
+    // class sets: one wave walking all C / 32 class tiles of its 32 samples was 4 waves on the chip for a batch of 128): every slice
+    // leaves its partial hinge sums / active counts behind the mask in `aux` and devise_finish_kernel adds them in slice order
+    // (deterministic: no floating-point atomics).
     __shared__ __attribute__((aligned(16))) float sA[32 * DV_LD];
     __shared__ __attribute__((aligned(16))) float sB[32 * DV_LD];
     __shared__ float sTrue[32];
@@ -89,21 +145,22 @@ __global__ __launch_bounds__(64) void devise_fwd_kernel(const float *__restrict_
     const int64_t row0 = (int64_t)blockIdx.x * 32;
     float *mask = aux + 2 * B;
 
-    // true_sim (utils.py:118): one k-ascending fmaf chain per sample, split over the two half-waves (even / odd half of D)
+    // true_sim (utils.py:118): the sample rows and their target rows go through LDS in the same 64-wide chunks as the class tiles
+    // (coalesced loads; walking D with one dependent global load per element was 2/3 of this kernel at D = 1000); lane (row, half)
+    // runs one k-ascending fmaf chain over the even / odd k of its row and the two halves are added at the end
     {
-        const int64_t r = row0 + col;
         float t = 0.f;
-        if (r < B) {
-            const float *p = yp + r * ldp;
-            const float *e;
-            if (yt) e = yt + r * ldt;
-            else {
-                int64_t y = labels[r];
-                y = y < 0 ? 0 : (y >= C ? C - 1 : y);
-                e = emb + y * lde;
+        for (int64_t k0 = 0; k0 < D; k0 += DV_BK) {
+            __syncthreads();
+            dv_stage(sA, yp, ldp, row0, B, k0, D);
+            dv_stage_target(sB, yt, ldt, labels, emb, lde, row0, B, C, k0, D);
+            __syncthreads();
+            const float *pa = sA + col * DV_LD + hi * 32, *pb = sB + col * DV_LD + hi * 32;
+#pragma unroll
+            for (int s4 = 0; s4 < 32; s4 += 4) {                   // zero padded beyond D: fmaf(0, 0, t) == t
+                const float4 a4 = *(const float4 *)(pa + s4), b4 = *(const float4 *)(pb + s4);
+                t = fmaf(a4.x, b4.x, t); t = fmaf(a4.y, b4.y, t); t = fmaf(a4.z, b4.z, t); t = fmaf(a4.w, b4.w, t);
             }
-            const int64_t half = (D + 1) / 2, d0 = hi ? half : 0, d1 = hi ? D : half;
-            for (int64_t d = d0; d < d1; d++) t = fmaf(p[d], e[d], t);
         }
         t += __shfl_xor(t, 32, 64);
         if (hi == 0) sTrue[col] = t;
@@ -114,7 +171,9 @@ __global__ __launch_bounds__(64) void devise_fwd_kernel(const float *__restrict_
 #pragma unroll
     for (int r = 0; r < 16; r++) { hinge[r] = 0.f; nact[r] = 0.f; }
 
-    for (int64_t c0 = 0; c0 < C; c0 += 32) {
+    const int64_t c_beg = (int64_t)blockIdx.y * tiles_per_block * 32;
+    const int64_t c_end = (c_beg + (int64_t)tiles_per_block * 32 < C) ? c_beg + (int64_t)tiles_per_block * 32 : C;
+    for (int64_t c0 = c_beg; c0 < c_end; c0 += 32) {
         dv_f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[r] = 0.f;
@@ -145,34 +204,78 @@ __global__ __launch_bounds__(64) void devise_fwd_kernel(const float *__restrict_
         }
         const int lr = (r & 3) + 8 * (r >> 2) + 4 * hi;
         if (col == 0 && row0 + lr < B) {
-            loss_i[row0 + lr] = hinge[r] - margin;
-            aux[row0 + lr] = sTrue[lr];
-            aux[B + row0 + lr] = nact[r];
+            if (gridDim.y == 1) {
+                loss_i[row0 + lr] = hinge[r] - margin;
+                aux[row0 + lr] = sTrue[lr];
+                aux[B + row0 + lr] = nact[r];
+            } else {
+                float *part = aux + 2 * B + B * C + (int64_t)blockIdx.y * 2 * B;     // [slices][2][B]
+                part[row0 + lr] = hinge[r];
+                part[B + row0 + lr] = nact[r];
+                if (blockIdx.y == 0) aux[row0 + lr] = sTrue[lr];
+            }
         }
     }
 }
 
-__global__ __launch_bounds__(64) void devise_bwd_kernel(const int64_t *__restrict__ labels, const float *__restrict__ yt, int64_t ldt,
-                                                        const float *__restrict__ emb, int64_t lde, const float *__restrict__ grad_loss_i,
-                                                        float grad_scale, int64_t B, int64_t D, int64_t C, const float *__restrict__ aux,
-                                                        float *__restrict__ dpred, int64_t lddp)
+__global__ __launch_bounds__(256) void devise_finish_kernel(float *__restrict__ aux, int64_t B, int64_t C, int slices, float margin,
+                                                           float *__restrict__ loss_i)
 {
-    __shared__ __attribute__((aligned(16))) float sA[32 * DV_LD];
-    __shared__ __attribute__((aligned(16))) float sB[32 * DV_LD];
-    const int lane = lane_id();
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= B) return;
+    const float *part = aux + 2 * B + B * C;
+    float h = 0.f, n = 0.f;
+    for (int s = 0; s < slices; s++) { h += part[(int64_t)s * 2 * B + r]; n += part[(int64_t)s * 2 * B + B + r]; }
+    loss_i[r] = h - margin;
+    aux[B + r] = n;
+}
+
+static int devise_tiles_per_block(int64_t B, int64_t C)
+{
+    const int64_t tiles = (C + 31) / 32, sample_blocks = (B + 31) / 32;
+    if (tiles <= 2 || sample_blocks >= 1024) return (int)tiles;
+    int64_t slices = 1024 / sample_blocks;                  // aim for ~1024 waves
+    if (slices > tiles) slices = tiles;
+    return (int)((tiles + slices - 1) / slices);
+}
+
+constexpr int DV_BW = 4;      // waves per backward workgroup: each takes every 4th class chunk, sums meet in LDS in wave order
+
+__global__ __launch_bounds__(64 * DV_BW) void devise_bwd_kernel(const int64_t *__restrict__ labels, const float *__restrict__ yt, int64_t ldt,
+                                                                const float *__restrict__ emb, int64_t lde, const float *__restrict__ grad_loss_i,
+                                                                float grad_scale, int64_t B, int64_t D, int64_t C, const float *__restrict__ aux,
+                                                                float *__restrict__ dpred, int64_t lddp)
+{
+    // one 32 x 32 tile of d_pred per workgroup; a single wave walking all C / 64 chunks left a batch of 128 x D = 1000 on 128 waves
+    // with 16 dependent stage -> MFMA rounds each, so the chunks are dealt to DV_BW waves with private staging buffers
+    __shared__ __attribute__((aligned(16))) float sAB[DV_BW][2][32 * DV_LD];
+    __shared__ float sRed[DV_BW - 1][16][64];
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
     const int col = lane & 31, hi = lane >> 5;
     const int64_t row0 = (int64_t)blockIdx.x * 32, d0 = (int64_t)blockIdx.y * 32;
     const float *mask = aux + 2 * B;
+    float *sA = sAB[wave][0], *sB = sAB[wave][1];
     dv_f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[r] = 0.f;
-    for (int64_t c0 = 0; c0 < C; c0 += DV_BK) {          // contraction over the classes
-        __syncthreads();
-        dv_stage(sA, mask, C, row0, B, c0, C);
-        dv_stage_t(sB, emb, lde, d0, D, c0, C);
-        __syncthreads();
+    for (int64_t c0 = (int64_t)wave * DV_BK; c0 < C; c0 += DV_BW * DV_BK) {          // contraction over the classes
+        dv_stage(sA, mask, C, row0, B, c0, C);                                        // wave-private buffers: a wave's LDS writes are
+        dv_stage_t(sB, emb, lde, d0, D, c0, C);                                       // ordered against its own reads by the waitcnt
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         acc = dv_mma_chunk(acc, sA, sB, col, hi, (C - c0 < DV_BK) ? (C - c0) : DV_BK);
+        __builtin_amdgcn_wave_barrier();
     }
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) sRed[wave - 1][r][lane] = acc[r];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int w = 0; w < DV_BW - 1; w++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[r] += sRed[w][r][lane];
     const int64_t d = d0 + col;
 #pragma unroll
     for (int r = 0; r < 16; r++) {
@@ -195,7 +298,13 @@ __global__ __launch_bounds__(64) void devise_bwd_kernel(const int64_t *__restric
 
 using namespace se;
 
-extern "C" int64_t se_devise_aux_floats(int64_t B, int64_t C) { return (B > 0 && C > 0) ? 2 * B + B * C : 0; }
+extern "C" int64_t se_devise_aux_floats(int64_t B, int64_t C)
+{
+    if (B <= 0 || C <= 0) return 0;
+    const int tpb = devise_tiles_per_block(B, C);
+    const int64_t slices = ((C + 31) / 32 + tpb - 1) / tpb;
+    return 2 * B + B * C + (slices > 1 ? slices * 2 * B : 0);       // true_sim, active count, mask [B, C], per-slice partial sums
+}
 
 extern "C" int se_devise_loss_fwd(const float *y_pred, int64_t ldp, const int64_t *labels, const float *y_true, int64_t ldt,
                                   const float *emb, int64_t lde, int64_t B, int64_t D, int64_t C, float margin, float *loss_i,
@@ -205,9 +314,15 @@ extern "C" int se_devise_loss_fwd(const float *y_pred, int64_t ldp, const int64_
     if (B == 0) return SE_OK;
     if (!y_pred || !emb || !loss_i || !aux || (!labels && !y_true)) return fail(SE_ERR_INVALID, "se_devise_loss_fwd: null pointer");
     if (ldp < D || lde < D || (y_true && ldt < D)) return fail(SE_ERR_INVALID, "se_devise_loss_fwd: leading dimension < D");
-    hipLaunchKernelGGL(devise_fwd_kernel, dim3((unsigned)((B + 31) / 32)), dim3(64), 0, (hipStream_t)stream, y_pred, ldp, labels, y_true, ldt,
-                       emb, lde, B, D, C, margin, loss_i, aux);
+    const int tpb = devise_tiles_per_block(B, C);
+    const int64_t slices = ((C + 31) / 32 + tpb - 1) / tpb;
+    hipLaunchKernelGGL(devise_fwd_kernel, dim3((unsigned)((B + 31) / 32), (unsigned)slices), dim3(64), 0, (hipStream_t)stream, y_pred, ldp, labels,
+                       y_true, ldt, emb, lde, B, D, C, margin, loss_i, aux, tpb);
     SE_LAUNCH_CHECK();
+    if (slices > 1) {
+        hipLaunchKernelGGL(devise_finish_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, (hipStream_t)stream, aux, B, C, (int)slices, margin, loss_i);
+        SE_LAUNCH_CHECK();
+    }
     return SE_OK;
 }
 
@@ -220,7 +335,7 @@ extern "C" int se_devise_loss_bwd(const int64_t *labels, const float *y_true, in
     if (!emb || !aux || !d_pred || (!labels && !y_true)) return fail(SE_ERR_INVALID, "se_devise_loss_bwd: null pointer");
     if (lde < D || lddp < D || (y_true && ldt < D)) return fail(SE_ERR_INVALID, "se_devise_loss_bwd: leading dimension < D");
     if ((D + 31) / 32 > 65535) return fail(SE_ERR_UNSUPPORTED, "se_devise_loss_bwd: D too large");
-    hipLaunchKernelGGL(devise_bwd_kernel, dim3((unsigned)((B + 31) / 32), (unsigned)((D + 31) / 32)), dim3(64), 0, (hipStream_t)stream, labels,
+    hipLaunchKernelGGL(devise_bwd_kernel, dim3((unsigned)((B + 31) / 32), (unsigned)((D + 31) / 32)), dim3(64 * DV_BW), 0, (hipStream_t)stream, labels,
                        y_true, ldt, emb, lde, grad_loss_i, grad_scale, B, D, C, aux, d_pred, lddp);
     SE_LAUNCH_CHECK();
     return SE_OK;

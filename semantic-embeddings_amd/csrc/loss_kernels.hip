@@ -212,25 +212,40 @@ constexpr int ACC_LD = ACC_BK + 4;    // padded row pitch (floats): conflict-fre
 __device__ __forceinline__ void stage_tile32(float *lds, const float *src, int64_t ld, int64_t row0,
                                              int64_t nrows, int64_t k0, int64_t K)
 {
-    // 32 rows x 64 k, each lane moves 8 float4 (row = idx / 16, 4 consecutive k = idx % 16)
+    // 32 rows x 64 k, each lane moves 8 float4 (row = idx / 16, 4 consecutive k = idx % 16).  The loads are unconditional
+    // (out-of-range elements read a valid address and are zeroed afterwards) so that all of them are in flight together.
     const int lane = lane_id();
+    float v[8][4];
+    const bool vec = ((ld | K) & 3) == 0 && (((uintptr_t)src) & 15) == 0;          // wave-uniform
 #pragma unroll
     for (int it = 0; it < 8; it++) {
         const int idx = it * 64 + lane;
         const int r = idx >> 4, kq = (idx & 15) * 4;
-        float v[4] = {0.f, 0.f, 0.f, 0.f};
-        if (row0 + r < nrows) {
-            const float *p = src + (row0 + r) * ld + k0 + kq;
+        const bool rok = row0 + r < nrows;
+        const float *p = src + (rok ? row0 + r : row0) * ld;
+        if (vec) {
+            const bool ok = rok && k0 + kq < K;
+            const float4 t = *(const float4 *)(p + (k0 + kq < K ? k0 + kq : 0));
+            v[it][0] = ok ? t.x : 0.f; v[it][1] = ok ? t.y : 0.f; v[it][2] = ok ? t.z : 0.f; v[it][3] = ok ? t.w : 0.f;
+        } else {
 #pragma unroll
-            for (int j = 0; j < 4; j++)
-                if (k0 + kq + j < K) v[j] = p[j];
+            for (int j = 0; j < 4; j++) {
+                const bool kok = k0 + kq + j < K;
+                const float t = p[kok ? k0 + kq + j : 0];
+                v[it][j] = (rok && kok) ? t : 0.f;
+            }
         }
+    }
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+        const int idx = it * 64 + lane;
+        const int r = idx >> 4, kq = (idx & 15) * 4;
         float *o = lds + r * ACC_LD;
         // even k -> [0, 32), odd k -> [32, 64)
-        o[(kq >> 1)] = v[0];
-        o[(kq >> 1) + 1] = v[2];
-        o[32 + (kq >> 1)] = v[1];
-        o[32 + (kq >> 1) + 1] = v[3];
+        o[(kq >> 1)] = v[it][0];
+        o[(kq >> 1) + 1] = v[it][2];
+        o[32 + (kq >> 1)] = v[it][1];
+        o[32 + (kq >> 1) + 1] = v[it][3];
     }
 }
 

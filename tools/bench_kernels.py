@@ -128,6 +128,23 @@ def main():
         xb = xx.bfloat16()
         med, mn = timeit(lambda: sehip.cosine_loss_forward(xb, yy, E, want_xhat=False), args.reps)
         print("loss fwd (no xhat) bf16: median %.3f ms  %.1f GB/s" % (med, (B * D * 6.0) / med / 1e6))
+        # DeViSE ranking loss (utils.py:103-122), forward + backward: the fused MFMA kernels against the same loss written in torch ops
+        for C2, B3 in ((100, 128), (1000, 128), (1000, 1024)):
+            Ed = torch.nn.functional.normalize(torch.randn(C2, C2, device="cuda"), dim=-1)
+            yp = torch.nn.functional.normalize(torch.randn(B3, C2, device="cuda"), dim=-1).requires_grad_(True)
+            yl = torch.randint(0, C2, (B3,), device="cuda")
+
+            def hip_step():
+                yp.grad = None
+                sehip.devise_ranking_loss(yp, yl, Ed, 0.1).mean().backward()
+
+            def torch_step():
+                yp.grad = None
+                true = (yp * Ed[yl]).sum(-1)
+                (torch.relu(0.1 - true[:, None] + yp @ Ed.t()).sum(-1) - 0.1).mean().backward()
+            mh, _ = timeit(hip_step, 20)
+            mt, _ = timeit(torch_step, 20)
+            print("devise fwd+bwd B=%d C=D=%d: HIP %.1f us, torch ops %.1f us" % (B3, C2, mh * 1e3, mt * 1e3))
         B2 = 128
         x2, y2, E2 = torch.randn(B2, 100, device="cuda"), torch.randint(0, 100, (B2,), device="cuda"), E[:100, :100].contiguous()
         med, mn = timeit(lambda: sehip.cosine_loss_forward(x2, y2, E2), 20)
