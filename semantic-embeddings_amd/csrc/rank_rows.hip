@@ -486,11 +486,22 @@ struct RRRankHW {
     }
 };
 
-template <int ITEMS, bool PROF, bool HWORD, int VAR>   // VAR: 0 plain, 1 group-peeling rank phase of the last pass, 2 two-pass path for rows that qualify
+// SEG (rows of more than RR_MAX_N columns, see rank_runs below): the kernel sorts SEGMENTS of rows -- "row" v of the loop is segment
+// v & (2^shift - 1) of matrix row v >> shift -- and instead of ranks it leaves each segment as a sorted RUN in three 16-bit planes
+// (segment-local index, key bits 16-31, key bits 0-15; 512 x ITEMS entries each, the padding sorted last) for the merge kernel.
+struct RankSeg {
+    int shift;            // log2(segments per row)
+    int seg_n;            // columns per segment (a row's last segment may be shorter)
+    uint16_t *planes;     // [3][virtual rows][512 x ITEMS]
+    int64_t plane_elems;  // virtual rows x 512 x ITEMS
+};
+
+template <int ITEMS, bool PROF, bool HWORD, int VAR, bool SEG = false>   // VAR: 0 plain, 1 group-peeling rank phase of the last pass, 2 two-pass path for rows that qualify
 __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_kernel(const float *__restrict__ pdist, int64_t ldp, int64_t Q,
                                                                     int N, void *rank, int64_t ldr, int idx64, int vec_ok,
-                                                                    unsigned long long *prof, const uint32_t *skew_flag)
+                                                                    unsigned long long *prof, const uint32_t *skew_flag, const RankSeg seg)
 {
+    static_assert(!SEG || (HWORD && VAR == 0 && !PROF), "segment runs: plain hardware-ordered build only");
     // one launch per variant when the detector is used: the variants that do not match its flag leave at once
     if (skew_flag && *skew_flag != (uint32_t)VAR) return;
     constexpr bool PEEL = VAR == 1;
@@ -513,6 +524,17 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
     const uint32_t xb = lds_off(xbuf);                                  // exchange buffer, byte address
     const uint32_t rb = xb + 2u * (uint32_t)wpos0;                      // this lane's read slot of step 0
 #define RR_DST(IR) (xb + (((IR) & 0xFFFFu) << 1))
+    // first distance and length of loop row v (SEG: a segment of matrix row v >> shift)
+    auto row_ptr = [&](int64_t v) -> const float * {
+        if constexpr (SEG) return pdist + (v >> seg.shift) * ldp + (v & ((1 << seg.shift) - 1)) * (int64_t)seg.seg_n;
+        else return pdist + v * ldp;
+    };
+    auto row_len = [&](int64_t v) -> int {
+        if constexpr (SEG) {
+            const int rest = N - (int)(v & ((1 << seg.shift) - 1)) * seg.seg_n;
+            return rest < seg.seg_n ? rest : seg.seg_n;
+        } else return N;
+    };
     // tuning aid (SE_RR_PROFILE=1): shader-clock cycles per phase, summed over every workgroup's wave 0
     uint64_t t_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_pp[24] = {}, t_last = PROF ? __builtin_amdgcn_s_memtime() : 0;
 #define RR_T(i) if constexpr (PROF) { lds_wait(); __syncthreads(); /* phase times are workgroup-wide: include the skew between the waves */ const uint64_t now = __builtin_amdgcn_s_memtime(); t_acc[i] += now - t_last; if (rr_pass >= 0) t_pp[(i) * 3 + rr_pass] += now - t_last; t_last = now; } else { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
@@ -523,43 +545,54 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
     // the stores, as in the first version, every row first waited for HBM to absorb its 200-400 KB: 29 % of the kernel.)
     uint32_t key[ITEMS], ir[ITEMS];   // ir = (index << 16) | (within-wave rank, then destination)
     uint32_t ring[RR_RING];
-#define RR_LOAD_ONE(DROW, WPOS, S)                                                                                   \
+#define RR_LOAD_ONE(DROW, WPOS, S, NN)                                                                               \
     {                                                                                                                 \
         /* unconditional load (clamped index; the padding is applied in RR_CANON): a branch around a load makes      \
            hipcc wait for each load before issuing the next */                                                        \
         const int pos = (WPOS) + (S) * WAVE;                                                                          \
-        uint32_t gi = (uint32_t)(pos < N ? pos : N - 1);   /* unsigned: scalar base + 32-bit lane offset addressing */ \
+        uint32_t gi = (uint32_t)(pos < (NN) ? pos : (NN) - 1);   /* unsigned: scalar base + 32-bit lane offset addressing */ \
         opaque(gi);                                                                                                   \
         key[S] = __float_as_uint((DROW)[gi]);                                                                         \
     }
-#define RR_CANON()                                                                                                    \
+#define RR_CANON(NN)                                                                                                  \
     {                                                                                                                 \
         int wpos_ = wpos0;                                                                                            \
         opaque(wpos_);                                                                                                \
         _Pragma("unroll") for (int s = 0; s < ITEMS; s++) {                                                           \
             const int pos = wpos_ + s * WAVE;                                                                         \
-            key[s] = rr_key(key[s], pos >= N); /* pos >= N: all ones */                                               \
+            key[s] = rr_key(key[s], pos >= (NN)); /* pos >= N: all ones */                                            \
         }                                                                                                             \
     }
 #define RR_PREFETCH_NEXT_ROW() \
     if (end >= 32 && more) { \
-                const char *nrow = (const char *)(pdist + (row + gridDim.x) * ldp); \
-                const uint32_t row_bytes = (uint32_t)N * 4u; \
+                const char *nrow = (const char *)row_ptr(row + gridDim.x); \
+                const uint32_t row_bytes = (uint32_t)row_len(row + gridDim.x) * 4u; \
                 for (uint32_t off = (uint32_t)tid * 128u; off < row_bytes; off += RR_THREADS * 128u) \
                     asm volatile("global_load_dword %0, %1, off" : "=v"(pf_sink) : "v"(nrow + off) : "memory"); \
             }
+    // SEG: the exchange buffer is one 16-bit plane of the sorted run -- 16 bytes per lane and step, straight from LDS to the plane
+#define RR_STREAM_PLANE(P, ROW)                                                                                       \
+    {                                                                                                                 \
+        uint16_t *pl = seg.planes + (P) * seg.plane_elems + (ROW) * (int64_t)(RR_THREADS * ITEMS);                    \
+        int j = tid * 8;                                                                                              \
+        opaque(j);                                                                                                    \
+        _Pragma("unroll 2") for (; j < RR_THREADS * ITEMS; j += RR_THREADS * 8)                                       \
+            *reinterpret_cast<uint4 *>(pl + j) = *reinterpret_cast<const uint4 *>(xbuf + j);                          \
+    }
     if ((int64_t)blockIdx.x < Q) {
-        const float *drow = pdist + (int64_t)blockIdx.x * ldp;
+        const float *drow = row_ptr(blockIdx.x);
+        const int n0 = row_len(blockIdx.x);
         int wpos = wpos0;
         opaque(wpos);
 #pragma unroll
-        for (int s = 0; s < ITEMS; s++) RR_LOAD_ONE(drow, wpos, s)
-        RR_CANON()
+        for (int s = 0; s < ITEMS; s++) RR_LOAD_ONE(drow, wpos, s, n0)
+        RR_CANON(n0)
     }
     uint32_t pf_sink = 0;
     [[maybe_unused]] int rr_pass = -1;   // profile build: pass index for the per-pass phase times
     for (int64_t row = blockIdx.x; row < Q; row += gridDim.x) {
         const bool more = row + gridDim.x < Q;
+        [[maybe_unused]] const int n_next = row_len(more ? row + gridDim.x : row);
         // ---- does the row qualify for the two-pass path?  (uniform per row; before the index registers exist: only the keys are live) ----
         bool two = false;
         [[maybe_unused]] int n_out = 0;
@@ -761,23 +794,36 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
             lds_wait();
             __syncthreads();
             RR_T(4)
-            if (end >= 32) break;   // last pass: the index buffer is the ranking
-            RRRead<ITEMS, true>::run(ir, ring, rb);
-            lds_wait();
-            __syncthreads();
+            const bool last = end >= 32;
+            if (last) {
+                if constexpr (!SEG) break;   // last pass: the index buffer is the ranking
+                else {                       // run planes: the indices leave now, the two key halves follow through the same buffer
+                    RR_STREAM_PLANE(0, row)
+                    __syncthreads();
+                }
+            } else {
+                RRRead<ITEMS, true>::run(ir, ring, rb);
+                lds_wait();
+                __syncthreads();
+            }
             RR_T(5)
 #pragma unroll
             for (int s = 0; s < ITEMS; s++) { opaque(ir[s]); lds_st16_hi(RR_DST(ir[s]), key[s]); }          // key bits 16-31  (opaque: no cached addresses)
             lds_wait();
             __syncthreads();
-            RRRead<ITEMS, true>::run(key, ring, rb);
-            lds_wait();
-            if (end < 16) {                                                              // key bits 0-15: still needed by a later pass
+            if (SEG && last) {
+                RR_STREAM_PLANE(1, row)
+            } else {
+                RRRead<ITEMS, true>::run(key, ring, rb);
+                lds_wait();
+            }
+            if (end < 16 || SEG) {                                                       // key bits 0-15: still needed by a later pass (SEG: by the run, so they travel through every pass)
                 __syncthreads();
 #pragma unroll
                 for (int s = 0; s < ITEMS; s++) { opaque(ir[s]); lds_st16_lo(RR_DST(ir[s]), key[s]); }      // (low half is still the old key's)
                 lds_wait();
                 __syncthreads();
+                if (SEG && last) break;      // the key registers are free: the next row is loaded before the last plane is streamed out
                 RRRead<ITEMS, false>::run(key, ring, rb);
                 lds_wait();
             }
@@ -807,15 +853,17 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
         // pushes the 98-key build into scratch; the row was prefetched into L2 during the last pass.  They are issued BEFORE the rank
         // stores and waited for after them: the memory pipeline serves them first and the write-out covers most of their latency.)
         {
-            const float *drow = pdist + (more ? row + gridDim.x : row) * ldp;
+            const float *drow = row_ptr(more ? row + gridDim.x : row);
             int wpos = wpos0;
             opaque(wpos);   // per-row opaque: otherwise hipcc hoists ITEMS row-invariant clamps out of the row loop and keeps them live
 #pragma unroll
-            for (int s = 0; s < ITEMS; s++) RR_LOAD_ONE(drow, wpos, s)
+            for (int s = 0; s < ITEMS; s++) RR_LOAD_ONE(drow, wpos, s, n_next)
         }
         int wt = tid;
         opaque(wt);   // per-row opaque: the write-out offsets are recomputed here instead of living (spilled) across the whole row loop
-        if (idx64) {
+        if constexpr (SEG) {
+            RR_STREAM_PLANE(2, row)
+        } else if (idx64) {
             int64_t *o = (int64_t *)rank + row * ldr;
             // (the next row's keys are live: no unrolling, the LDS read of the next step is issued before this step's stores instead)
             uint2 nv = *reinterpret_cast<const uint2 *>(xbuf + (wt * 4 < N ? wt * 4 : 0));
@@ -859,7 +907,7 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
             }
         }
         RR_T(7)
-        RR_CANON()
+        RR_CANON(n_next)
         if constexpr (PROF) {   // keep the canonicalisation (and with it the wait for the loads) inside the 'load' interval of the phase profile
             _Pragma("unroll") for (int s = 0; s < ITEMS; s++) opaque(key[s]);
         }
@@ -969,7 +1017,7 @@ static int launch_rank_reg_variant(const float *pdist, int64_t ldp, int64_t q, i
         SE_HIP_CHECK(hipMalloc((void **)&prof, 36 * sizeof(unsigned long long)));
         SE_HIP_CHECK(hipMemsetAsync(prof, 0, 36 * sizeof(unsigned long long), s));
     }
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(RR_THREADS), lds, s, pdist, ldp, q, n, rank, ldr, idx64, vec_ok, prof, skew_flag);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(RR_THREADS), lds, s, pdist, ldp, q, n, rank, ldr, idx64, vec_ok, prof, skew_flag, RankSeg{0, 0, nullptr, 0});
     SE_LAUNCH_CHECK();
     if (prof) {
         unsigned long long h[36];
@@ -1016,6 +1064,207 @@ static int launch_rank_reg(const float *pdist, int64_t ldp, int64_t q, int n, vo
     rc = launch_rank_reg_variant<ITEMS, true, 1>(pdist, ldp, q, n, rank, idx64, ldr, flag, s);
     if (rc != SE_OK || !two_ok) return rc;
     return launch_rank_reg_variant<ITEMS, true, two_ok ? 2 : 0>(pdist, ldp, q, n, rank, idx64, ldr, flag, s);
+}
+
+// ---- rows of RR_MAX_N < N <= 2 x RR_MAX_N columns: sorted runs + merge ------------------------------------------------------------
+// A row's working set in the register-resident kernel is 8 bytes of registers + 2 bytes of LDS per key: ~60k keys per CU.  Longer rows
+// are cut by POSITION into two segments, each sorted by that kernel (SEG build: output = a run of (key, segment-local index) in
+// three 16-bit planes), and the two runs are merged: ties between the runs go to the first one, whose indices are all smaller --
+// the canonical (key, index) order.  Per chunk of rows: segment sort (2 virtual rows per row), merge-path partition (one thread per
+// output tile: where the tile starts in run A), tile merge.  Chunks keep the run planes (6 bytes per key) small and cache-warm.
+constexpr int RC_CAP = 1022;   // listed rows (workspace: 256 B of probe / detector words + 4 KB of list)
+constexpr int MG_THREADS = 256;
+constexpr int MG_VT = 16;                         // outputs per thread of the merge kernel (tuning build: SE_MG_VT = 8 / 12 / 16 / 24)
+
+__device__ __forceinline__ uint32_t run_key(const uint16_t *khi, const uint16_t *klo, int i) { return ((uint32_t)khi[i] << 16) | klo[i]; }
+
+// splits[r * (tiles + 1) + t] = number of run-A entries among the first min(t * tile, N) entries of row r's merged order
+__global__ __launch_bounds__(256) void rank_merge_partition_kernel(const uint16_t *__restrict__ planes, int64_t plane_elems, int cap, int seg_n,
+                                                                   int N, int64_t rows, int tiles, int tile, int32_t *__restrict__ splits)
+{
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= rows * (tiles + 1)) return;
+    const int64_t r = g / (tiles + 1);
+    const int t = (int)(g - r * (tiles + 1));
+    const int na = seg_n < N ? seg_n : N, nb = N - na;
+    const uint16_t *ahi = planes + plane_elems + (2 * r) * (int64_t)cap, *alo = ahi + plane_elems;
+    const uint16_t *bhi = ahi + cap, *blo = alo + cap;
+    const int64_t d64 = (int64_t)t * tile;
+    const int d = (int)(d64 < N ? d64 : N);
+    int lo = d > nb ? d - nb : 0, hi = d < na ? d : na;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        // A[mid] goes before B[d - 1 - mid] when its key is <= (ties: run A first)
+        if (run_key(ahi, alo, mid) <= run_key(bhi, blo, d - 1 - mid)) lo = mid + 1;
+        else hi = mid;
+    }
+    splits[g] = lo;
+}
+
+// one part of a tile -> LDS: entries [e0, e0 + cnt) of a run to sK / sI [dst, dst + cnt); 4 entries (8 bytes of each plane) per lane and step
+__device__ __forceinline__ void merge_stage(const uint16_t *ix, const uint16_t *khi, const uint16_t *klo, int e0, int cnt, uint32_t *sK, uint16_t *sI,
+                                            int dst, int tid)
+{
+    const int e1 = e0 + cnt;
+    for (int j = (e0 & ~3) + tid * 4; j < e1; j += MG_THREADS * 4) {
+        const uint2 x = *reinterpret_cast<const uint2 *>(ix + j), h = *reinterpret_cast<const uint2 *>(khi + j), l = *reinterpret_cast<const uint2 *>(klo + j);
+        const uint32_t k[4] = {(h.x << 16) | (l.x & 0xFFFFu), (h.x & 0xFFFF0000u) | (l.x >> 16), (h.y << 16) | (l.y & 0xFFFFu), (h.y & 0xFFFF0000u) | (l.y >> 16)};
+        const uint32_t id[4] = {x.x & 0xFFFFu, x.x >> 16, x.y & 0xFFFFu, x.y >> 16};
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int pos = j + e - e0;
+            if (pos >= 0 && pos < cnt) { sK[dst + pos] = k[e]; sI[dst + pos] = (uint16_t)id[e]; }
+        }
+    }
+}
+
+template <bool IDX64, int VT>
+__global__ __launch_bounds__(MG_THREADS) void rank_merge_kernel(const uint16_t *__restrict__ planes, int64_t plane_elems, int cap, int seg_n, int N,
+                                                                int tiles, const int32_t *__restrict__ splits, void *__restrict__ rank, int64_t ldr,
+                                                                int vec_ok)
+{
+    constexpr int TILE = MG_THREADS * VT;
+    __shared__ __attribute__((aligned(16))) uint32_t sK[TILE + 8];
+    __shared__ __attribute__((aligned(16))) uint16_t sI[TILE + 8];
+    const int tid = threadIdx.x, t = blockIdx.x;
+    const int64_t r = blockIdx.y;
+    const int na_row = seg_n < N ? seg_n : N;
+    const int a0 = splits[r * (tiles + 1) + t], a1 = splits[r * (tiles + 1) + t + 1];
+    const int64_t o0 = (int64_t)t * TILE;
+    const int tot = (int)((o0 + TILE < N ? o0 + TILE : N) - o0);
+    const int b0 = (int)o0 - a0;
+    const int na = a1 - a0, nb = tot - na;
+    const uint16_t *aix = planes + (2 * r) * (int64_t)cap, *ahi = aix + plane_elems, *alo = ahi + plane_elems;
+    // ---- both parts of the tile -> LDS: [0, na) from run A, [na, tot) from run B ----
+    merge_stage(aix, ahi, alo, a0, na, sK, sI, 0, tid);
+    merge_stage(aix + cap, ahi + cap, alo + cap, b0, nb, sK, sI, na, tid);
+    __syncthreads();
+    // ---- this thread's VT outputs start at diagonal d of the tile: merge path through LDS ----
+    const int d = tid * VT < tot ? tid * VT : tot;
+    int lo = d > nb ? d - nb : 0, hi = d < na ? d : na;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (sK[mid] <= sK[na + d - 1 - mid]) lo = mid + 1;
+        else hi = mid;
+    }
+    int a = lo, b = d - lo;
+    uint32_t ka = a < na ? sK[a] : 0u, kb = b < nb ? sK[na + b] : 0u;
+    uint32_t out[VT];
+#pragma unroll
+    for (int i = 0; i < VT; i++) {
+        const bool take_a = (b >= nb) || (a < na && ka <= kb);
+        const int p = take_a ? a : na + b;
+        out[i] = (uint32_t)sI[p < tot ? p : 0] + (take_a ? 0u : (uint32_t)na_row);     // (beyond the tile's end the value is not stored)
+        if (take_a) { a++; ka = sK[a < na ? a : 0]; }
+        else { b++; kb = sK[na + (b < nb ? b : 0)]; }
+    }
+    __syncthreads();
+    // ---- transpose through LDS: 16-byte stores of consecutive ranks ----
+#pragma unroll
+    for (int i = 0; i < VT; i++) sK[tid * VT + i] = out[i];
+    __syncthreads();
+    if constexpr (IDX64) {
+        int64_t *o = (int64_t *)rank + r * ldr + o0;
+        for (int j = tid * 2; j < tot; j += MG_THREADS * 2) {
+            if (vec_ok && j + 1 < tot) *reinterpret_cast<longlong2 *>(o + j) = make_longlong2((int64_t)sK[j], (int64_t)sK[j + 1]);
+            else { o[j] = sK[j]; if (j + 1 < tot) o[j + 1] = sK[j + 1]; }
+        }
+    } else {
+        int32_t *o = (int32_t *)rank + r * ldr + o0;
+        for (int j = tid * 4; j < tot; j += MG_THREADS * 4) {
+            if (vec_ok && j + 3 < tot) *reinterpret_cast<uint4 *>(o + j) = *reinterpret_cast<const uint4 *>(sK + j);
+            else
+                for (int e = 0; e < 4 && j + e < tot; e++) o[j + e] = (int32_t)sK[j + e];
+        }
+    }
+}
+
+static int rank_merge_vt()
+{
+    if (kTuning) { const char *e = tuning_env("SE_MG_VT"); if (e) { const int v = atoi(e); if (v == 8 || v == 12 || v == 24) return v; } }
+    return MG_VT;
+}
+
+static bool rank_runs_ok(int64_t n)
+{
+    static const bool off = tuning_env("SE_RANK_NORUNS") != nullptr;     // -DSE_TUNING build only: long rows take the tiled kernel
+    return !off && n > RR_MAX_N && n <= 2 * (int64_t)RR_MAX_N;
+}
+// rows per chunk and bytes of the runs path's workspace: probe / detector / guard words, the split table, the three run planes
+static int64_t rank_runs_chunk(int64_t q)
+{
+    int64_t c = 2048;
+    if (kTuning) { const char *e = tuning_env("SE_RANK_CHUNK"); if (e && atoll(e) > 0) c = atoll(e); }
+    return q < c ? q : c;
+}
+static int rank_runs_items(int64_t n)
+{
+    const int64_t seg_n = ((n + 1) / 2 + 7) / 8 * 8;
+    const int items = (int)((seg_n + RR_THREADS - 1) / RR_THREADS);
+    return items <= 64 ? 64 : items <= 80 ? 80 : items <= 98 ? 98 : 104;
+}
+constexpr int64_t RUNS_HEAD = 256 + 4 * (RC_CAP + 2);
+static int64_t rank_runs_bytes(int64_t q, int64_t n)
+{
+    const int64_t tile = (int64_t)MG_THREADS * rank_merge_vt();
+    const int64_t chunk = rank_runs_chunk(q), cap = (int64_t)RR_THREADS * rank_runs_items(n), tiles = (n + tile - 1) / tile;
+    const int64_t head = (RUNS_HEAD + 255) / 256 * 256, split_bytes = (chunk * (tiles + 1) * 4 + 255) / 256 * 256;
+    return head + split_bytes + 3 * 2 * chunk * cap * 2;
+}
+
+template <int ITEMS>
+static int launch_rank_runs(const float *pdist, int64_t ldp, int64_t q, int n, void *rank, int idx64, int64_t ldr, void *workspace, hipStream_t s)
+{
+    constexpr bool wide = (size_t)RR_THREADS * ITEMS * sizeof(uint16_t) >= (size_t)RR_WAVES * RR_WIDE_WORDS * sizeof(uint32_t);
+    static_assert(wide, "segment runs use the long-row instantiations");
+    const size_t cnt_words = (size_t)(1 << RR_HW_BITS) / 2;
+    const size_t lds = (RR_WAVES * cnt_words + 32) * sizeof(uint32_t) + (size_t)RR_THREADS * ITEMS * sizeof(uint16_t);
+    auto kern = rank_rows_reg_kernel<ITEMS, false, true, 0, true>;
+    struct Resident { hipError_t err; int64_t grid; };
+    static const Resident res = [&]() -> Resident {
+        hipError_t e = hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        int dev = 0, occ = 0;
+        hipDeviceProp_t prop;
+        if (e == hipSuccess) e = hipGetDevice(&dev);
+        if (e == hipSuccess) e = hipGetDeviceProperties(&prop, dev);
+        if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, (const void *)kern, RR_THREADS, lds);
+        if (e != hipSuccess) return {e, 0};
+        return {hipSuccess, (int64_t)(prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256) * (occ > 0 ? occ : 1)};
+    }();
+    if (res.err != hipSuccess) return fail(SE_ERR_HIP, "se_rank_rows: kernel set-up failed: %s", hipGetErrorString(res.err));
+    const int vt = rank_merge_vt();
+    const int64_t tile = (int64_t)MG_THREADS * vt;
+    const int64_t chunk = rank_runs_chunk(q), cap = (int64_t)RR_THREADS * ITEMS, tiles = ((int64_t)n + tile - 1) / tile;
+    const int seg_n = (int)((((int64_t)n + 1) / 2 + 7) / 8 * 8);
+    const int64_t head = (RUNS_HEAD + 255) / 256 * 256, split_bytes = (chunk * (tiles + 1) * 4 + 255) / 256 * 256;
+    int32_t *splits = (int32_t *)((char *)workspace + head);
+    uint16_t *planes = (uint16_t *)((char *)workspace + head + split_bytes);
+    const int64_t plane_elems = 2 * chunk * cap;
+    const size_t esz = idx64 ? 8 : 4;
+    const int vec_ok = ((((uintptr_t)rank) & 15) == 0) && ((ldr * esz) % 16 == 0);
+    for (int64_t r0 = 0; r0 < q; r0 += chunk) {
+        const int64_t rows = q - r0 < chunk ? q - r0 : chunk, vrows = 2 * rows;
+        const int64_t grid = res.grid < vrows ? res.grid : vrows;
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(RR_THREADS), lds, s, pdist + r0 * ldp, ldp, vrows, n, (void *)nullptr, (int64_t)0, 0, 0,
+                           (unsigned long long *)nullptr, (const uint32_t *)nullptr, RankSeg{1, seg_n, planes, plane_elems});
+        SE_LAUNCH_CHECK();
+        const int64_t nsplit = rows * (tiles + 1);
+        hipLaunchKernelGGL(rank_merge_partition_kernel, dim3((unsigned)((nsplit + 255) / 256)), dim3(256), 0, s, planes, plane_elems, (int)cap, seg_n, n,
+                           rows, (int)tiles, (int)tile, splits);
+        SE_LAUNCH_CHECK();
+        void *rout = (char *)rank + (size_t)r0 * (size_t)ldr * esz;
+        const dim3 mgrid((unsigned)tiles, (unsigned)rows);
+#define SE_MG_LAUNCH(I64, V) hipLaunchKernelGGL((rank_merge_kernel<I64, V>), mgrid, dim3(MG_THREADS), 0, s, planes, plane_elems, (int)cap, seg_n, n, (int)tiles, splits, rout, ldr, vec_ok)
+        if (kTuning && vt != MG_VT) {
+            if (vt == 8) { if (idx64) SE_MG_LAUNCH(true, 8); else SE_MG_LAUNCH(false, 8); }
+            else if (vt == 12) { if (idx64) SE_MG_LAUNCH(true, 12); else SE_MG_LAUNCH(false, 12); }
+            else { if (idx64) SE_MG_LAUNCH(true, 24); else SE_MG_LAUNCH(false, 24); }
+        } else if (idx64) SE_MG_LAUNCH(true, MG_VT);
+        else SE_MG_LAUNCH(false, MG_VT);
+#undef SE_MG_LAUNCH
+        SE_LAUNCH_CHECK();
+    }
+    return SE_OK;
 }
 
 // ---- capability probe for the hardware-ordered ranking --------------------------------------------------
@@ -1144,7 +1393,6 @@ __global__ void rank_inject_kernel(void *rank, int idx64, int64_t ldr, int64_t Q
     else { int32_t *p = (int32_t *)rank + row * ldr + r; const int32_t t = p[0]; p[0] = p[1]; p[1] = t; }
 }
 
-constexpr int RC_CAP = 1022;   // listed rows (workspace: 256 B of probe / detector words + 4 KB of list)
 
 static int rank_check_launch(const float *pdist, int64_t ldp, int64_t q, int n, const void *rank, int idx64, int64_t ldr, uint32_t *bad, int cap,
                              int64_t row_stride, hipStream_t s)
@@ -1192,7 +1440,10 @@ extern "C" int64_t se_rank_rows_workspace_bytes(int64_t q, int64_t n)
 {
     if (q <= 0 || n <= 0) return 0;
     if (!rank_use_tiled(n)) return 256 + 4 * (RC_CAP + 2);   // register-resident kernel: capability probe / detector words + the order guard's row list
-    return (int64_t)rank_grid(q) * 4 * rank_npad(n) * (int64_t)sizeof(uint32_t);
+    const int64_t tiled = (int64_t)rank_grid(q) * 4 * rank_npad(n) * (int64_t)sizeof(uint32_t);
+    if (!rank_runs_ok(n)) return tiled;
+    const int64_t runs = rank_runs_bytes(q, n);              // sorted runs + merge; the tiled kernel stays the fallback (same buffer)
+    return runs > tiled ? runs : tiled;
 }
 
 extern "C" int se_rank_rows(const float *pdist, int64_t ldp, int64_t q, int64_t n, void *rank, int idx64,
@@ -1264,8 +1515,40 @@ extern "C" int se_rank_rows(const float *pdist, int64_t ldp, int64_t q, int64_t 
         }
         return SE_OK;
     }
-    const int64_t need = (int64_t)rank_grid(q) * 4 * rank_npad(n) * (int64_t)sizeof(uint32_t);
+    const int64_t need = se_rank_rows_workspace_bytes(q, n);
     if (!workspace || workspace_bytes < need) return fail(SE_ERR_WORKSPACE, "se_rank_rows: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)need);
+    if (rank_runs_ok(n) && rank_hw_order_ok(workspace, workspace_bytes, s)) {
+        // RR_MAX_N < n <= 2 RR_MAX_N: two sorted runs per row (hardware-ordered register-resident kernel on the halves) + merge
+        const int items = rank_runs_items(n);
+        int rc = SE_ERR_INVALID;
+        if (items == 64) rc = launch_rank_runs<64>(pdist, ldp, q, (int)n, rank, idx64, ldr, workspace, s);
+        else if (items == 80) rc = launch_rank_runs<80>(pdist, ldp, q, (int)n, rank, idx64, ldr, workspace, s);
+        else if (items == 98) rc = launch_rank_runs<98>(pdist, ldp, q, (int)n, rank, idx64, ldr, workspace, s);
+        else rc = launch_rank_runs<104>(pdist, ldp, q, (int)n, rank, idx64, ldr, workspace, s);
+        if (rc != SE_OK) return rc;
+        int dev = 0;
+        const bool have_dev = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64;
+        static const bool check_always = getenv("SE_RANK_CHECK") != nullptr && getenv("SE_RANK_CHECK")[0] != '0';
+        if (!have_dev || !(check_always || rr_checked[dev].load(std::memory_order_acquire) == 0)) return SE_OK;
+        if (kTuning && tuning_env("SE_RANK_NOGUARD")) return SE_OK;
+        if (kTuning && tuning_env("SE_RANK_INJECT")) {
+            hipLaunchKernelGGL(rank_inject_kernel, dim3((unsigned)((q / 7 + 256) / 256)), dim3(256), 0, s, rank, idx64, ldr, q, (int)n);
+            SE_LAUNCH_CHECK();
+        }   // -DSE_TUNING build only: look at the raw output of the run kernels
+        // order guard, as for the short rows: a sample of the rows behind the first hardware-ordered call of the process (every row
+        // under SE_RANK_CHECK=1); on a violation the whole call is redone by the tiled kernel below and the device leaves the fast paths
+        uint32_t *bad = (uint32_t *)((char *)workspace + 256);
+        const int64_t row_stride = check_always ? 1 : (q > 512 ? q / 512 : 1);
+        if (const int rc2 = rank_check_launch(pdist, ldp, q, (int)n, rank, idx64, ldr, bad, RC_CAP, row_stride, s)) return rc2;
+        uint32_t nbad = 0;
+        SE_HIP_CHECK(hipStreamSynchronize(s));
+        SE_HIP_CHECK(hipMemcpy(&nbad, bad, sizeof(uint32_t), hipMemcpyDeviceToHost));
+        rr_checked[dev].store(1, std::memory_order_release);
+        if (nbad == 0) return SE_OK;
+        rr_hw_state[dev].store(-1, std::memory_order_release);
+        fprintf(stderr, "[se_rank_rows] order guard: %u of %lld rows out of canonical order behind the hardware-ordered run kernel -- re-ranking the "
+                        "call with the tiled kernel; device %d leaves the hardware-ordered paths\n", nbad, (long long)q, dev);
+    }
     const size_t lds = sizeof(RankLds);
     if (idx64) {
         SE_HIP_CHECK(hipFuncSetAttribute((const void *)rank_rows_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
