@@ -131,7 +131,7 @@ def test_rank_rows_ties_nan_negzero_int64(sehip):
 @pytest.mark.parametrize("n", [1023, 1025, 4096, 10000, 10241, 20481, 32768, 32769, 40961, 50000, 50177, 53248, 53249, 70001])
 def test_rank_rows_register_kernel_boundaries(sehip, n):
     """Every instantiation of the register-resident kernel (keys per thread 2...104), its last
-    full / first ragged step, and the hand-over to the tiled kernel above 53248 columns; rows mix
+    full / first ragged step, and the hand-over to the sorted-runs path above 53248 columns; rows mix
     gaussian keys with exact-tie runs, NaN, infinities and signed zeros."""
     rng = np.random.default_rng(n)
     pd = rng.standard_normal((3, n)).astype(np.float32)
@@ -312,6 +312,93 @@ def test_rank_order_guard_repairs_injected_violations_in_subprocess(q):
         env.pop("SE_RANK_CHECK")
         out = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
         assert out.returncode == 0 and "guard-ok" in out.stdout and "order guard" in out.stdout, out.stdout
+
+
+def long_rows(n, seed):
+    rng = np.random.default_rng(seed)
+    pd = rng.standard_normal((6, n)).astype(np.float32)
+    pd[1] = rng.integers(-2, 3, size=n).astype(np.float32)          # five values: every tie group spans both segments
+    pd[2, ::3] = pd[2, 0]
+    pd[2, 1:9] = np.array([np.nan, 0.0, -0.0, np.inf, -np.inf, np.nan, 1e-38, -1e-38], dtype=np.float32)
+    pd[3] = 150.0 + 30.0 * np.abs(pd[3])                            # Euclidean-like: one exponent
+    pd[4, n // 2:] = pd[4, :n - n // 2]                             # the second half repeats the first: all ties go to the lower index
+    pd[5, ::2] = np.nan                                             # NaN in both segments, sorted last in index order
+    return pd
+
+
+@pytest.mark.parametrize("n", [53249, 53256, 65536, 65537, 81920, 81921, 100352, 100353, 106496])
+def test_rank_rows_long_rows_sorted_runs(sehip, n):
+    """53,248 < N <= 106,496: two segments sorted by the register-resident kernel (all four long-row instantiations: 64 / 80 / 98 /
+    104 keys per thread, first and last length of each) + merge-path partition + tile merge == the canonical ranking, int32 and
+    int64, ties across the segment boundary in index order."""
+    pd = long_rows(n, n)
+    want = ro.canon_rank_rows(pd)
+    assert np.array_equal(sehip.rank_rows(dev(pd)).cpu().numpy(), want)
+    assert np.array_equal(sehip.rank_rows(dev(pd), idx64=True).cpu().numpy(), want)
+    assert sehip.lib().se_rank_rows_workspace_bytes(6, n) >= 6 * n * 6
+
+
+def test_rank_rows_long_rows_chunks_strides_and_guard(sehip):
+    """More rows than one chunk of the runs path (2,048), a strided unaligned input and output (scalar write-out of the merge),
+    and the order guard's verdict on the result."""
+    q, n = 2100, 53301
+    x = torch.randn(q, n + 3, device="cuda")
+    x[::2, ::5] = 0.25
+    pd = x[:, 1:n + 1]
+    out = torch.empty((q, n + 2), dtype=torch.int32, device="cuda")[:, 1:n + 1]
+    sehip.rank_rows(pd, out=out)
+    want = torch.argsort(pd, dim=1, stable=True)                    # finite keys without signed zeros: the canonical order
+    assert bool((out.long() == want).all())
+    assert sehip.rank_rows_check(pd, out) == 0
+    out64 = sehip.rank_rows(pd[:300], idx64=True)
+    assert bool((out64 == want[:300]).all())
+
+
+def test_rank_rows_above_two_segments_and_pinned_tiled_kernel():
+    """Rows above 106,496 columns keep the tiled kernel; SE_RANK_NORUNS=1 (tuning build) pins it for the shorter ones too -- the
+    fallback of the runs path stays covered."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np, torch\n"
+        "sys.path[:0] = %r\n"
+        "import sehip\n"
+        "from oracle import retrieval_oracle as ro\n"
+        "sys.path.insert(0, %r)\n"
+        "import test_gpu_retrieval as T\n"
+        "for n in (60000, 106497, 131072):\n"
+        "    pd = T.long_rows(n, 1)\n"
+        "    got = sehip.rank_rows(torch.from_numpy(pd).cuda()).cpu().numpy()\n"
+        "    assert np.array_equal(got, ro.canon_rank_rows(pd)), n\n"
+        "print('tiled-ok')\n"
+    ) % ([PKG_DIR, ROOT_DIR], os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SE_RANK_NORUNS="1", SEHIP_LIB=os.path.join(PKG_DIR, "sehip", "libsehip_tuning.so"))
+    out = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert out.returncode == 0 and "tiled-ok" in out.stdout, out.stdout
+
+
+def test_rank_order_guard_behind_the_runs_path_in_subprocess():
+    """SE_RANK_INJECT=1 behind the sorted-runs path: the first-call guard finds the swapped ranks, the call is redone by the tiled
+    kernel and the device leaves the hardware-ordered paths (the next call, short rows, runs the ballot kernel)."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np, torch\n"
+        "sys.path[:0] = %r\n"
+        "import sehip\n"
+        "from oracle import retrieval_oracle as ro\n"
+        "rng = np.random.default_rng(9)\n"
+        "pd = rng.standard_normal((40, 60000)).astype(np.float32)\n"
+        "got = sehip.rank_rows(torch.from_numpy(pd).cuda()).cpu().numpy()\n"
+        "assert np.array_equal(got, ro.canon_rank_rows(pd))\n"
+        "got = sehip.rank_rows(torch.from_numpy(pd[:, :3000]).cuda()).cpu().numpy()\n"
+        "assert np.array_equal(got, ro.canon_rank_rows(pd[:, :3000]))\n"
+        "print('guard-ok')\n"
+    ) % ([PKG_DIR, ROOT_DIR],)
+    env = dict(os.environ, SE_RANK_INJECT="1", SE_RANK_VERBOSE="1", SEHIP_LIB=os.path.join(PKG_DIR, "sehip", "libsehip_tuning.so"))
+    out = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert out.returncode == 0 and "guard-ok" in out.stdout, out.stdout
+    assert "order guard" in out.stdout and "tiled kernel" in out.stdout, out.stdout
 
 
 @pytest.mark.parametrize("n", [300, 5000, 50000])

@@ -63,6 +63,14 @@ def main():
         pd = sehip.pairwise_dist(xe[:q], xe, metric=sehip.METRIC_EUCLID, sqa=sq[:q], sqb=sq, out=pd)
         med, mn = timeit(lambda: sehip.rank_rows(pd, out=rk), args.reps)
         print("rank (Euclidean rows) q=%d n=%d: median %.3f ms (min %.3f)  %.1f GB/s algorithmic" % (q, n, med, mn, 8.0 * q * n / med / 1e6))
+        # rows above 53,248 columns: two sorted runs + merge (real cosine rows: 8,192 queries against a 100,000-row gallery)
+        del pd, rk
+        xl = torch.from_numpy(np.random.default_rng(2).standard_normal((100000, d)).astype(np.float32)).cuda()
+        sehip.normalize_rows_(xl)
+        pdl = sehip.pairwise_dist(xl[:8192], xl, metric=sehip.METRIC_COSINE)
+        rkl = torch.empty((8192, 100000), dtype=torch.int32, device="cuda")
+        med, mn = timeit(lambda: sehip.rank_rows(pdl, out=rkl), args.reps)
+        print("rank (long rows) q=8192 n=100000: median %.3f ms (min %.3f)  %.2f ps per key, %.1f GB/s algorithmic" % (med, mn, med * 1e9 / (8192 * 100000), 8.0 * 8192 * 100000 / med / 1e6))
     elif args.what == "hprec":
         C = 100
         rng = np.random.default_rng(1)
