@@ -324,6 +324,29 @@ def bench_metrics(args, rk, reps=3):
             "metrics": "P@1..250 (WUP, LCS), whole-list AHP (WUP, LCS), AP; 100 classes", "finite": bool(torch.isfinite(res).all().item())}
 
 
+def bench_rank_long_rows(args, reps=3, q=8192, n=100000):
+    """Full ranking of rows above the 53,248-column limit of the register-resident kernel (SURVEY.md 8a row 10 has no size limit:
+    evaluate_retrieval.py:67): q queries against an n-row gallery, real cosine distances.  Two sorted runs per row + merge
+    (DESIGN.md 5.2); reported as time per key beside the headline kernel's."""
+    import sehip
+    x = torch.from_numpy(np.random.default_rng(2).standard_normal((n, args.d)).astype(np.float32)).cuda()
+    sehip.normalize_rows_(x)
+    pd = sehip.pairwise_dist(x[:q], x, metric=sehip.METRIC_COSINE)
+    rk = torch.empty((q, n), dtype=torch.int32, device="cuda")
+    sehip.rank_rows(pd, out=rk)
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); sehip.rank_rows(pd, out=rk); b.record()
+        torch.cuda.synchronize()
+        ts.append(a.elapsed_time(b))
+    ms = float(np.median(ts))
+    bad = sehip.rank_rows_check(pd, rk)
+    return {"ms": ms, "queries": q, "gallery": n, "ps_per_key": ms * 1e9 / (q * n), "algorithmic_GBps": 8.0 * q * n / ms / 1e6,
+            "order_guard_violations": int(bad)}
+
+
 def bench_topk_all_pairs(args, feats_h, reps=3, k=251):
     """The fused distance + top-k on the headline problem (se_retrieve_topk, all-pairs: every item query and gallery item): what
     `evaluate_retrieval.py --clip_ahp K --skip_ap` runs instead of distance matrix + full ranking.  No [Q, N] matrix exists:
@@ -573,6 +596,8 @@ def main(argv=None):
         del rk
         torch.cuda.empty_cache()
         leg("retrieve_topk", lambda: bench_topk_all_pairs(args, feats_h))
+        torch.cuda.empty_cache()
+        leg("rank_long_rows", lambda: bench_rank_long_rows(args))
         torch.cuda.empty_cache()
         if args.with_sharded:
             leg("sharded_gallery", lambda: bench_sharded_gallery(args, rank, world))

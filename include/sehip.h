@@ -199,7 +199,7 @@ int se_pairwise_dist(const float *a, int64_t lda, const float *b, int64_t ldb, c
  * Replaces: `ranking = np.argsort(pdist, axis = -1)`              evaluate_retrieval.py:67
  * (the reference's sort is unstable: ties are returned in canonical order here).
  *   rank: int32 [q, n] when idx64 == 0, int64 [q, n] (NumPy's dtype) otherwise.
- *   workspace: se_rank_rows_workspace_bytes(q, n) bytes of device memory.  n <= 53,248: one workgroup sorts a row in registers
+ *   workspace: se_rank_rows_workspace_bytes(q, n) bytes of device memory, 16-byte aligned.  n <= 53,248: one workgroup sorts a row in registers
  *   (4.4 KB of workspace: probe / guard words); 53,248 < n <= 106,496: the two halves of a row are sorted the same way into runs
  *   (6 bytes per key for 2,048 rows at a time) and merged; longer rows: LDS-tiled radix sort through 16 bytes per key of scratch
  *   per resident workgroup.

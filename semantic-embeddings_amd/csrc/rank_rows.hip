@@ -1517,6 +1517,7 @@ extern "C" int se_rank_rows(const float *pdist, int64_t ldp, int64_t q, int64_t 
     }
     const int64_t need = se_rank_rows_workspace_bytes(q, n);
     if (!workspace || workspace_bytes < need) return fail(SE_ERR_WORKSPACE, "se_rank_rows: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)need);
+    if ((((uintptr_t)workspace) & 15) != 0) return fail(SE_ERR_INVALID, "se_rank_rows: workspace must be 16-byte aligned");
     if (rank_runs_ok(n) && rank_hw_order_ok(workspace, workspace_bytes, s)) {
         // RR_MAX_N < n <= 2 RR_MAX_N: two sorted runs per row (hardware-ordered register-resident kernel on the halves) + merge
         const int items = rank_runs_items(n);

@@ -128,7 +128,7 @@ def test_rank_rows_ties_nan_negzero_int64(sehip):
     assert np.array_equal(got64, want)
 
 
-@pytest.mark.parametrize("n", [1023, 1025, 4096, 10000, 10241, 20481, 32768, 32769, 40961, 50000, 50177, 53248, 53249, 70001])
+@pytest.mark.parametrize("n", [1023, 1025, 4096, 10000, 10241, 20481, 32768, 32769, 40961, 50000, 50177, 53248, 53249, 65536, 70001, 100000])
 def test_rank_rows_register_kernel_boundaries(sehip, n):
     """Every instantiation of the register-resident kernel (keys per thread 2...104), its last
     full / first ragged step, and the hand-over to the sorted-runs path above 53248 columns; rows mix
