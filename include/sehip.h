@@ -200,9 +200,9 @@ int se_pairwise_dist(const float *a, int64_t lda, const float *b, int64_t ldb, c
  * (the reference's sort is unstable: ties are returned in canonical order here).
  *   rank: int32 [q, n] when idx64 == 0, int64 [q, n] (NumPy's dtype) otherwise.
  *   workspace: se_rank_rows_workspace_bytes(q, n) bytes of device memory, 16-byte aligned.  n <= 53,248: one workgroup sorts a row in registers
- *   (4.4 KB of workspace: probe / guard words); 53,248 < n <= 106,496: the two halves of a row are sorted the same way into runs
- *   (6 bytes per key for 2,048 rows at a time) and merged; longer rows: LDS-tiled radix sort through 16 bytes per key of scratch
- *   per resident workgroup.
+ *   (4.4 KB of workspace: probe / guard words); 53,248 < n <= 425,984: 2, 4 or 8 segments of a row are sorted the same way into
+ *   runs and merged pairwise (merge tree; up to 1.5 GB of run planes / level buffers for a chunk of rows at a time); longer rows:
+ *   LDS-tiled radix sort through 16 bytes per key of scratch per resident workgroup.
  */
 int64_t se_rank_rows_workspace_bytes(int64_t q, int64_t n);
 int se_rank_rows(const float *pdist, int64_t ldp, int64_t q, int64_t n, void *rank, int idx64,

@@ -23,6 +23,7 @@
 #include "se_common.h"
 #include <stdlib.h>
 #include <atomic>
+#include <type_traits>
 
 namespace se {
 
@@ -1066,78 +1067,112 @@ static int launch_rank_reg(const float *pdist, int64_t ldp, int64_t q, int n, vo
     return launch_rank_reg_variant<ITEMS, true, two_ok ? 2 : 0>(pdist, ldp, q, n, rank, idx64, ldr, flag, s);
 }
 
-// ---- rows of RR_MAX_N < N <= 2 x RR_MAX_N columns: sorted runs + merge ------------------------------------------------------------
+// ---- rows of more than RR_MAX_N columns: sorted runs + merge tree -----------------------------------------------------------------
 // A row's working set in the register-resident kernel is 8 bytes of registers + 2 bytes of LDS per key: ~60k keys per CU.  Longer rows
-// are cut by POSITION into two segments, each sorted by that kernel (SEG build: output = a run of (key, segment-local index) in
-// three 16-bit planes), and the two runs are merged: ties between the runs go to the first one, whose indices are all smaller --
-// the canonical (key, index) order.  Per chunk of rows: segment sort (2 virtual rows per row), merge-path partition (one thread per
-// output tile: where the tile starts in run A), tile merge.  Chunks keep the run planes (6 bytes per key) small and cache-warm.
+// are cut by POSITION into S = 2, 4 or 8 segments, each sorted by that kernel (SEG build: output = a run of (key, segment-local
+// index) in three 16-bit planes), and the runs are merged pairwise, level by level: ties between two runs go to the first one, whose
+// indices are all smaller -- the canonical (key, index) order.  The last level writes the ranks; the levels before it (S > 2) write
+// merged runs as (key, index) dword arrays laid out along the row (a run made of segments j .. j' starts at entry j x seg_n).  Per
+// chunk of rows and level: merge-path partition (one thread per output tile: where the tile starts in the pair's first run), tile
+// merge.  Chunks keep the scratch (6 bytes per key for the planes, 8 per intermediate level buffer) bounded.
 constexpr int RC_CAP = 1022;   // listed rows (workspace: 256 B of probe / detector words + 4 KB of list)
 constexpr int MG_THREADS = 256;
-constexpr int MG_VT = 16;                         // outputs per thread of the merge kernel (tuning build: SE_MG_VT = 8 / 12 / 16 / 24)
+constexpr int MG_VT = 16;                         // outputs per thread of the merge kernel (tuning build: SE_MG_VT = 8 / 12 / 24)
+constexpr int RUNS_MAX_SEG = 8;
 
-__device__ __forceinline__ uint32_t run_key(const uint16_t *khi, const uint16_t *klo, int i) { return ((uint32_t)khi[i] << 16) | klo[i]; }
+struct MergeLevel {
+    // input runs of a row: run j covers entries [j * run_n, min(N, (j + 1) * run_n)); pair p merges runs 2p and 2p + 1
+    int run_n, N, pairs, tiles, tile;      // tiles per pair (of `tile` outputs each)
+    // planes input (first level): run j of chunk row r = virtual row r * (2 * pairs) + j, `cap` entries per plane row
+    const uint16_t *planes; int64_t plane_elems; int cap;
+    // dword input (later levels): key / index arrays, `ld` entries per row, runs at their row offsets
+    const uint32_t *in_key, *in_idx; int64_t ld;
+};
 
-// splits[r * (tiles + 1) + t] = number of run-A entries among the first min(t * tile, N) entries of row r's merged order
-__global__ __launch_bounds__(256) void rank_merge_partition_kernel(const uint16_t *__restrict__ planes, int64_t plane_elems, int cap, int seg_n,
-                                                                   int N, int64_t rows, int tiles, int tile, int32_t *__restrict__ splits)
+template <bool PLANES>
+__device__ __forceinline__ uint32_t level_key(const MergeLevel &L, int64_t r, int run, int i)
+{
+    if constexpr (PLANES) {
+        const uint16_t *khi = L.planes + L.plane_elems + (r * (2 * L.pairs) + run) * (int64_t)L.cap, *klo = khi + L.plane_elems;
+        return ((uint32_t)khi[i] << 16) | klo[i];
+    } else return L.in_key[r * L.ld + (int64_t)run * L.run_n + i];
+}
+__device__ __forceinline__ int level_run_len(const MergeLevel &L, int run)
+{
+    const int64_t rest = (int64_t)L.N - (int64_t)run * L.run_n;
+    return rest <= 0 ? 0 : (rest < L.run_n ? (int)rest : L.run_n);
+}
+
+// splits[(r * pairs + p) * (tiles + 1) + t] = entries of the pair's first run among the first min(t * tile, pair length) merged entries
+template <bool PLANES>
+__global__ __launch_bounds__(256) void rank_merge_partition_kernel(const MergeLevel L, int64_t rows, int32_t *__restrict__ splits)
 {
     const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (g >= rows * (tiles + 1)) return;
-    const int64_t r = g / (tiles + 1);
-    const int t = (int)(g - r * (tiles + 1));
-    const int na = seg_n < N ? seg_n : N, nb = N - na;
-    const uint16_t *ahi = planes + plane_elems + (2 * r) * (int64_t)cap, *alo = ahi + plane_elems;
-    const uint16_t *bhi = ahi + cap, *blo = alo + cap;
-    const int64_t d64 = (int64_t)t * tile;
-    const int d = (int)(d64 < N ? d64 : N);
+    if (g >= rows * L.pairs * (L.tiles + 1)) return;
+    const int64_t rp = g / (L.tiles + 1);
+    const int t = (int)(g - rp * (L.tiles + 1));
+    const int64_t r = rp / L.pairs;
+    const int p = (int)(rp - r * L.pairs);
+    const int na = level_run_len(L, 2 * p), nb = level_run_len(L, 2 * p + 1);
+    const int64_t d64 = (int64_t)t * L.tile;
+    const int d = (int)(d64 < na + nb ? d64 : na + nb);
     int lo = d > nb ? d - nb : 0, hi = d < na ? d : na;
     while (lo < hi) {
         const int mid = (lo + hi) >> 1;
         // A[mid] goes before B[d - 1 - mid] when its key is <= (ties: run A first)
-        if (run_key(ahi, alo, mid) <= run_key(bhi, blo, d - 1 - mid)) lo = mid + 1;
+        if (level_key<PLANES>(L, r, 2 * p, mid) <= level_key<PLANES>(L, r, 2 * p + 1, d - 1 - mid)) lo = mid + 1;
         else hi = mid;
     }
     splits[g] = lo;
 }
 
-// one part of a tile -> LDS: entries [e0, e0 + cnt) of a run to sK / sI [dst, dst + cnt); 4 entries (8 bytes of each plane) per lane and step
-__device__ __forceinline__ void merge_stage(const uint16_t *ix, const uint16_t *khi, const uint16_t *klo, int e0, int cnt, uint32_t *sK, uint16_t *sI,
-                                            int dst, int tid)
+// one part of a tile -> LDS: entries [e0, e0 + cnt) of a run to sK / sI [dst, dst + cnt)
+template <bool PLANES, typename IT>
+__device__ __forceinline__ void merge_stage(const MergeLevel &L, int64_t r, int run, int e0, int cnt, uint32_t *sK, IT *sI, int dst, int tid)
 {
-    const int e1 = e0 + cnt;
-    for (int j = (e0 & ~3) + tid * 4; j < e1; j += MG_THREADS * 4) {
-        const uint2 x = *reinterpret_cast<const uint2 *>(ix + j), h = *reinterpret_cast<const uint2 *>(khi + j), l = *reinterpret_cast<const uint2 *>(klo + j);
-        const uint32_t k[4] = {(h.x << 16) | (l.x & 0xFFFFu), (h.x & 0xFFFF0000u) | (l.x >> 16), (h.y << 16) | (l.y & 0xFFFFu), (h.y & 0xFFFF0000u) | (l.y >> 16)};
-        const uint32_t id[4] = {x.x & 0xFFFFu, x.x >> 16, x.y & 0xFFFFu, x.y >> 16};
+    if constexpr (PLANES) {     // 4 entries (8 bytes of each plane) per lane and step
+        const uint16_t *ix = L.planes + (r * (2 * L.pairs) + run) * (int64_t)L.cap, *khi = ix + L.plane_elems, *klo = khi + L.plane_elems;
+        const int e1 = e0 + cnt;
+        for (int j = (e0 & ~3) + tid * 4; j < e1; j += MG_THREADS * 4) {
+            const uint2 x = *reinterpret_cast<const uint2 *>(ix + j), h = *reinterpret_cast<const uint2 *>(khi + j), l = *reinterpret_cast<const uint2 *>(klo + j);
+            const uint32_t k[4] = {(h.x << 16) | (l.x & 0xFFFFu), (h.x & 0xFFFF0000u) | (l.x >> 16), (h.y << 16) | (l.y & 0xFFFFu), (h.y & 0xFFFF0000u) | (l.y >> 16)};
+            const uint32_t id[4] = {x.x & 0xFFFFu, x.x >> 16, x.y & 0xFFFFu, x.y >> 16};
 #pragma unroll
-        for (int e = 0; e < 4; e++) {
-            const int pos = j + e - e0;
-            if (pos >= 0 && pos < cnt) { sK[dst + pos] = k[e]; sI[dst + pos] = (uint16_t)id[e]; }
+            for (int e = 0; e < 4; e++) {
+                const int pos = j + e - e0;
+                if (pos >= 0 && pos < cnt) { sK[dst + pos] = k[e]; sI[dst + pos] = (IT)id[e]; }
+            }
         }
+    } else {
+        const uint32_t *k = L.in_key + r * L.ld + (int64_t)run * L.run_n + e0, *ix = L.in_idx + r * L.ld + (int64_t)run * L.run_n + e0;
+        for (int j = tid; j < cnt; j += MG_THREADS) { sK[dst + j] = k[j]; sI[dst + j] = (IT)ix[j]; }
     }
 }
 
-template <bool IDX64, int VT>
-__global__ __launch_bounds__(MG_THREADS) void rank_merge_kernel(const uint16_t *__restrict__ planes, int64_t plane_elems, int cap, int seg_n, int N,
-                                                                int tiles, const int32_t *__restrict__ splits, void *__restrict__ rank, int64_t ldr,
-                                                                int vec_ok)
+// OUT_RANKS: the level's single pair is the whole row and its merged order is the ranking; otherwise the merged run goes to
+// out_key / out_idx (dword arrays like the later levels' input).
+template <bool PLANES, bool OUT_RANKS, bool IDX64, int VT>
+__global__ __launch_bounds__(MG_THREADS) void rank_merge_kernel(const MergeLevel L, const int32_t *__restrict__ splits, void *__restrict__ rank, int64_t ldr,
+                                                                int vec_ok, uint32_t *__restrict__ out_key, uint32_t *__restrict__ out_idx)
 {
     constexpr int TILE = MG_THREADS * VT;
+    using IT = typename std::conditional<PLANES, uint16_t, uint32_t>::type;
     __shared__ __attribute__((aligned(16))) uint32_t sK[TILE + 8];
-    __shared__ __attribute__((aligned(16))) uint16_t sI[TILE + 8];
-    const int tid = threadIdx.x, t = blockIdx.x;
+    __shared__ __attribute__((aligned(16))) IT sI[TILE + 8];
+    const int tid = threadIdx.x;
+    const int p = blockIdx.x / L.tiles, t = blockIdx.x - p * L.tiles;
     const int64_t r = blockIdx.y;
-    const int na_row = seg_n < N ? seg_n : N;
-    const int a0 = splits[r * (tiles + 1) + t], a1 = splits[r * (tiles + 1) + t + 1];
+    const int na_run = level_run_len(L, 2 * p), nb_run = level_run_len(L, 2 * p + 1);
     const int64_t o0 = (int64_t)t * TILE;
-    const int tot = (int)((o0 + TILE < N ? o0 + TILE : N) - o0);
+    if (o0 >= na_run + nb_run) return;               // (a row's last pair may be shorter than the others: whole workgroup)
+    const int32_t *sp = splits + (r * L.pairs + p) * (int64_t)(L.tiles + 1) + t;
+    const int a0 = sp[0], a1 = sp[1];
+    const int tot = (int)((o0 + TILE < na_run + nb_run ? o0 + TILE : na_run + nb_run) - o0);
     const int b0 = (int)o0 - a0;
     const int na = a1 - a0, nb = tot - na;
-    const uint16_t *aix = planes + (2 * r) * (int64_t)cap, *ahi = aix + plane_elems, *alo = ahi + plane_elems;
     // ---- both parts of the tile -> LDS: [0, na) from run A, [na, tot) from run B ----
-    merge_stage(aix, ahi, alo, a0, na, sK, sI, 0, tid);
-    merge_stage(aix + cap, ahi + cap, alo + cap, b0, nb, sK, sI, na, tid);
+    merge_stage<PLANES>(L, r, 2 * p, a0, na, sK, sI, 0, tid);
+    merge_stage<PLANES>(L, r, 2 * p + 1, b0, nb, sK, sI, na, tid);
     __syncthreads();
     // ---- this thread's VT outputs start at diagonal d of the tile: merge path through LDS ----
     const int d = tid * VT < tot ? tid * VT : tot;
@@ -1149,33 +1184,51 @@ __global__ __launch_bounds__(MG_THREADS) void rank_merge_kernel(const uint16_t *
     }
     int a = lo, b = d - lo;
     uint32_t ka = a < na ? sK[a] : 0u, kb = b < nb ? sK[na + b] : 0u;
+    // planes carry segment-local indices: the segment's first column is added here (run A = segment 2p, run B = segment 2p + 1)
+    const uint32_t base_a = PLANES ? (uint32_t)(2 * p) * (uint32_t)L.run_n : 0u, base_b = PLANES ? base_a + (uint32_t)L.run_n : 0u;
     uint32_t out[VT];
+    [[maybe_unused]] uint32_t outk[OUT_RANKS ? 1 : VT];
 #pragma unroll
     for (int i = 0; i < VT; i++) {
         const bool take_a = (b >= nb) || (a < na && ka <= kb);
-        const int p = take_a ? a : na + b;
-        out[i] = (uint32_t)sI[p < tot ? p : 0] + (take_a ? 0u : (uint32_t)na_row);     // (beyond the tile's end the value is not stored)
+        const int pp = take_a ? a : na + b;
+        out[i] = (uint32_t)sI[pp < tot ? pp : 0] + (take_a ? base_a : base_b);     // (beyond the tile's end the value is not stored)
+        if constexpr (!OUT_RANKS) outk[i] = take_a ? ka : kb;
         if (take_a) { a++; ka = sK[a < na ? a : 0]; }
         else { b++; kb = sK[na + (b < nb ? b : 0)]; }
     }
     __syncthreads();
-    // ---- transpose through LDS: 16-byte stores of consecutive ranks ----
+    if constexpr (OUT_RANKS) {
+        // ---- transpose through LDS: 16-byte stores of consecutive ranks ----
 #pragma unroll
-    for (int i = 0; i < VT; i++) sK[tid * VT + i] = out[i];
-    __syncthreads();
-    if constexpr (IDX64) {
-        int64_t *o = (int64_t *)rank + r * ldr + o0;
-        for (int j = tid * 2; j < tot; j += MG_THREADS * 2) {
-            if (vec_ok && j + 1 < tot) *reinterpret_cast<longlong2 *>(o + j) = make_longlong2((int64_t)sK[j], (int64_t)sK[j + 1]);
-            else { o[j] = sK[j]; if (j + 1 < tot) o[j + 1] = sK[j + 1]; }
+        for (int i = 0; i < VT; i++) sK[tid * VT + i] = out[i];
+        __syncthreads();
+        if constexpr (IDX64) {
+            int64_t *o = (int64_t *)rank + r * ldr + o0;
+            for (int j = tid * 2; j < tot; j += MG_THREADS * 2) {
+                if (vec_ok && j + 1 < tot) *reinterpret_cast<longlong2 *>(o + j) = make_longlong2((int64_t)sK[j], (int64_t)sK[j + 1]);
+                else { o[j] = sK[j]; if (j + 1 < tot) o[j + 1] = sK[j + 1]; }
+            }
+        } else {
+            int32_t *o = (int32_t *)rank + r * ldr + o0;
+            for (int j = tid * 4; j < tot; j += MG_THREADS * 4) {
+                if (vec_ok && j + 3 < tot) *reinterpret_cast<uint4 *>(o + j) = *reinterpret_cast<const uint4 *>(sK + j);
+                else
+                    for (int e = 0; e < 4 && j + e < tot; e++) o[j + e] = (int32_t)sK[j + e];
+            }
         }
     } else {
-        int32_t *o = (int32_t *)rank + r * ldr + o0;
-        for (int j = tid * 4; j < tot; j += MG_THREADS * 4) {
-            if (vec_ok && j + 3 < tot) *reinterpret_cast<uint4 *>(o + j) = *reinterpret_cast<const uint4 *>(sK + j);
-            else
-                for (int e = 0; e < 4 && j + e < tot; e++) o[j + e] = (int32_t)sK[j + e];
-        }
+        // ---- merged run: keys and indices to the level buffers, coalesced through LDS (sK: keys; the indices follow through it too) ----
+        const int64_t ob = r * L.ld + (int64_t)(2 * p) * L.run_n + o0;
+#pragma unroll
+        for (int i = 0; i < VT; i++) sK[tid * VT + i] = outk[i];
+        __syncthreads();
+        for (int j = tid; j < tot; j += MG_THREADS) out_key[ob + j] = sK[j];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < VT; i++) sK[tid * VT + i] = out[i];
+        __syncthreads();
+        for (int j = tid; j < tot; j += MG_THREADS) out_idx[ob + j] = sK[j];
     }
 }
 
@@ -1185,31 +1238,71 @@ static int rank_merge_vt()
     return MG_VT;
 }
 
-static bool rank_runs_ok(int64_t n)
+// segments per row: the smallest of 2 / 4 / 8 whose segments fit the register-resident kernel; 0 = none (tiled kernel)
+static int rank_runs_segments(int64_t n)
 {
     static const bool off = tuning_env("SE_RANK_NORUNS") != nullptr;     // -DSE_TUNING build only: long rows take the tiled kernel
-    return !off && n > RR_MAX_N && n <= 2 * (int64_t)RR_MAX_N;
+    if (off || n <= RR_MAX_N) return 0;
+    for (int sgm = 2; sgm <= RUNS_MAX_SEG; sgm *= 2)
+        if (((n + sgm - 1) / sgm + 7) / 8 * 8 <= RR_MAX_N) return sgm;
+    return 0;
 }
-// rows per chunk and bytes of the runs path's workspace: probe / detector / guard words, the split table, the three run planes
-static int64_t rank_runs_chunk(int64_t q)
-{
-    int64_t c = 2048;
-    if (kTuning) { const char *e = tuning_env("SE_RANK_CHUNK"); if (e && atoll(e) > 0) c = atoll(e); }
-    return q < c ? q : c;
-}
+static bool rank_runs_ok(int64_t n) { return rank_runs_segments(n) != 0; }
+static int64_t rank_runs_seg_n(int64_t n) { const int sgm = rank_runs_segments(n); return ((n + sgm - 1) / sgm + 7) / 8 * 8; }
 static int rank_runs_items(int64_t n)
 {
-    const int64_t seg_n = ((n + 1) / 2 + 7) / 8 * 8;
-    const int items = (int)((seg_n + RR_THREADS - 1) / RR_THREADS);
+    const int items = (int)((rank_runs_seg_n(n) + RR_THREADS - 1) / RR_THREADS);
     return items <= 64 ? 64 : items <= 80 ? 80 : items <= 98 ? 98 : 104;
 }
 constexpr int64_t RUNS_HEAD = 256 + 4 * (RC_CAP + 2);
-static int64_t rank_runs_bytes(int64_t q, int64_t n)
+struct RunsLayout { int64_t chunk, cap, tile, split_words, head, split_bytes, plane_bytes, level_bytes, total; int sgm; };
+static RunsLayout rank_runs_layout(int64_t q, int64_t n)
 {
-    const int64_t tile = (int64_t)MG_THREADS * rank_merge_vt();
-    const int64_t chunk = rank_runs_chunk(q), cap = (int64_t)RR_THREADS * rank_runs_items(n), tiles = (n + tile - 1) / tile;
-    const int64_t head = (RUNS_HEAD + 255) / 256 * 256, split_bytes = (chunk * (tiles + 1) * 4 + 255) / 256 * 256;
-    return head + split_bytes + 3 * 2 * chunk * cap * 2;
+    RunsLayout y;
+    y.sgm = rank_runs_segments(n);
+    y.cap = (int64_t)RR_THREADS * rank_runs_items(n);
+    y.tile = (int64_t)MG_THREADS * rank_merge_vt();
+    // rows per chunk: ~1.5 GB of planes + level buffers, at most 2,048 rows (tuning build: SE_RANK_CHUNK)
+    const int64_t per_row = 6 * y.sgm * y.cap + (y.sgm > 2 ? 8 * (n + 8) : 0) + (y.sgm > 4 ? 8 * (n + 8) : 0);
+    int64_t c = (int64_t)1536 * 1024 * 1024 / per_row;
+    c = c > 2048 ? 2048 : (c < 64 ? 64 : c);
+    if (kTuning) { const char *e = tuning_env("SE_RANK_CHUNK"); if (e && atoll(e) > 0) c = atoll(e); }
+    y.chunk = q < c ? q : c;
+    // split table: the first level has the most entries (rows x pairs x (tiles + 1), tiles per pair of 2 seg_n entries)
+    const int64_t seg_n = rank_runs_seg_n(n);
+    int64_t most = 0;
+    for (int64_t pairs = y.sgm / 2, run = seg_n; pairs >= 1; pairs /= 2, run *= 2) {
+        const int64_t words = y.chunk * pairs * ((2 * run + y.tile - 1) / y.tile + 1);
+        most = words > most ? words : most;
+    }
+    y.split_words = most;
+    y.head = (RUNS_HEAD + 255) / 256 * 256;
+    y.split_bytes = (most * 4 + 255) / 256 * 256;
+    y.plane_bytes = (3 * y.sgm * y.chunk * y.cap * 2 + 255) / 256 * 256;
+    y.level_bytes = y.sgm > 2 ? (y.chunk * (n + 8) * 4 + 255) / 256 * 256 : 0;      // one dword array of a level buffer
+    y.total = y.head + y.split_bytes + y.plane_bytes + (y.sgm > 2 ? 2 : 0) * y.level_bytes + (y.sgm > 4 ? 2 : 0) * y.level_bytes;
+    return y;
+}
+static int64_t rank_runs_bytes(int64_t q, int64_t n) { return rank_runs_layout(q, n).total; }
+
+template <bool PLANES, bool OUT_RANKS>
+static int launch_merge_level(const MergeLevel &L, int64_t rows, int32_t *splits, void *rout, int idx64, int64_t ldr, int vec_ok, uint32_t *out_key,
+                              uint32_t *out_idx, int vt, hipStream_t s)
+{
+    const int64_t nsplit = rows * L.pairs * (L.tiles + 1);
+    hipLaunchKernelGGL(rank_merge_partition_kernel<PLANES>, dim3((unsigned)((nsplit + 255) / 256)), dim3(256), 0, s, L, rows, splits);
+    SE_LAUNCH_CHECK();
+    const dim3 mgrid((unsigned)(L.pairs * L.tiles), (unsigned)rows);
+#define SE_MG_LAUNCH(I64, V) hipLaunchKernelGGL((rank_merge_kernel<PLANES, OUT_RANKS, I64, V>), mgrid, dim3(MG_THREADS), 0, s, L, splits, rout, ldr, vec_ok, out_key, out_idx)
+    if (kTuning && vt != MG_VT) {
+        if (vt == 8) { if (OUT_RANKS && idx64) SE_MG_LAUNCH(true, 8); else SE_MG_LAUNCH(false, 8); }
+        else if (vt == 12) { if (OUT_RANKS && idx64) SE_MG_LAUNCH(true, 12); else SE_MG_LAUNCH(false, 12); }
+        else { if (OUT_RANKS && idx64) SE_MG_LAUNCH(true, 24); else SE_MG_LAUNCH(false, 24); }
+    } else if (OUT_RANKS && idx64) SE_MG_LAUNCH(true, MG_VT);
+    else SE_MG_LAUNCH(false, MG_VT);
+#undef SE_MG_LAUNCH
+    SE_LAUNCH_CHECK();
+    return SE_OK;
 }
 
 template <int ITEMS>
@@ -1232,37 +1325,43 @@ static int launch_rank_runs(const float *pdist, int64_t ldp, int64_t q, int n, v
         return {hipSuccess, (int64_t)(prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256) * (occ > 0 ? occ : 1)};
     }();
     if (res.err != hipSuccess) return fail(SE_ERR_HIP, "se_rank_rows: kernel set-up failed: %s", hipGetErrorString(res.err));
-    const int vt = rank_merge_vt();
-    const int64_t tile = (int64_t)MG_THREADS * vt;
-    const int64_t chunk = rank_runs_chunk(q), cap = (int64_t)RR_THREADS * ITEMS, tiles = ((int64_t)n + tile - 1) / tile;
-    const int seg_n = (int)((((int64_t)n + 1) / 2 + 7) / 8 * 8);
-    const int64_t head = (RUNS_HEAD + 255) / 256 * 256, split_bytes = (chunk * (tiles + 1) * 4 + 255) / 256 * 256;
-    int32_t *splits = (int32_t *)((char *)workspace + head);
-    uint16_t *planes = (uint16_t *)((char *)workspace + head + split_bytes);
-    const int64_t plane_elems = 2 * chunk * cap;
+    const RunsLayout y = rank_runs_layout(q, n);
+    if (y.cap != (int64_t)RR_THREADS * ITEMS) return fail(SE_ERR_INVALID, "se_rank_rows: run layout mismatch");
+    const int vt = (int)(y.tile / MG_THREADS), sgm = y.sgm;
+    const int seg_n = (int)rank_runs_seg_n(n);
+    int seg_shift = 0;
+    while ((1 << seg_shift) < sgm) seg_shift++;
+    char *w = (char *)workspace + y.head;
+    int32_t *splits = (int32_t *)w;                         w += y.split_bytes;
+    uint16_t *planes = (uint16_t *)w;                       w += y.plane_bytes;
+    uint32_t *lvl[4] = {nullptr, nullptr, nullptr, nullptr};     // key / index arrays of the two intermediate level buffers
+    for (int i = 0; i < (sgm > 4 ? 4 : (sgm > 2 ? 2 : 0)); i++) { lvl[i] = (uint32_t *)w; w += y.level_bytes; }
+    const int64_t ld = (int64_t)n + 8;
     const size_t esz = idx64 ? 8 : 4;
     const int vec_ok = ((((uintptr_t)rank) & 15) == 0) && ((ldr * esz) % 16 == 0);
-    for (int64_t r0 = 0; r0 < q; r0 += chunk) {
-        const int64_t rows = q - r0 < chunk ? q - r0 : chunk, vrows = 2 * rows;
+    for (int64_t r0 = 0; r0 < q; r0 += y.chunk) {
+        const int64_t rows = q - r0 < y.chunk ? q - r0 : y.chunk, vrows = sgm * rows;
+        const int64_t plane_elems = sgm * rows * y.cap;
         const int64_t grid = res.grid < vrows ? res.grid : vrows;
         hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(RR_THREADS), lds, s, pdist + r0 * ldp, ldp, vrows, n, (void *)nullptr, (int64_t)0, 0, 0,
-                           (unsigned long long *)nullptr, (const uint32_t *)nullptr, RankSeg{1, seg_n, planes, plane_elems});
-        SE_LAUNCH_CHECK();
-        const int64_t nsplit = rows * (tiles + 1);
-        hipLaunchKernelGGL(rank_merge_partition_kernel, dim3((unsigned)((nsplit + 255) / 256)), dim3(256), 0, s, planes, plane_elems, (int)cap, seg_n, n,
-                           rows, (int)tiles, (int)tile, splits);
+                           (unsigned long long *)nullptr, (const uint32_t *)nullptr, RankSeg{seg_shift, seg_n, planes, plane_elems});
         SE_LAUNCH_CHECK();
         void *rout = (char *)rank + (size_t)r0 * (size_t)ldr * esz;
-        const dim3 mgrid((unsigned)tiles, (unsigned)rows);
-#define SE_MG_LAUNCH(I64, V) hipLaunchKernelGGL((rank_merge_kernel<I64, V>), mgrid, dim3(MG_THREADS), 0, s, planes, plane_elems, (int)cap, seg_n, n, (int)tiles, splits, rout, ldr, vec_ok)
-        if (kTuning && vt != MG_VT) {
-            if (vt == 8) { if (idx64) SE_MG_LAUNCH(true, 8); else SE_MG_LAUNCH(false, 8); }
-            else if (vt == 12) { if (idx64) SE_MG_LAUNCH(true, 12); else SE_MG_LAUNCH(false, 12); }
-            else { if (idx64) SE_MG_LAUNCH(true, 24); else SE_MG_LAUNCH(false, 24); }
-        } else if (idx64) SE_MG_LAUNCH(true, MG_VT);
-        else SE_MG_LAUNCH(false, MG_VT);
-#undef SE_MG_LAUNCH
-        SE_LAUNCH_CHECK();
+        int level = 0;
+        for (int pairs = sgm / 2, run = seg_n; pairs >= 1; pairs /= 2, run *= 2, level++) {
+            MergeLevel L;
+            L.run_n = run; L.N = n; L.pairs = pairs; L.tile = (int)y.tile; L.tiles = (int)((2 * (int64_t)run + y.tile - 1) / y.tile);
+            L.planes = planes; L.plane_elems = plane_elems; L.cap = (int)y.cap;
+            const int src = (level - 1) & 1, dst = level & 1;                     // level buffers alternate
+            L.in_key = level ? lvl[2 * src] : nullptr; L.in_idx = level ? lvl[2 * src + 1] : nullptr; L.ld = ld;
+            const bool last = pairs == 1;
+            int rc;
+            if (level == 0) rc = last ? launch_merge_level<true, true>(L, rows, splits, rout, idx64, ldr, vec_ok, nullptr, nullptr, vt, s)
+                                      : launch_merge_level<true, false>(L, rows, splits, nullptr, 0, 0, 0, lvl[2 * dst], lvl[2 * dst + 1], vt, s);
+            else rc = last ? launch_merge_level<false, true>(L, rows, splits, rout, idx64, ldr, vec_ok, nullptr, nullptr, vt, s)
+                           : launch_merge_level<false, false>(L, rows, splits, nullptr, 0, 0, 0, lvl[2 * dst], lvl[2 * dst + 1], vt, s);
+            if (rc != SE_OK) return rc;
+        }
     }
     return SE_OK;
 }

@@ -326,11 +326,11 @@ def long_rows(n, seed):
     return pd
 
 
-@pytest.mark.parametrize("n", [53249, 53256, 65536, 65537, 81920, 81921, 100352, 100353, 106496])
+@pytest.mark.parametrize("n", [53249, 53256, 65536, 65537, 81920, 81921, 100352, 100353, 106496, 106497, 131073, 212992, 212993, 425984])
 def test_rank_rows_long_rows_sorted_runs(sehip, n):
-    """53,248 < N <= 106,496: two segments sorted by the register-resident kernel (all four long-row instantiations: 64 / 80 / 98 /
-    104 keys per thread, first and last length of each) + merge-path partition + tile merge == the canonical ranking, int32 and
-    int64, ties across the segment boundary in index order."""
+    """53,248 < N <= 425,984: 2 / 4 / 8 segments sorted by the register-resident kernel (all four long-row instantiations: 64 / 80 /
+    98 / 104 keys per thread, first and last length of each) + merge tree (merge-path partition + tile merge per level; the levels
+    before the last write (key, index) runs) == the canonical ranking, int32 and int64, ties across segment boundaries in index order."""
     pd = long_rows(n, n)
     want = ro.canon_rank_rows(pd)
     assert np.array_equal(sehip.rank_rows(dev(pd)).cpu().numpy(), want)
@@ -354,9 +354,14 @@ def test_rank_rows_long_rows_chunks_strides_and_guard(sehip):
     assert bool((out64 == want[:300]).all())
 
 
-def test_rank_rows_above_two_segments_and_pinned_tiled_kernel():
-    """Rows above 106,496 columns keep the tiled kernel; SE_RANK_NORUNS=1 (tuning build) pins it for the shorter ones too -- the
-    fallback of the runs path stays covered."""
+def test_rank_rows_beyond_eight_segments_takes_the_tiled_kernel(sehip):
+    pd = long_rows(425985, 3)[:3]
+    assert np.array_equal(sehip.rank_rows(dev(pd)).cpu().numpy(), ro.canon_rank_rows(pd))
+
+
+def test_rank_rows_pinned_tiled_kernel_in_subprocess():
+    """SE_RANK_NORUNS=1 (tuning build) pins the tiled kernel for rows the merge tree would take: the fallback of the runs path (no
+    hardware-order guarantee, or a guard violation) stays covered."""
     import subprocess
     import sys
     code = (

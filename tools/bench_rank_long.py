@@ -15,7 +15,7 @@ def timeit(fn, reps=3):
 
 what = sys.argv[1:] or ["check", "time"]
 if "check" in what:
-    for n in (53249, 53256, 60000, 65536, 65537, 70001, 81920, 81921, 100352, 100353, 106496):
+    for n in (53249, 60000, 65537, 81921, 100353, 106496, 106497, 131072, 150000, 212992, 212993, 300000, 425984):
         rng = np.random.default_rng(n)
         pd = rng.standard_normal((5, n)).astype(np.float32)
         pd[1] = rng.integers(-2, 3, size=n).astype(np.float32)
@@ -37,7 +37,7 @@ if "check" in what:
     want = torch.argsort(x, dim=1, stable=True)
     print("1500 x 70001 vs torch stable argsort:", bool((got.long() == want).all()))
 if "time" in what:
-    for q, n in ((8192, 60000), (8192, 100000), (8192, 106496)):
+    for q, n in ((8192, 60000), (8192, 100000), (8192, 106496), (4096, 150000), (4096, 200000), (2048, 400000), (1024, 500000)):
         x = torch.randn(q, n, device="cuda")
         ms = timeit(lambda: sehip.rank_rows(x))
         print("rank_rows %d x %d: %.2f ms = %.2f ps/key  (50k x 50k rate: 3.76 ps/key)" % (q, n, ms, ms * 1e9 / (q * n)), flush=True)
