@@ -46,6 +46,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120.0)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--long", action="store_true", help="rows above 53,248 columns: sorted runs + merge tree (2 / 4 / 8 segments)")
     args = ap.parse_args()
     import torch
     import sehip
@@ -54,6 +55,9 @@ def main():
     t0, cases, rows = time.time(), 0, 0
     while time.time() - t0 < args.seconds:
         n = int(rng.choice([rng.integers(32768, 53249), 32768, 32769, 40960, 40961, 50000, 53248, rng.integers(700, 32768)]))
+        if args.long:   # every segment count, segment lengths around the instantiation boundaries of the segment kernel
+            n = int(rng.choice([rng.integers(53249, 106497), rng.integers(106497, 212993), rng.integers(212993, 425985), 53249, 65536, 65537,
+                                81920, 81921, 100352, 100353, 106496, 106497, 131072, 212992, 212993, 425984]))
         q = int(rng.integers(1, 9))
         pd = make_rows(rng, q, n)
         got = sehip.rank_rows(torch.from_numpy(pd).cuda()).cpu().numpy()
