@@ -495,7 +495,7 @@ def test_predict_keeps_features_on_the_device_for_the_metric_path(tmp_path):
     assert a == b
 
 
-def _sharded_topk_worker(rank, world, port, out):
+def _sharded_topk_worker(rank, world, port, out, d=200, kblocks=None):
     import torch.distributed as dist
     for p in (os.path.join(ROOT, "semantic-embeddings_amd"), ROOT):
         if p not in sys.path:
@@ -507,7 +507,7 @@ def _sharded_topk_worker(rank, world, port, out):
     import sehip
     import sharded_retrieval as sr
     rng = np.random.default_rng(0)
-    gallery = rng.standard_normal((3001, 200)).astype(np.float32)
+    gallery = rng.standard_normal((3001, d)).astype(np.float32)
     gallery[1500:1510] = gallery[0:10]                                # exact ties ACROSS the two shards
     queries = gallery[:300].copy()
     lo_, hi_ = sr.shard_bounds(len(gallery), world)[rank]
@@ -515,26 +515,28 @@ def _sharded_topk_worker(rank, world, port, out):
     q = torch.from_numpy(queries).cuda()
     sehip.normalize_rows_(g)
     sehip.normalize_rows_(q)
-    d, i = sr.sharded_topk(q, g, 251, lo_, metric=sehip.METRIC_COSINE)      # the real kernels: se_retrieve_topk + se_topk_merge
+    dd, i = sr.sharded_topk(q, g, 251, lo_, metric=sehip.METRIC_COSINE, kblocks=kblocks)      # the real kernels: se_retrieve_topk + se_topk_merge
     both = [None] * world
     dist.all_gather_object(both, i.cpu().numpy().tobytes())
     if rank == 0:
-        np.savez(out, d=d.cpu().numpy(), i=i.cpu().numpy(), gallery=gallery, queries=queries, same=both[0] == both[1])
+        np.savez(out, d=dd.cpu().numpy(), i=i.cpu().numpy(), gallery=gallery, queries=queries, same=both[0] == both[1])
     dist.destroy_process_group()
 
 
-def test_sharded_gallery_topk_two_processes_real_kernels(tmp_path):
+@pytest.mark.parametrize("d,kblocks,port", [(200, None, 29641), (555, [278, 277], 29643)])
+def test_sharded_gallery_topk_two_processes_real_kernels(tmp_path, d, kblocks, port):
     """The north_star retrieval split with the HIP kernels on both ranks (two processes on the one GPU, gloo transport):
     per-shard se_retrieve_topk -> all-gather -> se_topk_merge == canonical top-k over the whole gallery, identical on both
-    ranks, ties across shards broken by the GLOBAL index."""
+    ranks, ties across shards broken by the GLOBAL index; D = 555 with the BLAS K-block list on every shard (BASELINE configs[4]'s
+    arithmetic: the chain restarts per block)."""
     import torch.multiprocessing as mp
     out = str(tmp_path / "st.npz")
-    mp.spawn(_sharded_topk_worker, args=(2, 29641, out), nprocs=2, join=True)
+    mp.spawn(_sharded_topk_worker, args=(2, port, out, d, kblocks), nprocs=2, join=True)
     g = np.load(out)
     assert bool(g["same"])
     gal = ro.canon_normalize_rows(g["gallery"])
     qs = ro.canon_normalize_rows(g["queries"])
-    wd, wi = ro.canon_topk_rows(ro.canon_pdist(qs, gal, ro.METRIC_COSINE), 251)
+    wd, wi = ro.canon_topk_rows(ro.canon_pdist(qs, gal, ro.METRIC_COSINE, kblocks=kblocks), 251)
     assert np.array_equal(g["i"], wi) and np.array_equal(g["d"], wd)
 
 
