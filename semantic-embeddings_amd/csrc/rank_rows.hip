@@ -227,8 +227,8 @@ __global__ __launch_bounds__(RK_THREADS) void rank_rows_kernel(const float *__re
 // row in registers (ITEMS keys per thread), so a row costs ONE HBM read of the distances and ONE HBM
 // write of the ranks -- the algorithmic minimum -- and no global round trip sits between the passes.
 //   * position p of the current arrangement lives in wave p / (64 ITEMS), step (p / 64) % ITEMS,
-//     lane p % 64; positions >= N hold padding keys 0xFFFFFFFF whose initial position is behind
-//     every real key, so stability keeps them last and they are never written out;
+//     lane p % 64; positions >= N hold padding keys above every real key (rr_pad_key), so they end up
+//     last and are never written out;
 //   * per pass: (R) stable within-wave rank of every key on the wave's private LDS counters -- ONE returning add per key
 //     (hardware-ordered build: 3 passes of 11 + 11 + 10 or 10 + 10 + 12 bits) or an 8-ballot wave multisplit + one add per
 //     digit group (guaranteed-order build: 4 passes of 8 bits); (S) digit-major / wave-minor scan of the counters;
@@ -271,14 +271,23 @@ __device__ __forceinline__ void differ_mask(uint32_t d, uint32_t &lo, uint32_t &
 // Sort key of the register-resident kernel: the canonical order of canon_key() in 6 VALU instead of ~13 (the canonicalisation
 // of a 50k row is 98 keys x 2 waves per SIMD: 6k of a row's 115k cycles with canon_key).  Negative values map to ~u + 1, so
 // that -0.0 lands ON +0.0's key 0x80000000 without a compare (the keys never leave the kernel; order and ties are those of
-// canon_key: ascending value, -0.0 == +0.0, every NaN and every padding slot 0xFFFFFFFF).
-__device__ __forceinline__ uint32_t rr_key(uint32_t u, bool pad)
+// canon_key: ascending value, -0.0 == +0.0, every NaN on ONE key above +inf's 0xFF800000).
+// Padding slots (positions >= the row's length) sort behind every real key, NaN included, but NOT on one key: with 0xFFFFFFFF for
+// all of them every wave step of padding put its 64 returning adds on ONE counter in every pass -- 113 instead of 6.4 cycles per
+// step (a 26,624-column row in the 32,768-slot instantiation took LONGER than a 32,768-column one; NABirds' 24,633 and CUB's 5,794
+// test items sit deep inside their instantiations).  A lane's padding key carries the lane number in both lower digits (10 / 11-bit
+// splits alike: bits 0-5 and 11-16) and one of the six most significant 12-bit values above NaN's: distinct counters in the lower
+// passes, ~11 lanes per counter in the last one.  Their order among themselves does not matter: the output ends at the row's length.
+constexpr uint32_t RR_KEY_NAN = 0xFF900000u;
+__device__ __forceinline__ uint32_t rr_pad_key(uint32_t lane) { return 0xFFA00000u + ((lane % 6u) << 20) + (lane << 11) + lane; }
+__device__ __forceinline__ uint32_t rr_key(uint32_t u, bool pad, uint32_t pad_key)
 {
     const uint32_t sx = (uint32_t)((int32_t)u >> 31);                                   // 0 or ~0
     uint32_t k = __builtin_amdgcn_bitop3_b32(u, sx, 0x80000000u, 0x1E);                 // u ^ (sx | 0x80000000): ~u or u | 0x80000000
     k -= sx;                                                                            // negative: + 1
     const float f = __uint_as_float(u);
-    return (f != f || pad) ? 0xFFFFFFFFu : k;
+    k = (f != f) ? RR_KEY_NAN : k;
+    return pad ? pad_key : k;
 }
 
 template <typename T>
@@ -559,9 +568,10 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
     {                                                                                                                 \
         int wpos_ = wpos0;                                                                                            \
         opaque(wpos_);                                                                                                \
+        const uint32_t pk_ = rr_pad_key((uint32_t)wpos_ & 63u);                                                       \
         _Pragma("unroll") for (int s = 0; s < ITEMS; s++) {                                                           \
             const int pos = wpos_ + s * WAVE;                                                                         \
-            key[s] = rr_key(key[s], pos >= (NN)); /* pos >= N: all ones */                                            \
+            key[s] = rr_key(key[s], pos >= (NN), pk_); /* pos >= N: padding */                                        \
         }                                                                                                             \
     }
 #define RR_PREFETCH_NEXT_ROW() \
@@ -601,9 +611,13 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
             uint32_t *stat = wave_tot;                                  // [0, 8): per-wave maxima, [8, 16): per-wave counts below the window
             uint2 *outl = reinterpret_cast<uint2 *>(wcnt);              // (key, position) of the keys below the window (the dedicated counters are idle on this path)
             // (every step below is written for its instruction count: two waves per SIMD execute each of them over 98 keys)
-            uint32_t mx = 0;                                             // max of key + 1: NaN / padding (all ones) wrap to 0 and drop out
+            // max over the real, non-NaN keys: adding 2^32 - RR_KEY_NAN wraps NaN and padding (RR_KEY_NAN and above) below every real
+            // key's sum (real keys end at +inf's 0xFF800000: no wrap, and their sums are >= the constant itself), so they drop out
+            constexpr uint32_t WRAP = 0u - RR_KEY_NAN;
+            uint32_t mx = 0;
 #pragma unroll
-            for (int s = 0; s < ITEMS; s++) mx = max(mx, key[s] + 1u);
+            for (int s = 0; s < ITEMS; s++) mx = max(mx, key[s] + WRAP);
+            mx = mx >= WRAP ? mx - WRAP + 1u : 0u;                       // key + 1 of the largest real key, 0 when the row has none
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, off, 64));
             if (lane == 0) stat[wave] = mx;
@@ -1565,7 +1579,7 @@ extern "C" int se_rank_rows(const float *pdist, int64_t ldp, int64_t q, int64_t 
         int rc = SE_ERR_INVALID;
 #define SE_RR_CASE(I) if (rc == SE_ERR_INVALID && items <= I) rc = launch_rank_reg<I>(pdist, ldp, q, (int)n, rank, idx64, ldr, hw, scratch, s);
 #if SE_RR_THREADS == 512
-        SE_RR_CASE(2) SE_RR_CASE(8) SE_RR_CASE(20) SE_RR_CASE(40) SE_RR_CASE(64) SE_RR_CASE(80) SE_RR_CASE(98) SE_RR_CASE(104)
+        SE_RR_CASE(2) SE_RR_CASE(8) SE_RR_CASE(12) SE_RR_CASE(20) SE_RR_CASE(30) SE_RR_CASE(40) SE_RR_CASE(52) SE_RR_CASE(64) SE_RR_CASE(80) SE_RR_CASE(98) SE_RR_CASE(104)
 #else
         SE_RR_CASE(2) SE_RR_CASE(6) SE_RR_CASE(14) SE_RR_CASE(28) SE_RR_CASE(44) SE_RR_CASE(56) SE_RR_CASE(66) SE_RR_CASE(70)
 #endif
@@ -1591,7 +1605,7 @@ extern "C" int se_rank_rows(const float *pdist, int64_t ldp, int64_t q, int64_t 
         if (nbad > (uint32_t)RC_CAP || row_stride > 1) {   // more than the list holds, or only a sample was looked at: redo the whole call
 #define SE_RR_CASE(I) if (items <= I) return launch_rank_reg<I>(pdist, ldp, q, (int)n, rank, idx64, ldr, false, scratch, s);
 #if SE_RR_THREADS == 512
-            SE_RR_CASE(2) SE_RR_CASE(8) SE_RR_CASE(20) SE_RR_CASE(40) SE_RR_CASE(64) SE_RR_CASE(80) SE_RR_CASE(98) SE_RR_CASE(104)
+            SE_RR_CASE(2) SE_RR_CASE(8) SE_RR_CASE(12) SE_RR_CASE(20) SE_RR_CASE(30) SE_RR_CASE(40) SE_RR_CASE(52) SE_RR_CASE(64) SE_RR_CASE(80) SE_RR_CASE(98) SE_RR_CASE(104)
 #else
             SE_RR_CASE(2) SE_RR_CASE(6) SE_RR_CASE(14) SE_RR_CASE(28) SE_RR_CASE(44) SE_RR_CASE(56) SE_RR_CASE(66) SE_RR_CASE(70)
 #endif
@@ -1605,7 +1619,7 @@ extern "C" int se_rank_rows(const float *pdist, int64_t ldp, int64_t q, int64_t 
             int rc3 = SE_ERR_INVALID;
 #define SE_RR_CASE(I) if (rc3 == SE_ERR_INVALID && items <= I) rc3 = launch_rank_reg<I>(pdist + row * ldp, ldp, 1, (int)n, rrow, idx64, ldr, false, nullptr, s);
 #if SE_RR_THREADS == 512
-            SE_RR_CASE(2) SE_RR_CASE(8) SE_RR_CASE(20) SE_RR_CASE(40) SE_RR_CASE(64) SE_RR_CASE(80) SE_RR_CASE(98) SE_RR_CASE(104)
+            SE_RR_CASE(2) SE_RR_CASE(8) SE_RR_CASE(12) SE_RR_CASE(20) SE_RR_CASE(30) SE_RR_CASE(40) SE_RR_CASE(52) SE_RR_CASE(64) SE_RR_CASE(80) SE_RR_CASE(98) SE_RR_CASE(104)
 #else
             SE_RR_CASE(2) SE_RR_CASE(6) SE_RR_CASE(14) SE_RR_CASE(28) SE_RR_CASE(44) SE_RR_CASE(56) SE_RR_CASE(66) SE_RR_CASE(70)
 #endif
