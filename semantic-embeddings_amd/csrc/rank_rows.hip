@@ -604,6 +604,11 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
     for (int64_t row = blockIdx.x; row < Q; row += gridDim.x) {
         const bool more = row + gridDim.x < Q;
         [[maybe_unused]] const int n_next = row_len(more ? row + gridDim.x : row);
+        // a wave whose slots are ALL padding (rows well below the instantiation's capacity) sits the passes out: its counters stay zero,
+        // its slots of the exchange buffer are never read by anyone, and it only joins the barriers and the counter scan.  (The big
+        // instantiations keep the unconditional code: a branch around their unrolled phases makes hipcc copy the key registers.)
+        constexpr bool SKIP_WAVES = HWORD && ITEMS <= 80;
+        const bool wave_live = !SKIP_WAVES || wave * (ITEMS * WAVE) < row_len(row);
         // ---- does the row qualify for the two-pass path?  (uniform per row; before the index registers exist: only the keys are live) ----
         bool two = false;
         [[maybe_unused]] int n_out = 0;
@@ -688,8 +693,10 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
             // HWORD digit split: low wlo bits = counter word, the rest (0 or 1 bit) = half
             [[maybe_unused]] const uint32_t wlo = wide ? 11u : 10u, whi = (uint32_t)(end - shift) - wlo, hshift = (uint32_t)(shift + (int)wlo) & 31u;
             if constexpr (HWORD) {
-                uint32_t hr[RR_GH], hs[RR_GH], hg[RR_GH];
-                RRRankHW<ITEMS, PEEL>::run(ir, key, hr, hs, hg, (uint32_t)shift, hshift, wlo, whi, cb, lane, end >= 32 && !two);
+                if (wave_live) {
+                    uint32_t hr[RR_GH], hs[RR_GH], hg[RR_GH];
+                    RRRankHW<ITEMS, PEEL>::run(ir, key, hr, hs, hg, (uint32_t)shift, hshift, wlo, whi, cb, lane, end >= 32 && !two);
+                }
             }
             else RRRank<ITEMS>::run(ir, key, shift, lane, cb);
             lds_wait();
@@ -784,6 +791,7 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
             // SE_RR_PF (build-time tuning aid): 0 = no prefetch, 1 = before the destination phase of the last pass (default), 2 = after it, 3 = before its scan
             if (SE_RR_PF == 1) { RR_PREFETCH_NEXT_ROW() }
             // ---- X: destinations, then the 2-byte exchanges ----
+            if (wave_live) {
 #pragma unroll
             for (int s0 = 0; s0 < ITEMS; s0 += 8) {
                 uint32_t first[8];
@@ -801,11 +809,14 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
                     }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            }
             if (SE_RR_PF == 2) { RR_PREFETCH_NEXT_ROW() }
             if (wide) __syncthreads();   // the scatter below overwrites the (aliased) counters other waves may still be looking up
             RR_T(3)
+            if (wave_live) {
 #pragma unroll
-            for (int s = 0; s < ITEMS; s++) { opaque(ir[s]); lds_st16_hi(RR_DST(ir[s]), ir[s]); }           // index
+                for (int s = 0; s < ITEMS; s++) { opaque(ir[s]); lds_st16_hi(RR_DST(ir[s]), ir[s]); }       // index
+            }
             lds_wait();
             __syncthreads();
             RR_T(4)
@@ -817,29 +828,33 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
                     __syncthreads();
                 }
             } else {
-                RRRead<ITEMS, true>::run(ir, ring, rb);
+                if (wave_live) RRRead<ITEMS, true>::run(ir, ring, rb);
                 lds_wait();
                 __syncthreads();
             }
             RR_T(5)
+            if (wave_live) {
 #pragma unroll
-            for (int s = 0; s < ITEMS; s++) { opaque(ir[s]); lds_st16_hi(RR_DST(ir[s]), key[s]); }          // key bits 16-31  (opaque: no cached addresses)
+                for (int s = 0; s < ITEMS; s++) { opaque(ir[s]); lds_st16_hi(RR_DST(ir[s]), key[s]); }      // key bits 16-31  (opaque: no cached addresses)
+            }
             lds_wait();
             __syncthreads();
             if (SEG && last) {
                 RR_STREAM_PLANE(1, row)
             } else {
-                RRRead<ITEMS, true>::run(key, ring, rb);
+                if (wave_live) RRRead<ITEMS, true>::run(key, ring, rb);
                 lds_wait();
             }
             if (end < 16 || SEG) {                                                       // key bits 0-15: still needed by a later pass (SEG: by the run, so they travel through every pass)
                 __syncthreads();
+                if (wave_live) {
 #pragma unroll
-                for (int s = 0; s < ITEMS; s++) { opaque(ir[s]); lds_st16_lo(RR_DST(ir[s]), key[s]); }      // (low half is still the old key's)
+                    for (int s = 0; s < ITEMS; s++) { opaque(ir[s]); lds_st16_lo(RR_DST(ir[s]), key[s]); }  // (low half is still the old key's)
+                }
                 lds_wait();
                 __syncthreads();
                 if (SEG && last) break;      // the key registers are free: the next row is loaded before the last plane is streamed out
-                RRRead<ITEMS, false>::run(key, ring, rb);
+                if (wave_live) RRRead<ITEMS, false>::run(key, ring, rb);
                 lds_wait();
             }
             RR_T(6)
