@@ -201,7 +201,7 @@ int se_pairwise_dist(const float *a, int64_t lda, const float *b, int64_t ldb, c
  *   rank: int32 [q, n] when idx64 == 0, int64 [q, n] (NumPy's dtype) otherwise.
  *   workspace: se_rank_rows_workspace_bytes(q, n) bytes of device memory, 16-byte aligned.  n <= 53,248: one workgroup sorts a row in registers
  *   (4.4 KB of workspace: probe / guard words); 53,248 < n <= 425,984: 2, 4 or 8 segments of a row are sorted the same way into
- *   runs and merged pairwise (merge tree; up to 1.5 GB of run planes / level buffers for a chunk of rows at a time); longer rows:
+ *   runs and merged pairwise (merge tree; up to 3 GB of run planes / level buffers for a chunk of rows at a time); longer rows:
  *   LDS-tiled radix sort through 16 bytes per key of scratch per resident workgroup.
  */
 int64_t se_rank_rows_workspace_bytes(int64_t q, int64_t n);

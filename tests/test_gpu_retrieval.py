@@ -339,9 +339,9 @@ def test_rank_rows_long_rows_sorted_runs(sehip, n):
 
 
 def test_rank_rows_long_rows_chunks_strides_and_guard(sehip):
-    """More rows than one chunk of the runs path (2,048), a strided unaligned input and output (scalar write-out of the merge),
+    """More rows than one chunk of the runs path (4,096), a strided unaligned input and output (scalar write-out of the merge),
     and the order guard's verdict on the result."""
-    q, n = 2100, 53301
+    q, n = 4200, 53301
     x = torch.randn(q, n + 3, device="cuda")
     x[::2, ::5] = 0.25
     pd = x[:, 1:n + 1]
