@@ -126,7 +126,7 @@ def ranking_tiles(features, normalize=False, tile_rows=None, idx64=False, querie
         tile_rows = max(128, min(n, (DEFAULT_TILE_BYTES // (8 * max(n, 1))) // 128 * 128))
         if whole_if_fits and features.is_cuda and 8 * n * (q1 - q0) <= torch.cuda.mem_get_info(features.device)[0] // 3:
             tile_rows = max(tile_rows, q1 - q0)
-    pd = torch.empty((min(tile_rows, max(q1 - q0, 1)), n), dtype=torch.float32, device=features.device)
+    pd = sehip.empty_rows(min(tile_rows, max(q1 - q0, 1)), n, torch.float32, features.device)   # row pitch: a multiple of 16 bytes
     for r0 in range(q0, q1, tile_rows):
         rows = min(tile_rows, q1 - r0)
         sehip.pairwise_dist(features[r0:r0 + rows], features, metric=metric,

@@ -2,5 +2,5 @@
 training + retrieval hot path.  See include/sehip.h for the C ABI and DESIGN.md for the design."""
 from ._lib import (DTYPE_BF16, DTYPE_F32, EXPORTS, LIB_PATH, METRIC_COSINE, METRIC_DOT, METRIC_EUCLID, TOPK_MAX,
                    SehipError, build, lib)
-from .ops import (hierarchical_precision, hprec_reciprocal_curves, cosine_embedding_loss, devise_ranking_loss, cosine_loss_backward, cosine_loss_forward, l2norm, labelembed_loss, nn_accuracy, normalize_rows_,
+from .ops import (empty_rows, hierarchical_precision, hprec_reciprocal_curves, cosine_embedding_loss, devise_ranking_loss, cosine_loss_backward, cosine_loss_forward, l2norm, labelembed_loss, nn_accuracy, normalize_rows_,
                   pairwise_dist, rank_rows, rank_rows_check, retrieve_topk, row_sqnorm, topk_merge, topk_rows)
