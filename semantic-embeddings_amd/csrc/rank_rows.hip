@@ -607,7 +607,7 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
         // a wave whose slots are ALL padding (rows well below the instantiation's capacity) sits the passes out: its counters stay zero,
         // its slots of the exchange buffer are never read by anyone, and it only joins the barriers and the counter scan.  (The big
         // instantiations keep the unconditional code: a branch around their unrolled phases makes hipcc copy the key registers.)
-        constexpr bool SKIP_WAVES = HWORD && ITEMS <= 80;
+        constexpr bool SKIP_WAVES = HWORD && ITEMS <= 88;
         const bool wave_live = !SKIP_WAVES || wave * (ITEMS * WAVE) < row_len(row);
         // ---- does the row qualify for the two-pass path?  (uniform per row; before the index registers exist: only the keys are live) ----
         bool two = false;
@@ -1281,7 +1281,7 @@ static int64_t rank_runs_seg_n(int64_t n) { const int sgm = rank_runs_segments(n
 static int rank_runs_items(int64_t n)
 {
     const int items = (int)((rank_runs_seg_n(n) + RR_THREADS - 1) / RR_THREADS);
-    return items <= 64 ? 64 : items <= 80 ? 80 : items <= 98 ? 98 : 104;
+    return items <= 64 ? 64 : items <= 72 ? 72 : items <= 80 ? 80 : items <= 88 ? 88 : items <= 98 ? 98 : 104;
 }
 constexpr int64_t RUNS_HEAD = 256 + 4 * (RC_CAP + 2);
 struct RunsLayout { int64_t chunk, cap, tile, split_words, head, split_bytes, plane_bytes, level_bytes, total; int sgm; };
@@ -1595,7 +1595,7 @@ extern "C" int se_rank_rows(const float *pdist, int64_t ldp, int64_t q, int64_t 
         int rc = SE_ERR_INVALID;
 #define SE_RR_CASE(I) if (rc == SE_ERR_INVALID && items <= I) rc = launch_rank_reg<I>(pdist, ldp, q, (int)n, rank, idx64, ldr, hw, scratch, s);
 #if SE_RR_THREADS == 512
-        SE_RR_CASE(2) SE_RR_CASE(8) SE_RR_CASE(12) SE_RR_CASE(20) SE_RR_CASE(30) SE_RR_CASE(40) SE_RR_CASE(52) SE_RR_CASE(64) SE_RR_CASE(80) SE_RR_CASE(98) SE_RR_CASE(104)
+        SE_RR_CASE(2) SE_RR_CASE(8) SE_RR_CASE(12) SE_RR_CASE(20) SE_RR_CASE(30) SE_RR_CASE(40) SE_RR_CASE(46) SE_RR_CASE(52) SE_RR_CASE(58) SE_RR_CASE(64) SE_RR_CASE(72) SE_RR_CASE(80) SE_RR_CASE(88) SE_RR_CASE(98) SE_RR_CASE(104)
 #else
         SE_RR_CASE(2) SE_RR_CASE(6) SE_RR_CASE(14) SE_RR_CASE(28) SE_RR_CASE(44) SE_RR_CASE(56) SE_RR_CASE(66) SE_RR_CASE(70)
 #endif
@@ -1621,7 +1621,7 @@ extern "C" int se_rank_rows(const float *pdist, int64_t ldp, int64_t q, int64_t 
         if (nbad > (uint32_t)RC_CAP || row_stride > 1) {   // more than the list holds, or only a sample was looked at: redo the whole call
 #define SE_RR_CASE(I) if (items <= I) return launch_rank_reg<I>(pdist, ldp, q, (int)n, rank, idx64, ldr, false, scratch, s);
 #if SE_RR_THREADS == 512
-            SE_RR_CASE(2) SE_RR_CASE(8) SE_RR_CASE(12) SE_RR_CASE(20) SE_RR_CASE(30) SE_RR_CASE(40) SE_RR_CASE(52) SE_RR_CASE(64) SE_RR_CASE(80) SE_RR_CASE(98) SE_RR_CASE(104)
+            SE_RR_CASE(2) SE_RR_CASE(8) SE_RR_CASE(12) SE_RR_CASE(20) SE_RR_CASE(30) SE_RR_CASE(40) SE_RR_CASE(46) SE_RR_CASE(52) SE_RR_CASE(58) SE_RR_CASE(64) SE_RR_CASE(72) SE_RR_CASE(80) SE_RR_CASE(88) SE_RR_CASE(98) SE_RR_CASE(104)
 #else
             SE_RR_CASE(2) SE_RR_CASE(6) SE_RR_CASE(14) SE_RR_CASE(28) SE_RR_CASE(44) SE_RR_CASE(56) SE_RR_CASE(66) SE_RR_CASE(70)
 #endif
@@ -1635,7 +1635,7 @@ extern "C" int se_rank_rows(const float *pdist, int64_t ldp, int64_t q, int64_t 
             int rc3 = SE_ERR_INVALID;
 #define SE_RR_CASE(I) if (rc3 == SE_ERR_INVALID && items <= I) rc3 = launch_rank_reg<I>(pdist + row * ldp, ldp, 1, (int)n, rrow, idx64, ldr, false, nullptr, s);
 #if SE_RR_THREADS == 512
-            SE_RR_CASE(2) SE_RR_CASE(8) SE_RR_CASE(12) SE_RR_CASE(20) SE_RR_CASE(30) SE_RR_CASE(40) SE_RR_CASE(52) SE_RR_CASE(64) SE_RR_CASE(80) SE_RR_CASE(98) SE_RR_CASE(104)
+            SE_RR_CASE(2) SE_RR_CASE(8) SE_RR_CASE(12) SE_RR_CASE(20) SE_RR_CASE(30) SE_RR_CASE(40) SE_RR_CASE(46) SE_RR_CASE(52) SE_RR_CASE(58) SE_RR_CASE(64) SE_RR_CASE(72) SE_RR_CASE(80) SE_RR_CASE(88) SE_RR_CASE(98) SE_RR_CASE(104)
 #else
             SE_RR_CASE(2) SE_RR_CASE(6) SE_RR_CASE(14) SE_RR_CASE(28) SE_RR_CASE(44) SE_RR_CASE(56) SE_RR_CASE(66) SE_RR_CASE(70)
 #endif
@@ -1652,7 +1652,9 @@ extern "C" int se_rank_rows(const float *pdist, int64_t ldp, int64_t q, int64_t 
         const int items = rank_runs_items(n);
         int rc = SE_ERR_INVALID;
         if (items == 64) rc = launch_rank_runs<64>(pdist, ldp, q, (int)n, rank, idx64, ldr, workspace, s);
+        else if (items == 72) rc = launch_rank_runs<72>(pdist, ldp, q, (int)n, rank, idx64, ldr, workspace, s);
         else if (items == 80) rc = launch_rank_runs<80>(pdist, ldp, q, (int)n, rank, idx64, ldr, workspace, s);
+        else if (items == 88) rc = launch_rank_runs<88>(pdist, ldp, q, (int)n, rank, idx64, ldr, workspace, s);
         else if (items == 98) rc = launch_rank_runs<98>(pdist, ldp, q, (int)n, rank, idx64, ldr, workspace, s);
         else rc = launch_rank_runs<104>(pdist, ldp, q, (int)n, rank, idx64, ldr, workspace, s);
         if (rc != SE_OK) return rc;

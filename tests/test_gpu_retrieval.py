@@ -128,9 +128,10 @@ def test_rank_rows_ties_nan_negzero_int64(sehip):
     assert np.array_equal(got64, want)
 
 
-@pytest.mark.parametrize("n", [1023, 1025, 4096, 10000, 10241, 20481, 32768, 32769, 40961, 50000, 50177, 53248, 53249, 65536, 70001, 100000])
+@pytest.mark.parametrize("n", [1023, 1025, 4096, 4097, 6144, 6145, 10000, 10241, 15360, 15361, 20481, 23552, 23553, 26624, 26625, 29696, 29697, 32768, 32769,
+                               36864, 36865, 40961, 45056, 45057, 50000, 50177, 53248, 53249, 65536, 70001, 100000])
 def test_rank_rows_register_kernel_boundaries(sehip, n):
-    """Every instantiation of the register-resident kernel (keys per thread 2...104), its last
+    """Every instantiation of the register-resident kernel (2 / 8 / 12 / 20 / 30 / 40 / 46 / 52 / 58 / 64 / 72 / 80 / 88 / 98 / 104 keys per thread), its last
     full / first ragged step, and the hand-over to the sorted-runs path above 53248 columns; rows mix
     gaussian keys with exact-tie runs, NaN, infinities and signed zeros."""
     rng = np.random.default_rng(n)
@@ -326,10 +327,10 @@ def long_rows(n, seed):
     return pd
 
 
-@pytest.mark.parametrize("n", [53249, 53256, 65536, 65537, 81920, 81921, 100352, 100353, 106496, 106497, 131073, 212992, 212993, 425984])
+@pytest.mark.parametrize("n", [53249, 53256, 65536, 65537, 73728, 73729, 81920, 81921, 90112, 90113, 100352, 100353, 106496, 106497, 131073, 212992, 212993, 425984])
 def test_rank_rows_long_rows_sorted_runs(sehip, n):
-    """53,248 < N <= 425,984: 2 / 4 / 8 segments sorted by the register-resident kernel (all four long-row instantiations: 64 / 80 /
-    98 / 104 keys per thread, first and last length of each) + merge tree (merge-path partition + tile merge per level; the levels
+    """53,248 < N <= 425,984: 2 / 4 / 8 segments sorted by the register-resident kernel (all six long-row instantiations: 64 / 72 / 80 /
+    88 / 98 / 104 keys per thread, first and last length of each) + merge tree (merge-path partition + tile merge per level; the levels
     before the last write (key, index) runs) == the canonical ranking, int32 and int64, ties across segment boundaries in index order."""
     pd = long_rows(n, n)
     want = ro.canon_rank_rows(pd)
