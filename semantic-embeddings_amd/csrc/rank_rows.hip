@@ -277,7 +277,10 @@ __device__ __forceinline__ void differ_mask(uint32_t d, uint32_t &lo, uint32_t &
 // step (a 26,624-column row in the 32,768-slot instantiation took LONGER than a 32,768-column one; NABirds' 24,633 and CUB's 5,794
 // test items sit deep inside their instantiations).  A lane's padding key carries the lane number in both lower digits (10 / 11-bit
 // splits alike: bits 0-5 and 11-16) and one of the six most significant 12-bit values above NaN's: distinct counters in the lower
-// passes, ~11 lanes per counter in the last one.  Their order among themselves does not matter: the output ends at the row's length.
+// passes, ~11 lanes per counter in the last one.  Their order among themselves does not matter: the output ends at the row's length
+// -- but it decides which LDS banks their scatters hit: RR_CANON adds the step number (3 + 3 bits above the two lane fields), so that
+// the padding keys of one wave step end up 8 slots apart instead of (padding steps) slots apart (a multiple of 16: 4 banks); the 98-
+// and 104-key instantiations leave it out (one more instruction per key: +1 % at 50,000 columns, where there is next to no padding).
 constexpr uint32_t RR_KEY_NAN = 0xFF900000u;
 __device__ __forceinline__ uint32_t rr_pad_key(uint32_t lane) { return 0xFFA00000u + ((lane % 6u) << 20) + (lane << 11) + lane; }
 __device__ __forceinline__ uint32_t rr_key(uint32_t u, bool pad, uint32_t pad_key)
@@ -571,7 +574,7 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
         const uint32_t pk_ = rr_pad_key((uint32_t)wpos_ & 63u);                                                       \
         _Pragma("unroll") for (int s = 0; s < ITEMS; s++) {                                                           \
             const int pos = wpos_ + s * WAVE;                                                                         \
-            key[s] = rr_key(key[s], pos >= (NN), pk_); /* pos >= N: padding */                                        \
+            key[s] = rr_key(key[s], pos >= (NN), pk_ + (ITEMS <= 88 ? (uint32_t)((((s >> 3) & 7) << 17) | ((s & 7) << 6)) : 0u)); /* pos >= N: padding */ \
         }                                                                                                             \
     }
 #define RR_PREFETCH_NEXT_ROW() \
