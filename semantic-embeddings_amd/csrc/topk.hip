@@ -824,7 +824,7 @@ extern "C" int64_t se_retrieve_topk_workspace_bytes(int64_t q, int64_t n, int64_
     if (q <= 0 || n <= 0) return 0;
     const FusedPlan p = fused_plan(n, ldg, k);
     if (p.ok) return fused_layout(q, n, p).total;
-    return topk_qtile(q, n) * n * 4;
+    return topk_qtile(q, n) * ((n + 3) / 4 * 4) * 4;          // slab rows on a 16-byte pitch (16-byte row stores of the distance kernel)
 }
 
 extern "C" int se_retrieve_topk(const float *queries, int64_t ldq, const float *gallery, int64_t ldg,
@@ -851,10 +851,11 @@ extern "C" int se_retrieve_topk(const float *queries, int64_t ldq, const float *
         float *slab = (float *)workspace;
         for (int64_t q0 = 0; q0 < q; q0 += qt) {
             const int64_t rows = (q - q0 < qt) ? (q - q0) : qt;
+            const int64_t lds_ = (n + 3) / 4 * 4;
             int rc = se_pairwise_dist(queries + q0 * ldq, ldq, gallery, ldg, sqq ? sqq + q0 : nullptr, sqg, rows, n, d,
-                                      metric, multi ? kblocks : nullptr, multi ? nkb : 0, slab, n, stream);
+                                      metric, multi ? kblocks : nullptr, multi ? nkb : 0, slab, lds_, stream);
             if (rc != SE_OK) return rc;
-            rc = se_topk_rows(slab, n, rows, n, col_offset, k, out_d + q0 * k, out_i + q0 * k, stream);
+            rc = se_topk_rows(slab, lds_, rows, n, col_offset, k, out_d + q0 * k, out_i + q0 * k, stream);
             if (rc != SE_OK) return rc;
         }
         return SE_OK;
