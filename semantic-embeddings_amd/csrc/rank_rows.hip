@@ -1651,7 +1651,7 @@ extern "C" int se_rank_rows(const float *pdist, int64_t ldp, int64_t q, int64_t 
     if (!workspace || workspace_bytes < need) return fail(SE_ERR_WORKSPACE, "se_rank_rows: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)need);
     if ((((uintptr_t)workspace) & 15) != 0) return fail(SE_ERR_INVALID, "se_rank_rows: workspace must be 16-byte aligned");
     if (rank_runs_ok(n) && rank_hw_order_ok(workspace, workspace_bytes, s)) {
-        // RR_MAX_N < n <= 2 RR_MAX_N: two sorted runs per row (hardware-ordered register-resident kernel on the halves) + merge
+        // RR_MAX_N < n <= 8 RR_MAX_N: 2 / 4 / 8 sorted runs per row (hardware-ordered register-resident kernel on the segments) + merge tree
         const int items = rank_runs_items(n);
         int rc = SE_ERR_INVALID;
         if (items == 64) rc = launch_rank_runs<64>(pdist, ldp, q, (int)n, rank, idx64, ldr, workspace, s);
@@ -1665,11 +1665,11 @@ extern "C" int se_rank_rows(const float *pdist, int64_t ldp, int64_t q, int64_t 
         const bool have_dev = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64;
         static const bool check_always = getenv("SE_RANK_CHECK") != nullptr && getenv("SE_RANK_CHECK")[0] != '0';
         if (!have_dev || !(check_always || rr_checked[dev].load(std::memory_order_acquire) == 0)) return SE_OK;
-        if (kTuning && tuning_env("SE_RANK_NOGUARD")) return SE_OK;
+        if (kTuning && tuning_env("SE_RANK_NOGUARD")) return SE_OK;   // -DSE_TUNING build only: look at the raw output of the run kernels
         if (kTuning && tuning_env("SE_RANK_INJECT")) {
             hipLaunchKernelGGL(rank_inject_kernel, dim3((unsigned)((q / 7 + 256) / 256)), dim3(256), 0, s, rank, idx64, ldr, q, (int)n);
             SE_LAUNCH_CHECK();
-        }   // -DSE_TUNING build only: look at the raw output of the run kernels
+        }
         // order guard, as for the short rows: a sample of the rows behind the first hardware-ordered call of the process (every row
         // under SE_RANK_CHECK=1); on a violation the whole call is redone by the tiled kernel below and the device leaves the fast paths
         uint32_t *bad = (uint32_t *)((char *)workspace + 256);
