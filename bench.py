@@ -144,6 +144,58 @@ def max_over_ranks(value, world, device):
     return float(t.item())
 
 
+def comm_identity(world, dry=False):
+    """What the live communicator is, for the driver to confirm that N ranks really met over RCCL: backend name, library version as
+    torch reports it (torch.cuda.nccl.version() is RCCL's on ROCm), world size of the process group, and the (rank, device, PCI bus id)
+    triples collected THROUGH the communicator (an all-gather on the device for "nccl")."""
+    info = {"backend": None, "version": None, "world": world, "ranks_seen": []}
+    if world == 1:
+        info["backend"] = "none (single process)"
+        if not dry:
+            p = torch.cuda.get_device_properties(torch.cuda.current_device())
+            info["ranks_seen"] = [{"rank": 0, "device": torch.cuda.current_device(), "name": p.name}]
+        return info
+    info["backend"] = dist.get_backend()
+    if info["backend"] == "nccl":
+        try:
+            info["version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception as e:      # noqa: BLE001
+            info["version"] = "unknown (%s)" % type(e).__name__
+        info["library"] = "RCCL (torch's 'nccl' backend on ROCm)"
+        info["hip"] = torch.version.hip
+    dev = "cpu" if dry else "cuda"
+    me = torch.tensor([dist.get_rank(), -1 if dry else torch.cuda.current_device(), os.getpid()], dtype=torch.int64, device=dev)
+    seen = torch.empty((world, 3), dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(seen.view(-1), me)
+    info["ranks_seen"] = [{"rank": int(r), "device": int(d), "pid": int(p)} for r, d, p in seen.cpu().tolist()]
+    info["distinct_devices"] = len({(int(d)) for _, d, _ in seen.cpu().tolist()})
+    return info
+
+
+def multi_gpu_summary(out, world):
+    """At N > 1: the phases that actually cross xGMI, promoted next to the headline so that a SCALE run explains itself (the weak
+    headline is N independent retrieval jobs with no collective and says nothing about the fabric)."""
+    if world <= 1:
+        return None
+    summ = {"n_gpus": world, "headline_has_collective": False}
+    sg = out.get("sharded_gallery")
+    if isinstance(sg, dict) and "ms" in sg:
+        summ["sharded_gallery"] = {"all_gather_ms": sg["ms"]["all_gather"], "local_topk_ms": sg["ms"]["local_topk"], "merge_ms": sg["ms"]["merge"],
+                                   "all_gather_bytes_per_rank": sg.get("all_gather_bytes_per_rank"),
+                                   "all_gather_GBps_per_rank": sg.get("all_gather_GBps_per_rank"),
+                                   "exchange_frac_of_step": sg["ms"]["all_gather"] / sg["ms"]["total"], "collectives_per_step": 1}
+    for leg in ("train", "train_bf16", "train_r50", "train_r50_b128", "train_r50_ilsvrc"):
+        t = out.get(leg)
+        if isinstance(t, dict) and t.get("grad_allreduce_ms") is not None:
+            ar, step = t["grad_allreduce_ms"], t["ms_per_step"]
+            summ[leg] = {"images_per_sec": t["value"], "ms_per_step": step, "grad_allreduce_ms": ar, "grad_bytes": t.get("grad_bytes"),
+                         "allreduce_busbw_GBps": 2.0 * (world - 1) / world * t.get("grad_bytes", 0) / 1e6 / ar if ar else None,
+                         # exposed exchange time = step time - the same step's time with the collective hidden perfectly (unknown here);
+                         # the bound reported is the standalone all-reduce as a fraction of the step: overlap can only make it smaller
+                         "allreduce_frac_of_step_upper_bound": ar / step}
+    return summ
+
+
 class KernelTimer:
     """HIP-event timing of individual launches on the stream they are enqueued on (torch's current
     stream, which is the stream handed to the C ABI)."""
@@ -418,10 +470,16 @@ def pmc_traffic_gb(kernel, q, n, d):
         return None
 
 
-def cpu_baseline_retrieval(args, feats_h):
+def cpu_baseline_retrieval(args, feats_h, rk_gpu=None):
     """The reference's NumPy op sequence (oracle port) on a bounded query sample, host cores.  `value` uses the reference's own
     call, ``np.argsort`` with the default kind (evaluate_retrieval.py:67; NumPy 2.x: a vectorised quicksort); the stable kind
-    (the canonical tie order) is timed beside it."""
+    (the canonical tie order) is timed beside it.
+
+    Same-node parity evidence (not timed): ``host_blas_is_fma_chain`` -- does THIS host's BLAS compute the sequential fp32 FMA chain
+    the kernels reproduce (oracle/retrieval_oracle.probe_host_blas_is_fma_chain)?  When it does, the rankings the GPU produced in the
+    last timed step (``rk_gpu``) are compared with the host NumPy rankings of the same sampled queries: a row counts as different
+    when the distance sequences along the two rankings differ anywhere, i.e. when the rankings disagree OUTSIDE groups of exactly
+    equal distances (inside such a group np.argsort's default kind is free to order as it likes).  Expected: 0."""
     from oracle import retrieval_oracle as ro
     qn = min(args.cpu_sample_queries, feats_h.shape[0])
     f = feats_h.copy()
@@ -435,7 +493,23 @@ def cpu_baseline_retrieval(args, feats_h):
     t3 = time.perf_counter()
     assert rank.shape == (qn, feats_h.shape[0]) and rank_s.shape == (qs, feats_h.shape[0])
     n = feats_h.shape[0]
-    return {"value": qn * n / (t2 - t0) / 1e6, "unit": "Mpairs/s", "cores": os.cpu_count(), "kind": "port",
+    parity = {"host_blas_is_fma_chain": None, "gpu_vs_host_rows_compared": 0, "gpu_vs_host_rows_differing_outside_ties": None}
+    try:
+        parity["host_blas_is_fma_chain"] = bool(ro.probe_host_blas_is_fma_chain(d=feats_h.shape[1]))
+        if rk_gpu is not None and parity["host_blas_is_fma_chain"] and tuple(rk_gpu.shape) == (n, n):
+            differing = identical = 0
+            for r0 in range(0, qn, 2048):
+                r1 = min(qn, r0 + 2048)
+                g = rk_gpu[r0:r1].cpu().numpy().astype(np.int64)
+                a = np.take_along_axis(pdm[r0:r1], g, axis=1)
+                b = np.take_along_axis(pdm[r0:r1], rank[r0:r1], axis=1)
+                differing += int((a != b).any(axis=1).sum())
+                identical += int((g == rank[r0:r1]).all(axis=1).sum())
+            parity.update(gpu_vs_host_rows_compared=qn, gpu_vs_host_rows_differing_outside_ties=differing,
+                          gpu_vs_host_rows_identical_including_tie_order=identical)
+    except Exception as e:       # noqa: BLE001
+        parity["error"] = "%s: %s" % (type(e).__name__, e)
+    return {"value": qn * n / (t2 - t0) / 1e6, "unit": "Mpairs/s", "cores": os.cpu_count(), "kind": "port", "same_node_parity": parity,
             "value_stable_argsort": n / ((t1 - t0) / qn + (t3 - t2) / qs) / 1e6,
             "seconds": {"norm_and_dot": t1 - t0, "argsort_default": t2 - t1, "argsort_stable_%d_rows" % qs: t3 - t2},
             "sample": "%d of %d queries x %d gallery, D=%d: np.linalg.norm + np.dot (BLAS threads = all cores) + np.argsort "
@@ -450,9 +524,19 @@ def cpu_baseline_retrieval(args, feats_h):
 def bench_sharded_gallery(args, rank, world, reps=2):
     """50,000 queries (replicated) x world * 160,146 gallery rows (sharded) x D = 1000, k = 251: per-shard fused distance +
     top-k (se_retrieve_topk) -> RCCL all-gather of the [Q, k] (f32, i32) lists -> se_topk_merge; each phase timed separately
-    with barriers in between (HIP events on the launch stream for the kernels, host clock around the collective)."""
+    with barriers in between (HIP events on the launch stream for the kernels, host clock around the collective).
+
+    The headline of the leg uses the arithmetic that REPRODUCES the reference at this depth: at D = 1000 the host BLAS behind
+    `np.dot` (evaluate_retrieval.py:59) restarts its fp32 chain per K block -- `host_blas_kblocks(1000)` = [448, 276, 276] --
+    and one single chain does not give the reference's near-tie order (tests/golden/topk_head_d1000_*).  The single-chain time
+    stands beside it (`ms.local_topk_single_chain`).  AFTER the timed region >= 50 sampled queries of this rank's shard result
+    are compared with oracle/canon.c run with the same K-block list (`verified`)."""
     import sehip
+    from evaluate_retrieval import host_blas_kblocks
+    from sharded_retrieval import all_gather_packed
     Q, NS, D, K = args.shard_queries, args.shard_rows, args.shard_dim, args.shard_k
+    kblocks = host_blas_kblocks(D)
+    kblocks = kblocks if len(kblocks) > 1 else None
     gen = torch.Generator(device="cuda").manual_seed(1000 + rank)
     shard = torch.randn((NS, D), generator=gen, device="cuda", dtype=torch.float32)
     gq = torch.Generator(device="cuda").manual_seed(7)              # the same queries on every rank
@@ -460,46 +544,67 @@ def bench_sharded_gallery(args, rank, world, reps=2):
     sehip.normalize_rows_(shard)
     sehip.normalize_rows_(queries)
     off = rank * NS
-    all_d = torch.empty((world * Q, K), dtype=torch.float32, device="cuda")
-    all_i = torch.empty((world * Q, K), dtype=torch.int32, device="cuda")
-    t_local, t_gather, t_merge = [], [], []
+    t_local, t_single, t_gather, t_merge = [], [], [], []
+    packed = torch.empty((2, Q, K), dtype=torch.int32, device="cuda")          # this rank's all-gather send block: (distance bits | indices)
+    d, i = packed[0].view(torch.float32), packed[1]
     md = mi = None
     for it in range(reps + 1):
         barrier_sync(world)
         t0 = time.perf_counter()
-        d, i = sehip.retrieve_topk(queries, shard, K, metric=sehip.METRIC_COSINE, col_offset=off)
+        sehip.retrieve_topk(queries, shard, K, metric=sehip.METRIC_COSINE, col_offset=off, kblocks=kblocks, out=(d, i))
         barrier_sync(world)
         t1 = time.perf_counter()
-        if world > 1:
-            dist.all_gather_into_tensor(all_d, d)
-            dist.all_gather_into_tensor(all_i, i)
-        else:
-            all_d.copy_(d)
-            all_i.copy_(i)
+        gathered = all_gather_packed(packed, world)                 # ONE all-gather of the packed lists
         barrier_sync(world)
         t2 = time.perf_counter()
-        md, mi = sehip.topk_merge(all_d.view(world, Q, K), all_i.view(world, Q, K))
+        md, mi = sehip.topk_merge(gathered)                          # se_topk_merge_packed, straight out of the receive buffer
         barrier_sync(world)
         t3 = time.perf_counter()
+        if kblocks is not None:                                      # beside it: the one-chain arithmetic (not the reference's at D > 448)
+            sehip.retrieve_topk(queries, shard, K, metric=sehip.METRIC_COSINE, col_offset=off)
+            barrier_sync(world)
+        t4 = time.perf_counter()
         if it > 0:            # first round: workspace allocation, RCCL channel set-up
             t_local.append(t1 - t0)
             t_gather.append(t2 - t1)
             t_merge.append(t3 - t2)
-    loc, gat, mer = (max_over_ranks(float(np.mean(t)), world, "cuda") * 1e3 for t in (t_local, t_gather, t_merge))
-    # size-independent sanity of the merged lists (the per-kernel parity tests carry the bit-exact checks)
+            t_single.append(t4 - t3)
+    loc, gat, mer, sgl = (max_over_ranks(float(np.mean(t)), world, "cuda") * 1e3 for t in (t_local, t_gather, t_merge, t_single))
+    # size-independent sanity of the merged lists
     sorted_ok = bool((md[:, 1:] >= md[:, :-1]).all()) and bool(((md[:, 1:] > md[:, :-1]) | (mi[:, 1:] > mi[:, :-1])).all())
     in_range = bool(((mi >= 0) & (mi < world * NS)).all())
     total = loc + gat + mer
     flops = 2.0 * Q * NS * D
-    return {"metric": "sharded_retrieval_Mpairs_per_sec", "value": float(Q) * NS * world / total / 1e3, "unit": "Mpairs/s", "n_gpus": world,
-            "ms": {"local_topk": loc, "all_gather": gat, "merge": mer, "total": total}, "reps": reps,
-            "config": {"workload": "ILSVRC-sized sharded-gallery retrieval: %d queries x %d x %d gallery rows, D=%d, k=%d, cosine"
-                                   % (Q, world, NS, D, K), "queries": Q, "gallery_rows_per_gpu": NS, "dim": D, "k": K,
-                       "parallelism": "gallery sharded %d ways, RCCL all-gather of per-shard top-k, canonical merge" % world},
-            "all_gather_bytes_per_rank": Q * K * 8, "all_gather_GBps_per_rank": (world - 1) * Q * K * 8 / 1e6 / gat if world > 1 else None,
-            "local_topk_TFLOPs": flops / 1e9 / loc, "local_topk_frac_mfma_f32": flops / 1e9 / loc / MFMA_F32_PEAK_TFLOPS,
-            "merged_lists_sorted_with_index_tiebreak": sorted_ok, "merged_indices_in_range": in_range, "scaling": "weak",
-            "data": "synthetic"}
+    out = {"metric": "sharded_retrieval_Mpairs_per_sec", "value": float(Q) * NS * world / total / 1e3, "unit": "Mpairs/s", "n_gpus": world,
+           "ms": {"local_topk": loc, "all_gather": gat, "merge": mer, "total": total,
+                  "local_topk_single_chain": sgl if kblocks is not None else loc}, "reps": reps,
+           "config": {"workload": "ILSVRC-sized sharded-gallery retrieval: %d queries x %d x %d gallery rows, D=%d, k=%d, cosine"
+                                  % (Q, world, NS, D, K), "queries": Q, "gallery_rows_per_gpu": NS, "dim": D, "k": K,
+                      "kblocks": kblocks, "arithmetic": "fp32 FMA chain restarted per host-BLAS K block (what np.dot computes at this depth)"
+                      if kblocks is not None else "one fp32 FMA chain",
+                      "parallelism": "gallery sharded %d ways, ONE RCCL all-gather of the packed per-shard top-k lists, canonical merge" % world},
+           "all_gather_bytes_per_rank": Q * K * 8, "all_gather_GBps_per_rank": (world - 1) * Q * K * 8 / 1e6 / gat if world > 1 else None,
+           "local_topk_TFLOPs": flops / 1e9 / loc, "local_topk_frac_mfma_f32": flops / 1e9 / loc / MFMA_F32_PEAK_TFLOPS,
+           "local_topk_note": "useful flops 2 Q N D over the time of the whole call, against the fp32 MFMA peak (the exact path's pipe); "
+                              "the pre-filter of the call runs on the bf16 pipe, see DESIGN.md 5.3",
+           "merged_lists_sorted_with_index_tiebreak": sorted_ok, "merged_indices_in_range": in_range, "scaling": "weak",
+           "data": "synthetic"}
+    if args.verify:
+        try:
+            from oracle import verify
+            t0 = time.perf_counter()
+            rows = verify.sample_rows(Q, n_random=36)
+            det = verify.verify_topk_sample(queries.cpu().numpy(), shard.cpu().numpy(), 0, K, d, i, rows, col_offset=off, kblocks=kblocks)
+            det["seconds"] = time.perf_counter() - t0
+            ok = det["distances_bit_equal"] and det["indices_equal"] and sorted_ok and in_range
+        except Exception as e:
+            ok, det = False, {"error": "%s: %s" % (type(e).__name__, e)}
+        if world > 1:
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = bool(int(flag.item()))
+        out["verified"], out["verify_detail"] = bool(ok), det
+    return out
 
 
 # ---------------------------------------------------------------------------------------------
@@ -593,6 +698,8 @@ def main(argv=None):
                 out[name] = {"error": "%s: %s" % (type(e).__name__, e)}
 
         leg("hierarchical_precision", lambda: bench_metrics(args, rk))
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:      # reported baseline: rank 0 at N = 1 only, bounded sample; it also
+            leg("cpu_baseline", lambda: cpu_baseline_retrieval(args, feats_h, rk))   # compares rk with the host ranks
         del rk
         torch.cuda.empty_cache()
         leg("retrieve_topk", lambda: bench_topk_all_pairs(args, feats_h))
@@ -614,14 +721,23 @@ def main(argv=None):
             r50 = argparse.Namespace(**dict(vars(args), arch="resnet-50", batch=64))
             leg("train_r50", lambda: bench_train(r50, rank, world, scaling=sc))                            # configs[3]: CUB, 200 classes
             leg("train_r50_ilsvrc", lambda: bench_train(r50, rank, world, classes=1000, scaling=sc))    # configs[4]: C = D = 1000
+            r50b = argparse.Namespace(**dict(vars(args), arch="resnet-50", batch=128))                  # B = 128 per GPU
+            leg("train_r50_b128", lambda: bench_train(r50b, rank, world, scaling=sc))
+            leg("train_r50_ilsvrc_b128", lambda: bench_train(r50b, rank, world, classes=1000, scaling=sc))
         if rank == 0 and world == 1 and not args.no_cpu_baseline:      # reported baselines: rank 0 at N = 1 only, bounded samples
-            out["cpu_baseline"] = cpu_baseline_retrieval(args, feats_h)
             if args.with_train and "error" not in out["train"]:
                 try:
                     from train_bench import cpu_baseline_train
                     out["train"]["cpu_baseline"] = cpu_baseline_train(args)
                 except Exception as e:
                     out["train"]["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    try:
+        out["rccl"] = comm_identity(world, dry=args.dry)
+        mg = multi_gpu_summary(out, world)
+        if mg is not None:
+            out["multi_gpu"] = mg
+    except Exception as e:       # noqa: BLE001 -- identity fields must never lose the measurement
+        out["rccl"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if rank == 0:
         print(json.dumps(out))
         sys.stdout.flush()

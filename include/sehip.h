@@ -241,6 +241,14 @@ int se_topk_merge(const float *d, const int32_t *idx, int parts, int64_t q, int 
                   int32_t *out_i, se_stream_t stream);
 
 /*
+ * The same merge on PACKED lists: part p is one contiguous block of 2 q k 32-bit words -- its [q, k] distances (f32) followed by
+ * its [q, k] indices (i32).  That is the receive buffer of ONE all-gather in which every rank contributes its (dist | idx) block
+ * (sharded_retrieval.all_gather_lists): half the collectives of gathering distances and indices separately.
+ */
+int se_topk_merge_packed(const void *packed, int parts, int64_t q, int k, float *out_d, int32_t *out_i,
+                         se_stream_t stream);
+
+/*
  * Fused distance + top-k: the k nearest gallery rows of every query WITHOUT the [q, n] distance matrix
  * (SURVEY.md section 8d "fused top-k": bytes = 4 (q + n) d + 8 q k).
  * Replaces: the head of evaluate_retrieval.py:57-67 (normalise / distances / np.argsort) for consumers that read only the

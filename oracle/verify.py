@@ -80,3 +80,17 @@ def verify_retrieval_step(feats, pd, rk, metric, queries=None, n_random=40, kblo
     detail.update(check_sampled_rows(feats, pd, rk, metric, sample_rows(pd.shape[0], n_random), queries, kblocks))
     all_ok = all(v for k, v in detail.items() if k != "rows_checked")
     return all_ok, detail
+
+
+def verify_topk_sample(queries, gallery, metric, k, got_d, got_i, rows, col_offset=0, kblocks=None):
+    """Sampled queries of a fused distance + top-k call (``se_retrieve_topk``: one shard of the sharded-gallery split, or an
+    all-pairs call) against the oracle: rows ``rows`` of ``(got_d, got_i)`` [Q, k] must equal the first k entries of the canonical
+    ranking of canon.c's distances (same K-block list) bit for bit.  ``queries`` / ``gallery``: host f32 rows as the kernel saw them."""
+    rows = [int(r) for r in rows]
+    want_pd = ro.canon_pdist(np.ascontiguousarray(queries[rows]), gallery, metric, kblocks)
+    wd, wi = ro.canon_topk_rows(want_pd, k, col_offset=col_offset)
+    gd = np.asarray(got_d)[rows] if not hasattr(got_d, "cpu") else got_d[rows].cpu().numpy()
+    gi = np.asarray(got_i)[rows] if not hasattr(got_i, "cpu") else got_i[rows].cpu().numpy()
+    bad_rows = [rows[j] for j in range(len(rows)) if not (np.array_equal(gd[j], wd[j]) and np.array_equal(gi[j], wi[j]))]
+    return {"queries_checked": len(rows), "distances_bit_equal": bool(np.array_equal(gd, wd)), "indices_equal": bool(np.array_equal(gi, wi)),
+            "mismatching_queries": bad_rows[:8]}

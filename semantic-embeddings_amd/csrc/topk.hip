@@ -340,7 +340,7 @@ __global__ __launch_bounds__(TK_THREADS, 4) void topk_sample_kernel(const float 
     }
 }
 
-__global__ __launch_bounds__(256) void topk_merge_kernel(const float *__restrict__ d, const int32_t *__restrict__ idx,
+__global__ __launch_bounds__(256) void topk_merge_kernel(const float *__restrict__ d, const int32_t *__restrict__ idx, int64_t part_stride,
                                                          int parts, int64_t Q, int k, int P,
                                                          float *__restrict__ out_d, int32_t *__restrict__ out_i)
 {
@@ -352,7 +352,7 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(const float *__restrict
             uint64_t v = ~0ull;
             if (t < m) {
                 const int p = t / k, r = t - p * k;
-                const int64_t src = ((int64_t)p * Q + row) * k + r;
+                const int64_t src = (int64_t)p * part_stride + row * k + r;
                 v = ((uint64_t)canon_key(d[src]) << 32) | (uint32_t)idx[src];
             }
             mg_lds[t] = v;
@@ -405,19 +405,34 @@ extern "C" int se_topk_rows(const float *pdist, int64_t ldp, int64_t q, int64_t 
     return SE_OK;
 }
 
-extern "C" int se_topk_merge(const float *d, const int32_t *idx, int parts, int64_t q, int k, float *out_d,
+static int topk_merge_launch(const char *who, const float *d, const int32_t *idx, int64_t part_stride, int parts, int64_t q, int k, float *out_d,
                              int32_t *out_i, se_stream_t stream)
 {
-    if (parts < 1 || q < 0 || k < 1) return fail(SE_ERR_INVALID, "se_topk_merge: bad shape");
-    if ((int64_t)parts * k > (int64_t)SE_TOPK_MAX * 4) return fail(SE_ERR_UNSUPPORTED, "se_topk_merge: parts*k = %lld exceeds %d", (long long)parts * k, SE_TOPK_MAX * 4);
+    if (parts < 1 || q < 0 || k < 1) return fail(SE_ERR_INVALID, "%s: bad shape", who);
+    if ((int64_t)parts * k > (int64_t)SE_TOPK_MAX * 4) return fail(SE_ERR_UNSUPPORTED, "%s: parts*k = %lld exceeds %d", who, (long long)parts * k, SE_TOPK_MAX * 4);
     if (q == 0) return SE_OK;
-    if (!d || !idx || !out_d || !out_i) return fail(SE_ERR_INVALID, "se_topk_merge: null pointer");
+    if (!d || !idx || !out_d || !out_i) return fail(SE_ERR_INVALID, "%s: null pointer", who);
     const int P = next_pow2(parts * k);
     const size_t lds = (size_t)P * 8;
     const int64_t grid = q < 4096 ? q : 4096;
-    hipLaunchKernelGGL(topk_merge_kernel, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, d, idx, parts, q, k, P, out_d, out_i);
+    hipLaunchKernelGGL(topk_merge_kernel, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, d, idx, part_stride, parts, q, k, P, out_d, out_i);
     SE_LAUNCH_CHECK();
     return SE_OK;
+}
+
+extern "C" int se_topk_merge(const float *d, const int32_t *idx, int parts, int64_t q, int k, float *out_d,
+                             int32_t *out_i, se_stream_t stream)
+{
+    return topk_merge_launch("se_topk_merge", d, idx, q * k, parts, q, k, out_d, out_i, stream);
+}
+
+// packed lists: per part one contiguous block of 2 q k words -- [q, k] distances (f32) followed by [q, k] indices (i32) -- i.e.
+// exactly what ONE all-gather of every rank's (dist | idx) block produces
+extern "C" int se_topk_merge_packed(const void *packed, int parts, int64_t q, int k, float *out_d, int32_t *out_i, se_stream_t stream)
+{
+    const float *d = (const float *)packed;
+    const int32_t *idx = packed ? (const int32_t *)packed + q * k : nullptr;
+    return topk_merge_launch("se_topk_merge_packed", d, idx, 2 * q * k, parts, q, k, out_d, out_i, stream);
 }
 
 // ------------------------------------------------------------------------------------------------

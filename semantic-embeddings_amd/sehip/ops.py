@@ -374,9 +374,20 @@ def topk_rows(pdist, k, col_offset=0):
     return od, oi
 
 
-def topk_merge(d, idx):
-    """Merge per-shard lists [parts, q, k] (e.g. an all-gather result) into the global top-k."""
+def topk_merge(d, idx=None):
+    """Merge per-shard lists [parts, q, k] (e.g. an all-gather result) into the global top-k.  With ``idx=None``, ``d`` is a PACKED
+    int32 buffer [parts, 2, q, k] -- per part the float32 distance bits followed by the indices, the receive buffer of ONE
+    all-gather (``se_topk_merge_packed``)."""
     require_gpu(d, idx)
+    if idx is None:
+        if d.dim() != 4 or d.shape[1] != 2 or d.dtype != torch.int32:
+            raise SehipError("packed lists must be an int32 tensor [parts, 2, q, k]")
+        d = d.contiguous()
+        parts, _, q, k = d.shape
+        od = torch.empty((q, k), dtype=torch.float32, device=d.device)
+        oi = torch.empty((q, k), dtype=torch.int32, device=d.device)
+        check(lib().se_topk_merge_packed(ptr(d), parts, q, k, ptr(od), ptr(oi), stream_ptr()), "se_topk_merge_packed")
+        return od, oi
     d = d.contiguous(); idx = idx.contiguous()
     parts, q, k = d.shape
     od = torch.empty((q, k), dtype=torch.float32, device=d.device)
@@ -391,9 +402,10 @@ def _kblocks_arg(kblocks):
     return (ctypes.c_int32 * len(kblocks))(*[int(v) for v in kblocks]), len(kblocks)
 
 
-def retrieve_topk(queries, gallery, k, metric=METRIC_COSINE, col_offset=0, sqq=None, sqg=None, kblocks=None):
+def retrieve_topk(queries, gallery, k, metric=METRIC_COSINE, col_offset=0, sqq=None, sqg=None, kblocks=None, out=None):
     """Fused distances + top-k (``se_retrieve_topk``): the first k entries of every query's canonical ranking against ``gallery``
-    without the [q, n] matrix; ``kblocks`` = the BLAS K-block list of ``pairwise_dist`` (D > 448)."""
+    without the [q, n] matrix; ``kblocks`` = the BLAS K-block list of ``pairwise_dist`` (D > 448).  ``out``: optional
+    ``(dist f32 [q, k], idx i32 [q, k])`` contiguous destination tensors (e.g. the two halves of a packed all-gather send buffer)."""
     require_gpu(queries, gallery, sqq, sqg)
     _f32_rows(queries, "queries"); _f32_rows(gallery, "gallery")
     q, d = queries.shape
@@ -403,8 +415,15 @@ def retrieve_topk(queries, gallery, k, metric=METRIC_COSINE, col_offset=0, sqq=N
     if metric == METRIC_EUCLID:
         sqq = row_sqnorm(queries) if sqq is None else sqq
         sqg = row_sqnorm(gallery) if sqg is None else sqg
-    od = torch.empty((q, k), dtype=torch.float32, device=queries.device)
-    oi = torch.empty((q, k), dtype=torch.int32, device=queries.device)
+    if out is None:
+        od = torch.empty((q, k), dtype=torch.float32, device=queries.device)
+        oi = torch.empty((q, k), dtype=torch.int32, device=queries.device)
+    else:
+        od, oi = out
+        require_gpu(od, oi)
+        if od.dtype != torch.float32 or oi.dtype != torch.int32 or tuple(od.shape) != (q, k) or tuple(oi.shape) != (q, k) \
+                or not od.is_contiguous() or not oi.is_contiguous():
+            raise SehipError("out must be contiguous (float32 [q, k], int32 [q, k]) tensors")
     need = lib().se_retrieve_topk_workspace_bytes(q, n, gallery.stride(0), int(k))
     ws = _workspace(need, queries.device)
     kb, nkb = _kblocks_arg(kblocks)

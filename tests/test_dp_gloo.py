@@ -96,6 +96,29 @@ def _topk_worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
+def _packed_worker(rank, world, port, out):
+    _setup(rank, world, port)
+    import sharded_retrieval as sr
+    q, k = 5, 7
+    d = torch.full((q, k), float(rank) + 0.5) + torch.arange(k, dtype=torch.float32)
+    i = torch.arange(q * k, dtype=torch.int32).view(q, k) + 1000 * rank
+    g = sr.all_gather_packed(sr.pack_lists(d, i), world)
+    assert tuple(g.shape) == (world, 2, q, k) and g.dtype == torch.int32 and g.is_contiguous()
+    for r in range(world):                                   # rank-major blocks: distance bits, then indices
+        assert torch.equal(g[r, 0].view(torch.float32), torch.full((q, k), float(r) + 0.5) + torch.arange(k, dtype=torch.float32))
+        assert torch.equal(g[r, 1], torch.arange(q * k, dtype=torch.int32).view(q, k) + 1000 * r)
+    if rank == 0:
+        np.savez(out, ok=np.ones(1))
+    dist.destroy_process_group()
+
+
+def test_packed_all_gather_layout(tmp_path):
+    """ONE all-gather of every rank's packed (distance bits | indices) block -> [world, 2, Q, k], the layout se_topk_merge_packed reads."""
+    out = str(tmp_path / "packed.npz")
+    mp.spawn(_packed_worker, args=(2, 29641, out), nprocs=2, join=True)
+    assert os.path.exists(out)
+
+
 def test_sharded_gallery_topk_equals_unsharded(tmp_path):
     from oracle import retrieval_oracle as ro
     out = str(tmp_path / "topk.npz")

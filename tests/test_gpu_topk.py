@@ -181,3 +181,56 @@ def test_fused_topk_full_size_head_equals_full_ranking(sehip):
     rows = [0, 127, 128, 25000, 49999]
     wd, wi = want_topk(xh[rows], xh, k, ro.METRIC_COSINE)
     assert np.array_equal(ii[rows].cpu().numpy(), wi) and np.array_equal(dd[rows].cpu().numpy(), wd)
+
+
+@pytest.mark.parametrize("metric", [0, 1])
+def test_product_library_d1000_kblocks_large_gallery(sehip, metric):
+    """BASELINE configs[4]'s arithmetic through the PRODUCT library (no switches): D = 1000 with the host-BLAS K-block list
+    [448, 276, 276] (what np.dot computes at this depth, evaluate_retrieval.py:59), a gallery above the 16,384-row threshold of
+    the fused passes, k = 251, both metrics, trained-like features (class-embedding row + noise: dense near-ties) -- sampled
+    queries bit-equal to canon.c with the same list."""
+    from evaluate_retrieval import host_blas_kblocks
+    from oracle import verify
+    kb = host_blas_kblocks(1000)
+    assert kb == [448, 276, 276]
+    n, q, d, k = 18000, 640, 1000, 251
+    emb = np.load(os.path.join(os.path.dirname(__file__), "golden", "imagenet_mintree_unitsphere.npz"))["embedding"]
+    rng = np.random.default_rng(31 + metric)
+    y = rng.integers(0, emb.shape[0], size=n)
+    g = (emb[y] + 0.03 * rng.standard_normal((n, d))).astype(np.float32)
+    yq = rng.integers(0, emb.shape[0], size=q)
+    qs = (emb[yq] + 0.03 * rng.standard_normal((q, d))).astype(np.float32)
+    if metric == 0:
+        g, qs = ro.canon_normalize_rows(g), ro.canon_normalize_rows(qs)
+    need = sehip.lib().se_retrieve_topk_workspace_bytes(q, n, d, k)
+    assert need < q * n * 4 + 256 * n * 4 + (64 << 20), "fused layout expected (candidate lists, not a distance slab)"
+    dd, ii = sehip.retrieve_topk(dev(qs), dev(g), k, metric=metric, kblocks=kb, col_offset=n)
+    rows = verify.sample_rows(q, n_random=12)
+    det = verify.verify_topk_sample(qs, g, metric, k, dd, ii, rows, col_offset=n, kblocks=kb)
+    assert det["indices_equal"] and det["distances_bit_equal"], det
+    # every list sorted under the canonical order, indices inside the shard's global range
+    assert bool(((dd[:, 1:] > dd[:, :-1]) | ((dd[:, 1:] == dd[:, :-1]) & (ii[:, 1:] > ii[:, :-1]))).all())
+    assert bool(((ii >= n) & (ii < 2 * n)).all())
+    # all-pairs call on the same gallery (upper-triangle walk + mirrored filter) with the list
+    x = dev(g)
+    sq = sehip.row_sqnorm(x) if metric == 1 else None
+    d2, i2 = sehip.retrieve_topk(x, x, k, metric=metric, kblocks=kb, sqq=sq, sqg=sq)
+    rows2 = verify.sample_rows(n, n_random=6)
+    det2 = verify.verify_topk_sample(g, g, metric, k, d2, i2, rows2, kblocks=kb)
+    assert det2["indices_equal"] and det2["distances_bit_equal"], det2
+
+
+def test_topk_merge_packed_equals_separate_lists(sehip):
+    """se_topk_merge_packed on the receive buffer of ONE all-gather ([parts, 2, q, k]: distance bits | indices per part) ==
+    se_topk_merge on separate [parts, q, k] tensors == the oracle's merge."""
+    rng = np.random.default_rng(5)
+    parts, q, k = 4, 300, 251
+    d = np.sort(rng.standard_normal((parts, q, k)).astype(np.float32), axis=-1)
+    d[1, :, :40] = d[0, :, :40]                              # exact ties across parts: global index decides
+    i = (np.arange(parts)[:, None, None] * 100000 + np.sort(rng.integers(0, 100000, size=(parts, q, k)), axis=-1)).astype(np.int32)
+    packed = np.stack([d.view(np.int32), i], axis=1)         # [parts, 2, q, k]
+    md, mi = sehip.topk_merge(dev(d), dev(i))
+    pd_, pi_ = sehip.topk_merge(dev(packed))
+    wd, wi = ro.canon_topk_merge(d, i)
+    assert np.array_equal(md.cpu().numpy(), wd) and np.array_equal(mi.cpu().numpy(), wi)
+    assert np.array_equal(pd_.cpu().numpy(), wd) and np.array_equal(pi_.cpu().numpy(), wi)
