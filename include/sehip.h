@@ -11,9 +11,17 @@
  *   - row-major, innermost dimension contiguous, explicit leading dimensions in ELEMENTS;
  *   - the caller owns every buffer; scratch memory is sized by the *_workspace_bytes() queries
  *     and passed in -- the library never allocates device memory;
- *   - `stream` is a hipStream_t passed as void*; all work is enqueued asynchronously on it;
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued asynchronously on it.  Exceptions, each marked at its
+ *     declaration: se_rank_rows_init and se_rank_rows_check synchronise the stream (they hand a verdict to the host), and
+ *     se_rank_rows synchronises ONCE per process and device when se_rank_rows_init was not called first (see there);
  *   - return value: SE_OK (0) or a negative SE_ERR_* code; se_last_error() (thread-local text)
- *     explains the last failure; no exceptions, no global mutable state, re-entrant;
+ *     explains the last failure; no exceptions; re-entrant, safe from any host thread.  Process-wide state is limited to
+ *     read-mostly caches filled at first use: device properties (CU count, kernel occupancies), the plan table of
+ *     se_retrieve_topk, and -- the only one that influences which kernel runs -- the per-device verdict of the ranking's
+ *     capability probe / self-test (atomics; see se_rank_rows_init).  Three environment variables are read by the product build,
+ *     all of them by the ranking only: SE_RANK_SAFE=1 (never use the hardware-ordered kernels), SE_RANK_CHECK=1 (audit every row
+ *     of every se_rank_rows call: synchronises every call), SE_RANK_VERBOSE=1 (probe / self-test verdicts on stderr).  Results
+ *     never depend on them; no other switch exists in libsehip.so (libsehip_tuning.so is the build with tuning switches);
  *   - float32 arithmetic on the bit-exact paths follows the "canonical arithmetic" of
  *     DESIGN.md section 3 (sequential fp32 FMA chain over k, NumPy pairwise row sums,
  *     ascending (distance, index) order, NaN last, -0 == +0).
@@ -207,6 +215,23 @@ int se_pairwise_dist(const float *a, int64_t lda, const float *b, int64_t ldb, c
 int64_t se_rank_rows_workspace_bytes(int64_t q, int64_t n);
 int se_rank_rows(const float *pdist, int64_t ldp, int64_t q, int64_t n, void *rank, int idx64,
                  int64_t ldr, void *workspace, int64_t workspace_bytes, se_stream_t stream);
+
+/*
+ * One-time set-up of the ranking on the CURRENT device -- the only entry point of the ranking that synchronises by design.
+ * The fastest kernels of se_rank_rows take their stable order from the lane order in which the LDS serves same-address
+ * returning adds of one wave instruction: gfx950 serves them in ascending lane order, the ISA does not promise it.  This call
+ * (1) probes the property (64 workgroups, four conflict patterns, the production counter format) and (2) ranks crafted
+ * tie-heavy rows through EVERY hardware-ordered kernel variant (short / long instantiation x plain / group-peeling / two-pass,
+ * segment runs + merge) and audits every row of every result (se_rank_rows_check's kernel).  The verdict is cached per device:
+ * afterwards se_rank_rows is purely asynchronous -- no probe, no guard, no host round trip; it can be captured into a HIP graph --
+ * and uses the hardware-ordered kernels iff both steps passed (else the ballot / tiled kernels, whose order holds by construction).
+ * WITHOUT this call the first se_rank_rows of a process on a device does the probe itself and audits 512 sampled rows of its own
+ * result (hipStreamSynchronize + one 4-byte copy, ~0.5 ms) before it returns; a call that cannot (no workspace for the guard, or
+ * a stream under capture) uses the ballot kernel.
+ *   workspace: se_rank_rows_init_workspace_bytes() bytes (~5 MB), 256-byte aligned; may be freed afterwards.  ~3 ms.
+ */
+int64_t se_rank_rows_init_workspace_bytes(void);
+int se_rank_rows_init(void *workspace, int64_t workspace_bytes, se_stream_t stream);
 
 /*
  * Order guard of se_rank_rows: counts the rows of a finished ranking that violate the canonical order -- along every row

@@ -1568,6 +1568,103 @@ static int rank_hw_order_ok(void *workspace, int64_t workspace_bytes, hipStream_
     return state[dev].load(std::memory_order_acquire) == 1;
 }
 
+// ---- se_rank_rows_init: the ONE synchronising entry point of the ranking --------------------------------------------------------
+// Probe (rank_order_probe_kernel) + a self-test that ranks crafted rows through EVERY hardware-ordered kernel variant -- short
+// instantiation (11 + 11 + 10-bit digits) plain / group-peeling, long instantiation (10 + 10 + 12 bits, aliased counters) plain /
+// peeling / two-pass, and the segment-run build + merge -- and audits every row of every result with rank_check_kernel.  The rows
+// are made of few distinct values (thousands of exact ties per row: stability is what is being tested), mixed signs for the
+// three-pass variants and one binade for the two-pass one.  Afterwards the per-device verdict is cached and se_rank_rows neither
+// probes, guards nor synchronises again (SE_RANK_CHECK=1 still audits every call).
+constexpr int RI_ROWS = 4, RI_N_SHORT = 4000, RI_N_LONG = 36000, RI_N_SEG = 70000;
+
+__global__ void rank_selftest_fill_kernel(float *pd, int64_t ld, int rows, int n, int mode)
+{
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= (int64_t)rows * n) return;
+    const int r = (int)(g / n), c = (int)(g - (int64_t)r * n);
+    uint32_t h = (uint32_t)c * 2654435761u + (uint32_t)(r + 1) * 40503u + (uint32_t)mode * 97u;
+    h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+    float v;
+    if (mode == 2) v = 1.0f + (float)(h % 3001u) * (1.0f / 8192.0f);              // one binade: the two-pass window holds every key
+    else v = ((float)(h % 2001u) - 1000.0f) * (1.0f / 1024.0f);                     // mixed signs, +-0 included (canon: -0 == +0)
+    if (mode != 2 && (h >> 20) % 97u == 0) v = -0.0f;
+    if (mode == 1 && c % 1013 == 5) v = __builtin_nanf("");                         // a few NaN keys: sorted last, index order
+    pd[r * ld + c] = v;
+}
+
+extern "C" int64_t se_rank_rows_init_workspace_bytes(void)
+{
+    const int64_t mat = (int64_t)RI_ROWS * (RI_N_SEG + 8) * 4;
+    return 4096 + 4 * (RC_CAP + 2) + 2 * mat + rank_runs_bytes(RI_ROWS, RI_N_SEG) + 1024;
+}
+
+extern "C" int se_rank_rows_init(void *workspace, int64_t workspace_bytes, se_stream_t stream)
+{
+    if (!workspace || workspace_bytes < se_rank_rows_init_workspace_bytes())
+        return fail(SE_ERR_WORKSPACE, "se_rank_rows_init: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)se_rank_rows_init_workspace_bytes());
+    if ((((uintptr_t)workspace) & 255) != 0) return fail(SE_ERR_INVALID, "se_rank_rows_init: workspace must be 256-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return fail(SE_ERR_HIP, "se_rank_rows_init: no current device");
+    if (!rank_hw_order_ok(workspace, workspace_bytes, s)) {       // SE_RANK_SAFE, or the probe refuted the lane order: ballot kernels, nothing to audit
+        rr_checked[dev].store(1, std::memory_order_release);
+        return SE_OK;
+    }
+    char *w = (char *)workspace + 4096;
+    uint32_t *bad = (uint32_t *)w;                               w += (4 * (RC_CAP + 2) + 255) / 256 * 256;
+    const int64_t ld = RI_N_SEG + 8;
+    float *pd = (float *)w;                                      w += (RI_ROWS * ld * 4 + 255) / 256 * 256;
+    int32_t *rk = (int32_t *)w;                                  w += (RI_ROWS * ld * 4 + 255) / 256 * 256;
+    void *runs_ws = w;
+    uint32_t total_bad = 0;
+    const bool verbose = getenv("SE_RANK_VERBOSE") != nullptr;
+    auto audit = [&](const char *what, int n, int rc) -> int {
+        if (rc != SE_OK) return rc;
+        if (const int rc2 = rank_check_launch(pd, ld, RI_ROWS, n, rk, 0, ld, bad, RC_CAP, 1, s)) return rc2;
+        uint32_t h = 0;
+        SE_HIP_CHECK(hipStreamSynchronize(s));
+        SE_HIP_CHECK(hipMemcpy(&h, bad, sizeof(h), hipMemcpyDeviceToHost));
+        if (verbose || h) fprintf(stderr, "[se_rank_rows_init] device %d, %s: %u of %d rows out of canonical order\n", dev, what, h, RI_ROWS);
+        total_bad += h;
+        return SE_OK;
+    };
+    auto fill = [&](int n, int mode) {
+        hipLaunchKernelGGL(rank_selftest_fill_kernel, dim3((unsigned)(((int64_t)RI_ROWS * n + 255) / 256)), dim3(256), 0, s, pd, ld, RI_ROWS, n, mode);
+    };
+    constexpr int IS = (RI_N_SHORT + RR_THREADS - 1) / RR_THREADS <= 8 ? 8 : 12;          // short instantiation that holds RI_N_SHORT
+#if SE_RR_THREADS == 512
+    constexpr int IL = 72;                                                                // long instantiation that holds RI_N_LONG (and the 35,000-column segments)
+#else
+    constexpr int IL = 70;
+#endif
+    static_assert((int64_t)IL * RR_THREADS >= RI_N_LONG, "self-test row does not fit its instantiation");
+    int rc;
+    fill(RI_N_SHORT, 0);
+    if ((rc = audit("short rows, plain", RI_N_SHORT, launch_rank_reg_variant<IS, true, 0>(pd, ld, RI_ROWS, RI_N_SHORT, rk, 0, ld, nullptr, s)))) return rc;
+    fill(RI_N_SHORT, 1);
+    if ((rc = audit("short rows, group-peeling", RI_N_SHORT, launch_rank_reg_variant<IS, true, 1>(pd, ld, RI_ROWS, RI_N_SHORT, rk, 0, ld, nullptr, s)))) return rc;
+    fill(RI_N_LONG, 0);
+    if ((rc = audit("long rows, plain", RI_N_LONG, launch_rank_reg_variant<IL, true, 0>(pd, ld, RI_ROWS, RI_N_LONG, rk, 0, ld, nullptr, s)))) return rc;
+    fill(RI_N_LONG, 1);
+    if ((rc = audit("long rows, group-peeling", RI_N_LONG, launch_rank_reg_variant<IL, true, 1>(pd, ld, RI_ROWS, RI_N_LONG, rk, 0, ld, nullptr, s)))) return rc;
+#if SE_RR_TWO
+    fill(RI_N_LONG, 2);
+    if ((rc = audit("long rows, two-pass", RI_N_LONG, launch_rank_reg_variant<IL, true, 2>(pd, ld, RI_ROWS, RI_N_LONG, rk, 0, ld, nullptr, s)))) return rc;
+#endif
+#if SE_RR_THREADS == 512
+    if (rank_runs_ok(RI_N_SEG) && rank_runs_items(RI_N_SEG) == IL) {
+        fill(RI_N_SEG, 1);
+        if ((rc = audit("segment runs + merge", RI_N_SEG, launch_rank_runs<IL>(pd, ld, RI_ROWS, RI_N_SEG, rk, 0, ld, runs_ws, s)))) return rc;
+    }
+#endif
+    if (total_bad) {
+        rr_hw_state[dev].store(-1, std::memory_order_release);
+        fprintf(stderr, "[se_rank_rows_init] device %d leaves the hardware-ordered ranking kernels (ballot / tiled kernels from now on)\n", dev);
+    }
+    rr_checked[dev].store(1, std::memory_order_release);
+    return SE_OK;
+}
+
 extern "C" int64_t se_rank_rows_workspace_bytes(int64_t q, int64_t n)
 {
     if (q <= 0 || n <= 0) return 0;
@@ -1587,14 +1684,17 @@ extern "C" int se_rank_rows(const float *pdist, int64_t ldp, int64_t q, int64_t 
     hipStream_t s = (hipStream_t)stream;
     if (!rank_use_tiled(n)) {
         const int items = (int)((n + RR_THREADS - 1) / RR_THREADS);
-        const bool hw = rank_hw_order_ok(workspace, workspace_bytes, s) != 0;
+        bool hw = rank_hw_order_ok(workspace, workspace_bytes, s) != 0;
         void *scratch = (workspace && workspace_bytes >= 256) ? workspace : nullptr;
-        // order guard (see rank_check_kernel): behind the first hardware-ordered ranking of a process and under SE_RANK_CHECK=1
+        // order guard (see rank_check_kernel): behind the first hardware-ordered ranking of a process that did not call
+        // se_rank_rows_init, and under SE_RANK_CHECK=1
         int dev = 0;
         const bool have_dev = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64;
         static const bool check_always = getenv("SE_RANK_CHECK") != nullptr && getenv("SE_RANK_CHECK")[0] != '0';
-        const bool guard = hw && have_dev && workspace && workspace_bytes >= 256 + 4 * (RC_CAP + 2) &&
-                           (check_always || rr_checked[dev].load(std::memory_order_acquire) == 0);
+        const bool audited = have_dev && rr_checked[dev].load(std::memory_order_acquire) != 0;
+        const bool can_guard = have_dev && workspace && workspace_bytes >= 256 + 4 * (RC_CAP + 2);
+        if (hw && !audited && !can_guard) hw = false;   // never run the hardware-ordered kernel unaudited: no room for the guard -> ballot kernel
+        const bool guard = hw && can_guard && (check_always || !audited);
         int rc = SE_ERR_INVALID;
 #define SE_RR_CASE(I) if (rc == SE_ERR_INVALID && items <= I) rc = launch_rank_reg<I>(pdist, ldp, q, (int)n, rank, idx64, ldr, hw, scratch, s);
 #if SE_RR_THREADS == 512

@@ -7,9 +7,16 @@
 // loops_utils.h.src: blocks of <= 128 elements summed with 8 interleaved accumulators, combined
 // as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), tail added sequentially, larger rows split recursively
 // at n/2 rounded down to a multiple of 8).  The order of the additions decides the rounding, so
-// the kernel reproduces exactly that tree: the 8 accumulators of a leaf block are 8 lanes'
-// private chains... kept simple here: one lane walks one row in NumPy's order.  The rows are
-// staged through LDS with coalesced loads first, so HBM sees each byte once, streaming.
+// the kernels reproduce exactly that tree.  Two kernels:
+//   * rownorm_kernel (D < 256): one LANE walks one row in NumPy's order; the rows of a workgroup are staged
+//     through LDS with coalesced loads first, so HBM sees each byte once, streaming.
+//   * rownorm_wave_kernel (256 <= D <= 4096): one WAVE per row.  The row is staged in LDS with coalesced 16-byte
+//     loads; the tree's leaves (host-computed from D: the tree depends on nothing else) are dealt eight at a time to
+//     the eight 8-lane groups of the wave, lane u of a group running accumulator r[u] of its leaf (<= 16 sequential
+//     adds); the ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) combination is a 3-step xor butterfly inside the group (IEEE
+//     addition commutes, the association is NumPy's), the group's first lane adds the leaf's tail, and lane 0 folds
+//     the <= 64 leaf sums with the recursion's postfix program.  The one-lane-per-row kernel needed 132 VGPRs +
+//     scratch for its recursion stack and crawled at ~0.36 TB/s on D = 1000 rows (one lane = 4 KB of sequential work).
 // x*x, the adds, sqrtf and the division are all IEEE round-to-nearest (this file is compiled with
 // -ffp-contract=off; hipcc's default keeps fp32 sqrt/div correctly rounded).
 #include "se_common.h"
@@ -112,6 +119,115 @@ __global__ __launch_bounds__(RN_ROWS) void rownorm_kernel(float *__restrict__ x,
     }
 }
 
+// ---- one wave per row (256 <= D <= 4096) ------------------------------------------------------------------------------------
+constexpr int RW_MAX_LEAVES = 64, RW_MAX_D = 4096, RW_MIN_D = 256;
+struct RowTree {
+    int nleaves, nprog;
+    uint16_t off[RW_MAX_LEAVES];           // first column of leaf i
+    uint8_t len[RW_MAX_LEAVES];            // its length (8 ... 128: a row of >= 256 columns has no shorter leaf)
+    uint8_t prog[2 * RW_MAX_LEAVES];       // postfix fold of the recursion: 0 = push the next leaf sum, 1 = pop b, pop a, push a + b
+};
+
+static void row_tree_build(int off, int n, RowTree &t)
+{
+    if (n <= RN_CHUNK) {
+        t.off[t.nleaves] = (uint16_t)off;
+        t.len[t.nleaves] = (uint8_t)n;
+        t.nleaves++;
+        t.prog[t.nprog++] = 0;
+        return;
+    }
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    row_tree_build(off, n2, t);
+    row_tree_build(off + n2, n - n2, t);
+    t.prog[t.nprog++] = 1;
+}
+
+template <bool NORMALIZE, bool VEC>
+__global__ __launch_bounds__(256) void rownorm_wave_kernel(float *__restrict__ x, int64_t ldx, int64_t n, int d, float *__restrict__ sq,
+                                                           const RowTree t)
+{
+    extern __shared__ __attribute__((aligned(16))) float rw_lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int dpad = (d + 3) & ~3;
+    float *row = rw_lds + wave * (dpad + RW_MAX_LEAVES + 64);        // [dpad] staged row | [64] leaf sums | [64] fold stack
+    float *leaf = row + dpad, *stack = leaf + RW_MAX_LEAVES;
+    const int grp = lane >> 3, u = lane & 7;
+    for (int64_t r = (int64_t)blockIdx.x * nw + wave; r < n; r += (int64_t)gridDim.x * nw) {
+        float *xr = x + r * ldx;
+        // ---- stage the row (coalesced) ----
+        if (VEC) {
+            for (int c = lane * 4; c < d; c += 256) *(float4 *)(row + c) = *(const float4 *)(xr + c);
+        } else {
+            for (int c = lane; c < d; c += 64) row[c] = xr[c];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        // ---- leaves, eight at a time: lane (grp, u) runs accumulator u of leaf l0 + grp ----
+        for (int l0 = 0; l0 < t.nleaves; l0 += 8) {
+            const int li = l0 + grp;
+            const bool have = li < t.nleaves;
+            const int lo = have ? t.off[li] : 0, ln = have ? t.len[li] : 8;
+            const float *a = row + lo;
+            const int body = ln - (ln % 8);
+            float acc = a[u] * a[u];
+            for (int i = 8; i < body; i += 8) { const float v = a[i + u]; acc = acc + v * v; }
+            // ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7)): xor butterfly inside the 8-lane group
+            acc = acc + __shfl_xor(acc, 1, 64);
+            acc = acc + __shfl_xor(acc, 2, 64);
+            acc = acc + __shfl_xor(acc, 4, 64);
+            if (u == 0 && have) {
+                for (int i = body; i < ln; i++) { const float v = a[i]; acc = acc + v * v; }
+                leaf[li] = acc;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        // ---- fold the leaf sums in the recursion's order (lane 0; <= 127 steps) ----
+        float ss = 0.f;
+        if (lane == 0) {
+            int sp = 0, next = 0;
+            for (int i = 0; i < t.nprog; i++) {
+                if (t.prog[i] == 0) stack[sp++] = leaf[next++];
+                else { const float b = stack[sp - 1], aa = stack[sp - 2]; sp--; stack[sp - 1] = aa + b; }
+            }
+            ss = stack[0];
+        }
+        ss = __shfl(ss, 0, 64);
+        if (!NORMALIZE) {
+            if (lane == 0) sq[r] = ss;
+        } else {
+            const float nrm = sqrtf(ss);
+            if (VEC) {
+                for (int c = lane * 4; c < d; c += 256) {
+                    const float4 v = *(const float4 *)(row + c);
+                    *(float4 *)(xr + c) = make_float4(v.x / nrm, v.y / nrm, v.z / nrm, v.w / nrm);
+                }
+            } else {
+                for (int c = lane; c < d; c += 64) xr[c] = row[c] / nrm;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");       // the next row overwrites the stage
+    }
+}
+
+template <bool NORMALIZE>
+static int launch_rownorm_wave(float *x, int64_t ldx, int64_t n, int d, float *sq, hipStream_t s)
+{
+    RowTree t;
+    t.nleaves = t.nprog = 0;
+    row_tree_build(0, d, t);
+    const int dpad = (d + 3) & ~3;
+    const int waves = d <= 1024 ? 4 : (d <= 2048 ? 2 : 1);             // <= ~36 KB of LDS per workgroup
+    const size_t lds = (size_t)waves * (dpad + RW_MAX_LEAVES + 64) * sizeof(float);
+    const bool vec = (d % 4 == 0) && (ldx % 4 == 0) && ((((uintptr_t)x) & 15) == 0);
+    int64_t grid = (n + waves - 1) / waves;
+    if (grid > 256 * 16) grid = 256 * 16;
+    if (vec) hipLaunchKernelGGL((rownorm_wave_kernel<NORMALIZE, true>), dim3((unsigned)grid), dim3(waves * 64), lds, s, x, ldx, n, d, sq, t);
+    else hipLaunchKernelGGL((rownorm_wave_kernel<NORMALIZE, false>), dim3((unsigned)grid), dim3(waves * 64), lds, s, x, ldx, n, d, sq, t);
+    SE_LAUNCH_CHECK();
+    return SE_OK;
+}
+
 }  // namespace se
 
 using namespace se;
@@ -121,6 +237,7 @@ extern "C" int se_row_sqnorm(const float *x, int64_t ldx, int64_t n, int64_t d, 
     if (n < 0 || d <= 0 || d > 0x7FFFFFFF) return fail(SE_ERR_INVALID, "se_row_sqnorm: bad shape");
     if (n == 0) return SE_OK;
     if (!x || !sq || ldx < d) return fail(SE_ERR_INVALID, "se_row_sqnorm: bad argument");
+    if (d >= RW_MIN_D && d <= RW_MAX_D) return launch_rownorm_wave<false>(const_cast<float *>(x), ldx, n, (int)d, sq, (hipStream_t)stream);
     hipLaunchKernelGGL(rownorm_kernel<false>, dim3((unsigned)((n + RN_ROWS - 1) / RN_ROWS)), dim3(RN_ROWS), 0,
                        (hipStream_t)stream, const_cast<float *>(x), ldx, n, (int)d, sq);
     SE_LAUNCH_CHECK();
@@ -132,6 +249,7 @@ extern "C" int se_normalize_rows(float *x, int64_t ldx, int64_t n, int64_t d, se
     if (n < 0 || d <= 0 || d > 0x7FFFFFFF) return fail(SE_ERR_INVALID, "se_normalize_rows: bad shape");
     if (n == 0) return SE_OK;
     if (!x || ldx < d) return fail(SE_ERR_INVALID, "se_normalize_rows: bad argument");
+    if (d >= RW_MIN_D && d <= RW_MAX_D) return launch_rownorm_wave<true>(x, ldx, n, (int)d, (float *)nullptr, (hipStream_t)stream);
     hipLaunchKernelGGL(rownorm_kernel<true>, dim3((unsigned)((n + RN_ROWS - 1) / RN_ROWS)), dim3(RN_ROWS), 0,
                        (hipStream_t)stream, x, ldx, n, (int)d, (float *)nullptr);
     SE_LAUNCH_CHECK();

@@ -48,24 +48,39 @@ def backbone_mode(architecture):
             torch.contiguous_format if layout == 'nchw' else torch.channels_last)
 
 
+FLAT_ALIGN_ELEMS = 64      # every parameter slice of the flat buffers starts on a 256-byte boundary
+
+
 class FlatState(object):
     """Re-homes every trainable parameter of ``model`` into one flat fp32 buffer (keeping each
     parameter's shape and strides, e.g. channels_last conv kernels), with matching flat gradient,
-    velocity and L2-coefficient buffers."""
+    velocity and L2-coefficient buffers.
 
-    def __init__(self, model, l2_of=None):
+    Every slice starts on a 256-byte boundary (``align`` elements; the padding words stay zero in all four buffers, so the
+    whole-buffer update, clip norm and all-reduce see zeros there).  A freshly allocated parameter tensor is 256-byte aligned
+    in PyTorch and vendor kernels may assume so; packing 16-64-element bias vectors back to back put them at arbitrary 4-byte
+    offsets -- the one difference between this trainer's captured step and a plain capture of the same network
+    (DESIGN.md section 7.1)."""
+
+    def __init__(self, model, l2_of=None, align=None):
         params = [p for p in model.parameters() if p.requires_grad]
         self.params = params
-        total = sum(p.numel() for p in params)
+        align = int(os.environ.get('SE_FLAT_ALIGN', FLAT_ALIGN_ELEMS)) if align is None else int(align)
+        self.align = max(align, 1)
+        starts, off = [], 0
+        for p in params:
+            off = (off + self.align - 1) // self.align * self.align
+            starts.append(off)
+            off += p.numel()
+        total = (off + self.align - 1) // self.align * self.align
         dev = params[0].device
-        self.flat_p = torch.empty(total, dtype=torch.float32, device=dev)
+        self.flat_p = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_g = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_v = torch.zeros(total, dtype=torch.float32, device=dev)
         self.flat_l2 = torch.zeros(total, dtype=torch.float32, device=dev)
         self.offsets = []
-        off = 0
         l2_of = l2_of or {}
-        for p in params:
+        for p, off in zip(params, starts):
             n = p.numel()
             dense = p.is_contiguous() or p.is_contiguous(memory_format=torch.channels_last)
             src = p.data if dense else p.data.contiguous()
@@ -77,11 +92,13 @@ class FlatState(object):
             if lam:
                 self.flat_l2[off:off + n] = 2.0 * lam        # d/dw (lam * w^2)
             self.offsets.append((off, n))
-            off += n
         self.total = total
         self.frozen_l2 = [(p, float(l2_of[id(p)])) for p in model.parameters() if not p.requires_grad and l2_of.get(id(p), 0.0)]
         self.has_l2 = bool((self.flat_l2 != 0).any().item())
         self.all_contiguous = all(p.is_contiguous() for p in params)
+        self.packed = all(o == (self.offsets[i - 1][0] + self.offsets[i - 1][1] if i else 0) for i, (o, _) in enumerate(self.offsets)) \
+            and total == sum(n for _, n in self.offsets)
+        self._grad_views = [self.flat_g[o:o + n].view(p.shape) for p, (o, n) in zip(params, self.offsets)] if self.all_contiguous else None
 
     def bind_grads(self):
         """(Re-)point every ``p.grad`` at its slice of the flat gradient buffer (accumulating mode)."""
@@ -90,8 +107,13 @@ class FlatState(object):
 
     def gather_grads(self):
         """Stolen-gradient mode: autograd left every gradient in a tensor of its own (``p.grad`` was None, so nothing
-        was accumulated); pack them into the flat buffer with one batched ``cat`` (4 launches for 442 tensors)."""
-        torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in self.params], out=self.flat_g)
+        was accumulated); pack them into the flat buffer with one batched copy (a handful of multi-tensor launches for 442
+        tensors; the padding words between the slices are never written and stay zero)."""
+        grads = [(p.grad if p.grad is not None else torch.zeros_like(p)) for p in self.params]
+        if self.packed:
+            torch.cat([g.reshape(-1) for g in grads], out=self.flat_g)
+        else:
+            torch._foreach_copy_(self._grad_views, grads)
 
 
 class BucketedAllReduce(object):
@@ -238,7 +260,7 @@ class Trainer(object):
 
     # ---------------------------------------------------------------- HIP-graph replay of the step
 
-    def enable_graphs(self, X, y, warmup=3, validate=4, tol=2e-3, max_noise=0.05):
+    def enable_graphs(self, X, y, warmup=3, validate=4, tol=2e-3, max_noise=0.05, allow_autocast=False):
         """Capture the training step into two HIP graphs (``torch.cuda.CUDAGraph``): A = zero grads + forward + fused
         loss/metric + backward, B = the whole-buffer SGD update; the RCCL all-reduce of the flat gradient buffer stays
         an eager call between them (one message per step), so 1-GPU and N-GPU runs replay identical graphs.
@@ -254,7 +276,7 @@ class Trainer(object):
         On failure the trainer stays eager, says so, and returns False."""
         if not X.is_cuda:
             return False
-        if self.autocast_dtype is not None:
+        if self.autocast_dtype is not None and not allow_autocast:
             # bf16-autocast replays of these backbones return non-finite conv-bias gradients inside this trainer's flat-buffer layout
             # (DESIGN.md section 7.1; root cause not found) and would save nothing (the bf16 ResNet-50 step is GPU-bound in eager mode):
             # the mode is not offered.
@@ -445,8 +467,16 @@ class Trainer(object):
         reg = 0.0
         if flat.has_l2:
             reg += float(0.5 * torch.dot(flat.flat_l2, flat.flat_p * flat.flat_p))     # flat_l2 holds 2 lam
-        for p, lam in flat.frozen_l2:      # layers frozen by --finetune_init keep their regularisers in Keras' loss
-            reg += lam * float((p.detach().float() ** 2).sum())
+        if flat.frozen_l2:                 # layers frozen by --finetune_init keep their regularisers in Keras' loss
+            # their weights do not move while they stay frozen: one device reduction + ONE host sync per (frozen set, weight version)
+            # instead of a launch and a sync per tensor on every call (~160 for a --finetune_init ResNet-50)
+            key = tuple((id(p), p._version, bool(p.requires_grad)) for p, _ in flat.frozen_l2)
+            if getattr(self, '_frozen_reg_key', None) != key:
+                total = torch.zeros((), dtype=torch.float32, device=flat.flat_p.device)
+                for p, lam in flat.frozen_l2:
+                    total = total + lam * (p.detach().float() ** 2).sum()
+                self._frozen_reg, self._frozen_reg_key = float(total), key
+            reg += self._frozen_reg
         return reg
 
     def _reduce_logs(self, logs, n=None):

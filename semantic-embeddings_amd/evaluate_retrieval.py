@@ -20,6 +20,7 @@ reference: evaluate_retrieval.py:22-73 (pairwise_retrieval), :76-151 (reporting 
 import argparse
 import os.path
 import pickle
+import warnings
 from collections import OrderedDict
 
 import numpy as np
@@ -124,8 +125,12 @@ def ranking_tiles(features, normalize=False, tile_rows=None, idx64=False, querie
     q0, q1 = (0, n) if queries is None else queries
     if tile_rows is None:
         tile_rows = max(128, min(n, (DEFAULT_TILE_BYTES // (8 * max(n, 1))) // 128 * 128))
-        if whole_if_fits and features.is_cuda and 8 * n * (q1 - q0) <= torch.cuda.mem_get_info(features.device)[0] // 3:
-            tile_rows = max(tile_rows, q1 - q0)
+        if whole_if_fits and features.is_cuda:
+            # distances + ranks of all queries, plus what the ranking will ask of the (grow-only) workspace cache on top of what that
+            # cache already holds -- up to ~3 GB for rows above 53,248 columns
+            extra_ws = max(0, sehip.rank_rows_workspace_bytes(q1 - q0, n) - sehip.workspace_bytes(features.device))
+            if 8 * n * (q1 - q0) + extra_ws <= torch.cuda.mem_get_info(features.device)[0] // 3:
+                tile_rows = max(tile_rows, q1 - q0)
     pd = sehip.empty_rows(min(tile_rows, max(q1 - q0, 1)), n, torch.float32, features.device)   # row pitch: a multiple of 16 bytes
     for r0 in range(q0, q1, tile_rows):
         rows = min(tile_rows, q1 - r0)
@@ -151,6 +156,13 @@ def pairwise_retrieval(features, normalize=False, return_generator=True, kblocks
     import sehip  # raises SehipError if the HIP library is missing -- no CPU fallback
 
     features, ind2id, owned = _as_feature_matrix(features)
+    if isinstance(features, np.ndarray) and features.dtype == np.float64:
+        # the reference computes in the caller's dtype (evaluate_retrieval.py:57-67): float64 features give float64 distances and
+        # their ranking.  The kernels are float32 (the dtype of every feature dump the reference writes,
+        # learn_image_embeddings.py:270-275): say so instead of casting silently.
+        warnings.warn("pairwise_retrieval: float64 features are ranked in float32 here (the reference would compute float64 distances); "
+                      "orders can differ where float32 rounding creates or breaks near-ties.  Feature dumps of the reference are float32.",
+                      RuntimeWarning, stacklevel=2)
     feats_h = np.ascontiguousarray(features, dtype=np.float32)
     sehip._lib.require_gpu()
     dev = torch.from_numpy(feats_h).cuda()

@@ -45,28 +45,39 @@ class ClsModel(nn.Module):
         self.head = head
         self._tap = None
         self.cls_base = None
+        # cls_base 'l2norm' / 'softmax' names the LAST layer of the reference's embedding model (learn_image_embeddings.py:127-133):
+        # its output is the first output itself, i.e. the default base -- nothing to tap.
         if cls_base is not None and str(cls_base) not in ('l2norm', 'softmax'):
             # reference: `embed_model.layers[int(cls_base)].output` / `embed_model.get_layer(cls_base).output`
             # (learn_image_embeddings.py:34-40).  Names are module names of the embedding model ('avg_pool' = the pooled backbone
             # features, 'embedding' = the dense layer in front of l2norm, dotted names for anything deeper); an integer indexes its
             # leaf modules in definition order (Keras numbers its own layer list: indices are not portable between the two).
             named = [(n, m) for n, m in embed_model.named_modules() if n]
+            no_such = '--cls_base {!r}: no such layer; the embedding model has {}'.format(cls_base, ', '.join(n for n, _ in named))
             try:
-                leaves = [(n, m) for n, m in named if not list(m.children())]
-                name, tap = leaves[int(cls_base)]
+                index = int(cls_base)
             except ValueError:
+                index = None
+            if index is not None:
+                leaves = [(n, m) for n, m in named if not list(m.children())]
+                if not -len(leaves) <= index < len(leaves):
+                    raise ValueError(no_such + ' ({} leaf layers)'.format(len(leaves)))
+                name, tap = leaves[index]
+            else:
                 found = dict(named)
                 if str(cls_base) not in found:
-                    raise ValueError('--cls_base {!r}: no such layer; the embedding model has {}'.format(cls_base, ', '.join(n for n, _ in named)))
+                    raise ValueError(no_such)
                 name, tap = str(cls_base), found[str(cls_base)]
+            # the tap's width must follow from the layer itself -- the caller's `width` describes the embedding OUTPUT, not an inner layer
             if isinstance(tap, nn.Linear):
                 width = tap.out_features
             elif isinstance(tap, (nn.BatchNorm1d, nn.BatchNorm2d)):
                 width = tap.num_features
             elif name == 'avg_pool' or name.endswith('.avg_pool'):
                 width = embed_model.num_features
-            elif width is None:
-                raise ValueError('--cls_base {!r}: cannot tell the width of that layer\'s output (dense, batch-norm and avg_pool layers are supported)'.format(cls_base))
+            else:
+                raise ValueError('--cls_base {!r} ({}): cannot tell the width of that layer\'s output (dense, batch-norm and avg_pool '
+                                 'layers are supported)'.format(cls_base, type(tap).__name__))
             self.cls_base = name
             tap.register_forward_hook(self._remember)
         if width is None:       # width of what the embedding model emits (resnet-32 / -110 without -fc: the pooled features)

@@ -25,7 +25,7 @@ EXPORTS = (
     "se_labelembed_aux_floats", "se_labelembed_loss_fwd", "se_labelembed_loss_bwd",
     "se_devise_aux_floats", "se_devise_loss_fwd", "se_devise_loss_bwd",
     "se_row_sqnorm", "se_normalize_rows", "se_pairwise_dist",
-    "se_rank_rows_workspace_bytes", "se_rank_rows", "se_rank_rows_check_workspace_bytes", "se_rank_rows_check",
+    "se_rank_rows_workspace_bytes", "se_rank_rows", "se_rank_rows_init_workspace_bytes", "se_rank_rows_init", "se_rank_rows_check_workspace_bytes", "se_rank_rows_check",
     "se_topk_rows", "se_topk_merge", "se_topk_merge_packed",
     "se_retrieve_topk_workspace_bytes", "se_retrieve_topk", "se_hierarchical_precision",
     "se_hprec_order_workspace_bytes", "se_hprec_curve_len", "se_hprec_reciprocal_curves",
@@ -101,6 +101,9 @@ def lib():
     L.se_rank_rows_workspace_bytes.argtypes = [c_i64, c_i64]
     L.se_rank_rows_workspace_bytes.restype = c_i64
     L.se_rank_rows.argtypes = [vp, c_i64, c_i64, c_i64, vp, c_int, c_i64, vp, c_i64, vp]
+    L.se_rank_rows_init_workspace_bytes.argtypes = []
+    L.se_rank_rows_init_workspace_bytes.restype = c_i64
+    L.se_rank_rows_init.argtypes = [vp, c_i64, vp]
     L.se_rank_rows_check_workspace_bytes.argtypes = []
     L.se_rank_rows_check_workspace_bytes.restype = c_i64
     L.se_rank_rows_check.argtypes = [vp, c_i64, c_i64, c_i64, vp, c_int, c_i64, vp, c_i64, ctypes.POINTER(c_i64), vp]

@@ -333,10 +333,49 @@ def _workspace(nbytes, device):
     return ws
 
 
+_rank_ready = set()
+
+
+def rank_rows_init(device=None):
+    """``se_rank_rows_init`` on ``device`` (default: current): capability probe + self-test of every hardware-ordered ranking kernel
+    variant; the one synchronising call of the ranking.  ``rank_rows`` calls it by itself before its first ranking on a device, so
+    that every later ``se_rank_rows`` is purely asynchronous (graph-capturable)."""
+    require_gpu()
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    with torch.cuda.device(key):
+        ws = torch.empty((int(lib().se_rank_rows_init_workspace_bytes()),), dtype=torch.uint8, device=dev)
+        check(lib().se_rank_rows_init(ptr(ws), ws.numel(), stream_ptr()), "se_rank_rows_init")
+    _rank_ready.add(key)
+
+
+def workspace_bytes(device=None):
+    """Bytes the per-device workspace cache currently holds."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    ws = _ws_cache.get(dev.index if dev.index is not None else torch.cuda.current_device())
+    return 0 if ws is None else int(ws.numel())
+
+
+def release_workspace(device=None):
+    """Drop the grow-only scratch buffer of ``device`` (default: every device): the long-row ranking grows it to ~3 GB, the fused
+    top-k to ~4 GB, and it is otherwise kept for the life of the process."""
+    if device is None:
+        _ws_cache.clear()
+    else:
+        dev = torch.device(device)
+        _ws_cache.pop(dev.index if dev.index is not None else torch.cuda.current_device(), None)
+
+
+def rank_rows_workspace_bytes(q, n):
+    return int(lib().se_rank_rows_workspace_bytes(int(q), int(n)))
+
+
 def rank_rows(pdist, idx64=False, out=None):
     """Canonical ``np.argsort(pdist, axis=-1)`` (evaluate_retrieval.py:67): (distance, index) ascending."""
     require_gpu(pdist, out)
     _f32_rows(pdist, "pdist")
+    if (pdist.device.index if pdist.device.index is not None else torch.cuda.current_device()) not in _rank_ready:
+        rank_rows_init(pdist.device)
     q, n = pdist.shape
     if out is None:
         out = empty_rows(q, n, torch.int64 if idx64 else torch.int32, pdist.device)

@@ -37,6 +37,7 @@ def gauss(n, d, seed=0):
 
 @pytest.mark.parametrize("d", [1, 5, 7, 8, 9, 63, 64, 100, 127, 128, 129, 200, 255, 256, 257, 555, 1000, 2048, 2500])
 def test_row_sqnorm_and_normalize_bit_exact(sehip, d):
+    """D < 256: one lane per row; 256 <= D <= 4096: one wave per row (leaves of NumPy's pairwise tree dealt to 8-lane groups)."""
     x = gauss(131, d, seed=d)
     sq = sehip.row_sqnorm(dev(x)).cpu().numpy()
     assert np.array_equal(sq, np.sum(x ** 2, axis=-1))          # NumPy itself
@@ -45,6 +46,26 @@ def test_row_sqnorm_and_normalize_bit_exact(sehip, d):
     ref = x.copy()
     ref /= np.linalg.norm(ref, axis=-1, keepdims=True)
     assert np.array_equal(xn, ref)
+
+
+@pytest.mark.parametrize("d", [260, 263, 300, 511, 1023, 1024, 1025, 1999, 3001, 4095, 4096, 4097, 5000])
+def test_row_norms_wave_per_row_kernel_shapes(sehip, d):
+    """The wave-per-row kernel on both sides of its range (256 ... 4096), odd widths (element loads instead of 16-byte ones),
+    leaf tails (D % 8 != 0), unaligned row pitches (a column slice of a wider matrix), more rows than resident waves, and rows whose
+    squares span 40 binades (the summation order is what decides the bits)."""
+    rng = np.random.default_rng(d)
+    for rows, ld in ((131, d), (37, d + 3), (9000 if d <= 1025 else 600, d + 4)):
+        wide = (rng.standard_normal((rows, ld)) * np.exp2(rng.integers(-20, 20, size=(rows, ld)))).astype(np.float32)
+        x = wide[:, :d]
+        xd = dev(wide)[:, :d]
+        assert xd.stride(0) == ld
+        sq = sehip.row_sqnorm(xd).cpu().numpy()
+        assert np.array_equal(sq, np.sum(np.ascontiguousarray(x) ** 2, axis=-1))
+        assert np.array_equal(sq, ro.canon_row_sqsum(np.ascontiguousarray(x)))
+        xn = sehip.normalize_rows_(xd).cpu().numpy()
+        ref = np.ascontiguousarray(x).copy()
+        ref /= np.linalg.norm(ref, axis=-1, keepdims=True)
+        assert np.array_equal(xn, ref)
 
 
 def test_normalize_zero_row_gives_nan_like_numpy(sehip):
@@ -296,6 +317,7 @@ def test_rank_order_guard_repairs_injected_violations_in_subprocess(q):
         "sys.path[:0] = %r\n"
         "import sehip\n"
         "from oracle import retrieval_oracle as ro\n"
+        "sehip.ops._rank_ready.add(0)\n"      # no se_rank_rows_init: the LAZY first-call guard of se_rank_rows is what is being tested
         "rng = np.random.default_rng(9)\n"
         "pd = rng.standard_normal((%d, 2500)).astype(np.float32)\n"
         "got = sehip.rank_rows(torch.from_numpy(pd).cuda()).cpu().numpy()\n"
@@ -313,6 +335,47 @@ def test_rank_order_guard_repairs_injected_violations_in_subprocess(q):
         env.pop("SE_RANK_CHECK")
         out = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
         assert out.returncode == 0 and "guard-ok" in out.stdout and "order guard" in out.stdout, out.stdout
+
+
+def test_rank_rows_init_self_test_and_graph_capture():
+    """se_rank_rows_init audits every hardware-ordered kernel variant on crafted tie-heavy rows (verdict lines under
+    SE_RANK_VERBOSE=1, all clean on MI355X); afterwards se_rank_rows is purely asynchronous: it can be captured into a HIP graph
+    (a synchronising call would fail the capture) and the replayed graph re-ranks new distances in place -- bit-equal to the oracle."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, ctypes, numpy as np, torch\n"
+        "sys.path[:0] = %r\n"
+        "import sehip\n"
+        "from sehip._lib import lib, ptr, check\n"
+        "from oracle import retrieval_oracle as ro\n"
+        "sehip.rank_rows_init()\n"
+        "rng = np.random.default_rng(11)\n"
+        "for n in (3000, 40000, 60000):\n"
+        "    a = rng.standard_normal((6, n)).astype(np.float32); a[1] = rng.integers(-2, 3, size=n)\n"
+        "    b = 100.0 + np.abs(rng.standard_normal((6, n))).astype(np.float32); b[2, ::4] = b[2, 0]\n"
+        "    pd = torch.from_numpy(a).cuda(); rk = torch.empty((6, n), dtype=torch.int32, device='cuda')\n"
+        "    ws = torch.empty((int(lib().se_rank_rows_workspace_bytes(6, n)),), dtype=torch.uint8, device='cuda')\n"
+        "    side = torch.cuda.Stream()\n"
+        "    side.wait_stream(torch.cuda.current_stream())\n"
+        "    g = torch.cuda.CUDAGraph()\n"
+        "    with torch.cuda.graph(g, stream=side):\n"
+        "        check(lib().se_rank_rows(ptr(pd), pd.stride(0), 6, n, ptr(rk), 0, rk.stride(0), ptr(ws), ws.numel(),\n"
+        "                                 ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), 'se_rank_rows under capture')\n"
+        "    g.replay(); torch.cuda.synchronize()\n"
+        "    assert np.array_equal(rk.cpu().numpy(), ro.canon_rank_rows(a)), n\n"
+        "    pd.copy_(torch.from_numpy(b)); g.replay(); torch.cuda.synchronize()\n"
+        "    assert np.array_equal(rk.cpu().numpy(), ro.canon_rank_rows(b)), n\n"
+        "print('init-ok')\n"
+    ) % ([PKG_DIR, ROOT_DIR],)
+    env = dict(os.environ, SE_RANK_VERBOSE="1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert out.returncode == 0 and "init-ok" in out.stdout, out.stdout[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("[se_rank_rows_init]")]
+    assert len(lines) >= 5 and all(": 0 of 4 rows" in ln for ln in lines), out.stdout[-3000:]
+    for what in ("short rows, plain", "short rows, group-peeling", "long rows, plain", "long rows, two-pass", "segment runs + merge"):
+        assert any(what in ln for ln in lines), (what, lines)
+    assert "order guard" not in out.stdout          # the lazy guard never ran: init had the verdict
 
 
 def long_rows(n, seed):
@@ -393,6 +456,7 @@ def test_rank_order_guard_behind_the_runs_path_in_subprocess():
         "sys.path[:0] = %r\n"
         "import sehip\n"
         "from oracle import retrieval_oracle as ro\n"
+        "sehip.ops._rank_ready.add(0)\n"      # no se_rank_rows_init: the lazy first-call guard is what is being tested
         "rng = np.random.default_rng(9)\n"
         "pd = rng.standard_normal((40, 60000)).astype(np.float32)\n"
         "got = sehip.rank_rows(torch.from_numpy(pd).cuda()).cpu().numpy()\n"

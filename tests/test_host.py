@@ -445,8 +445,23 @@ def test_cls_base_taps_named_or_indexed_layers():
     assert m.cls_base == 'avg_pool' and m(x)[1].shape == (4, 7)
     with pytest.raises(ValueError, match='no such layer'):
         lie.ClsModel(net, 7, cls_base='does_not_exist')
-    with pytest.raises(ValueError):                                           # a convolution's 4-d output cannot feed the dense classifier
-        lie.ClsModel(net, 7, cls_base='conv0')
+    with pytest.raises(ValueError, match='cannot tell the width'):            # a convolution's 4-d output cannot feed the dense classifier,
+        lie.ClsModel(net, 7, cls_base='conv0', width=10)                     # whatever width the caller knows for the embedding OUTPUT
+    with pytest.raises(ValueError, match='no such layer'):                    # an index past the last leaf: the same message, not IndexError
+        lie.ClsModel(net, 7, cls_base=str(len(leaves) + 5))
+    m = lie.ClsModel(net, 7, cls_base='l2norm', head='l2norm', width=10)      # the reference's last layer == the default base
+    assert m.cls_base is None
+
+
+def test_float64_features_are_not_cast_silently():
+    """The reference computes in the caller's dtype (evaluate_retrieval.py:57-67); the drop-in ranks in float32 and says so."""
+    import evaluate_retrieval as er
+    x = np.random.default_rng(0).standard_normal((8, 4))
+    with pytest.warns(RuntimeWarning, match='float64 features'):
+        try:
+            er.pairwise_retrieval(x, normalize=True)
+        except Exception:       # no GPU here: the call fails loudly AFTER the warning (no CPU fallback)
+            pass
 
 
 # ---------------------------------------------------------------- in-memory data path pinned to the reference's own classes

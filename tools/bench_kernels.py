@@ -27,7 +27,7 @@ def timeit(fn, reps):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["pdist", "rank", "loss", "topk", "fused", "hprec", "shard"])
+    ap.add_argument("what", choices=["pdist", "rank", "loss", "topk", "fused", "hprec", "shard", "rownorm"])
     ap.add_argument("--hp-mode", default="all", choices=["all", "whole", "sweep"], help="hprec: every configuration, or whole-list AHP + AP in class order only (profiling)")
     ap.add_argument("--n", type=int, default=50000)
     ap.add_argument("--q", type=int, default=None)
@@ -39,6 +39,16 @@ def main():
     q = args.q or n
     x = torch.from_numpy(np.random.default_rng(0).standard_normal((n, d)).astype(np.float32)).cuda()
     sehip.normalize_rows_(x)
+    if args.what == "rownorm":
+        # se_normalize_rows / se_row_sqnorm at the retrieval shapes: CIFAR (50k x 100: one lane per row) and one ILSVRC gallery
+        # shard (160,146 x 1000: one wave per row)
+        for rows, dd in ((50000, 100), (160146, 1000), (160146, 555), (40000, 4096)):
+            y = torch.from_numpy(np.random.default_rng(3).standard_normal((rows, dd)).astype(np.float32)).cuda()
+            med, mn = timeit(lambda: sehip.normalize_rows_(y), args.reps)
+            print("normalize_rows %d x %d: median %.3f ms (min %.3f)  %.2f TB/s (read + write)" % (rows, dd, med, mn, 8.0 * rows * dd / med / 1e9))
+            med, mn = timeit(lambda: sehip.row_sqnorm(y), args.reps)
+            print("row_sqnorm     %d x %d: median %.3f ms (min %.3f)  %.2f TB/s (read)" % (rows, dd, med, mn, 4.0 * rows * dd / med / 1e9))
+        return
     if args.what == "pdist":
         out = torch.empty((q, n), dtype=torch.float32, device="cuda")
         y = x.clone()
@@ -107,8 +117,12 @@ def main():
         qq = torch.from_numpy(np.random.default_rng(2).standard_normal((Q, D)).astype(np.float32)).cuda()
         sehip.normalize_rows_(g); sehip.normalize_rows_(qq)
         med, mn = timeit(lambda: sehip.retrieve_topk(qq, g, K, metric=sehip.METRIC_COSINE, col_offset=NS), max(2, args.reps // 2))
-        print("shard retrieve_topk q=%d n=%d d=%d k=%d: median %.1f ms (min %.1f)  %.1f Mpairs/s, %.1f TFLOP/s (fp32 MFMA)" %
+        print("shard retrieve_topk (one chain) q=%d n=%d d=%d k=%d: median %.1f ms (min %.1f)  %.1f Mpairs/s, %.1f TFLOP/s useful" %
               (Q, NS, D, K, med, mn, Q * NS / med / 1e3, 2.0 * Q * NS * D / med / 1e9))
+        kb = [448, 276, 276]                  # evaluate_retrieval.host_blas_kblocks(1000): the arithmetic that reproduces np.dot at this depth
+        med, mn = timeit(lambda: sehip.retrieve_topk(qq, g, K, metric=sehip.METRIC_COSINE, col_offset=NS, kblocks=kb), max(2, args.reps // 2))
+        print("shard retrieve_topk (K-blocks %s) q=%d n=%d d=%d k=%d: median %.1f ms (min %.1f)  %.1f Mpairs/s, %.1f TFLOP/s useful" %
+              (kb, Q, NS, D, K, med, mn, Q * NS / med / 1e3, 2.0 * Q * NS * D / med / 1e9))
         od, oi = sehip.retrieve_topk(qq, g, K, metric=sehip.METRIC_COSINE)
         dd = torch.stack([od + 1e-3 * r for r in range(8)]); ii = torch.stack([oi + NS * r for r in range(8)])
         med, mn = timeit(lambda: sehip.topk_merge(dd, ii), args.reps)

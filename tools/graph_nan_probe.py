@@ -1,4 +1,6 @@
-"""Why is the replayed bf16 gradient NaN in the Trainer when a plain torch capture of the same network replays fine?"""
+"""Why is the replayed bf16 gradient NaN in the Trainer when a plain torch capture of the same network replays fine?
+Round 4: the flat parameter buffer now aligns every slice to 256 bytes (engine.FlatState); SE_FLAT_ALIGN=1 restores the packed layout.
+    python tools/graph_nan_probe.py            # every configuration with aligned, then with packed slices"""
 import os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -19,7 +21,8 @@ class TorchLoss(object):
         self.last_normalized = xh.detach()
         return 1.0 - (xh * self.e[y]).sum(-1)
 
-def make(loss_kind, metric_on, steal, fmt):
+def make(loss_kind, metric_on, steal, fmt, align):
+    os.environ["SE_FLAT_ALIGN"] = str(align)
     torch.manual_seed(0)
     m = utils.build_network(100, "resnet-110-fc", input_channels=3).to(dev)
     loss = utils.CosineEmbeddingLoss(emb) if loss_kind == "hip" else TorchLoss(emb)
@@ -32,16 +35,18 @@ def make(loss_kind, metric_on, steal, fmt):
 gen = SyntheticGenerator(100, 32, 3, 128 * 8, 128)
 seq = gen.train_sequence(128, shuffle=False)
 X, y = seq[0]
-for loss_kind, metric_on, steal, fmt in (("hip", True, True, torch.channels_last), ("torch", False, True, torch.channels_last),
-                                         ("torch", False, False, torch.channels_last), ("hip", True, False, torch.channels_last),
-                                         ("torch", False, True, torch.contiguous_format)):
-    t = make(loss_kind, metric_on, steal, fmt)
-    ok = t.enable_graphs(X.contiguous(memory_format=fmt), y, validate=3)
-    info = getattr(t, "graph_validation", None)
-    print("loss=%s metric=%s steal=%s fmt=%s -> graphs=%s %s" % (loss_kind, metric_on, steal, "nhwc" if fmt == torch.channels_last else "nchw", ok, info), flush=True)
-    if not ok:
-        g = t.flat.flat_g
-        bad = ~torch.isfinite(g)
-        names = [n for n, p in t.model.named_parameters() if p.requires_grad]
-        hit = [names[i] for i, (off, n) in enumerate(t.flat.offsets) if bool(bad[off:off + n].any())]
-        print("   non-finite in %d of %d parameters, first: %s" % (len(hit), len(names), hit[:4]), flush=True)
+for align in (64, 1):
+  for loss_kind, metric_on, steal, fmt in (("hip", True, True, torch.channels_last), ("torch", False, True, torch.channels_last),
+                                           ("torch", False, False, torch.channels_last), ("hip", True, False, torch.channels_last),
+                                           ("torch", False, True, torch.contiguous_format)):
+    for rep in range(2):
+        t = make(loss_kind, metric_on, steal, fmt, align)
+        ok = t.enable_graphs(X.contiguous(memory_format=fmt), y, validate=3, allow_autocast=True)
+        info = getattr(t, "graph_validation", None)
+        print("align=%d loss=%s metric=%s steal=%s fmt=%s rep=%d -> graphs=%s %s" % (align, loss_kind, metric_on, steal, "nhwc" if fmt == torch.channels_last else "nchw", rep, ok, info), flush=True)
+        if not ok:
+            g = t.flat.flat_g
+            bad = ~torch.isfinite(g)
+            names = [n for n, p in t.model.named_parameters() if p.requires_grad]
+            hit = [names[i] for i, (off, n) in enumerate(t.flat.offsets) if bool(bad[off:off + n].any())]
+            print("   non-finite in %d of %d parameters, first: %s" % (len(hit), len(names), hit[:4]), flush=True)
