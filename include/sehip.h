@@ -282,14 +282,19 @@ int se_topk_merge_packed(const void *packed, int parts, int64_t q, int k, float 
  * Same arithmetic as se_pairwise_dist (sequential fp32 FMA chain, optional K-block list `kblocks` -- HOST pointer, may be
  * NULL -- for d > 448, evaluate_retrieval.py:59 on OpenBLAS) and the same canonical order as se_rank_rows: out_i[i, :] ==
  * the first k entries of se_rank_rows(se_pairwise_dist(queries, gallery))[i], out_d the distances, bit for bit.
- * Galleries of >= 16384 rows: a sample pass over <= 4096 gallery rows gives every query a distance threshold, the main
- * pass appends the few values below it to per-query candidate lists from the MFMA tile epilogue, a per-query kernel
- * sorts them; queries whose list missed [k, capacity] are redone exactly.  Smaller galleries go
- * through a [rows, n] distance slab in the workspace.
+ * Galleries of >= 16384 rows (k <= 512): the Q x N distances are first BOUNDED, not computed -- a pass on the bf16 matrix cores over
+ * bf16-rounded copies of the operands gives d~ with |d~ - d| <= eps(query) (a rigorous bound from the operands' actual rounding
+ * residuals).  A sample of <= 4096 gallery rows gives every query a threshold, the full pass appends the few
+ * items with d~ <= threshold to per-query candidate lists, and a per-query kernel recomputes, with the exact fp32 chain, the items
+ * within 2 eps of the list's k-th smallest d~, sorts them and accepts the first k once it has proved that nothing outside that set
+ * can precede them; queries it cannot prove (short / overflowing lists, NaN rows, tie groups of thousands) are redone exactly over the
+ * whole gallery.  The output does not depend on what the bf16 pass computed.  Smaller galleries go through a [rows, n] distance slab
+ * in the workspace; k > 512 through the fp32 form of the same passes.
  *   metric: SE_METRIC_COSINE or SE_METRIC_EUCLID (then sqq [q], sqg [n] = se_row_sqnorm of the operands).
- *   workspace: se_retrieve_topk_workspace_bytes(q, n, ldg, k) bytes, 256-byte aligned.
+ *   workspace: se_retrieve_topk_workspace_bytes(q, n, d, ldg, k) bytes, 256-byte aligned (candidate lists, bf16 operand copies:
+ *   2 bytes x (n + q) x d rounded up to a multiple of 64, scratch rows of the exact fallback).
  */
-int64_t se_retrieve_topk_workspace_bytes(int64_t q, int64_t n, int64_t ldg, int k);
+int64_t se_retrieve_topk_workspace_bytes(int64_t q, int64_t n, int64_t d, int64_t ldg, int k);
 int se_retrieve_topk(const float *queries, int64_t ldq, const float *gallery, int64_t ldg,
                      const float *sqq, const float *sqg, int64_t q, int64_t n, int64_t d,
                      int metric, const int32_t *kblocks, int nkb, int64_t col_offset, int k,

@@ -1595,7 +1595,7 @@ __global__ void rank_selftest_fill_kernel(float *pd, int64_t ld, int rows, int n
 extern "C" int64_t se_rank_rows_init_workspace_bytes(void)
 {
     const int64_t mat = (int64_t)RI_ROWS * (RI_N_SEG + 8) * 4;
-    return 4096 + 4 * (RC_CAP + 2) + 2 * mat + rank_runs_bytes(RI_ROWS, RI_N_SEG) + 1024;
+    return 4096 + 4 * (RC_CAP + 2) + 2 * mat + (rank_runs_ok(RI_N_SEG) ? rank_runs_bytes(RI_ROWS, RI_N_SEG) : 0) + 1024;
 }
 
 extern "C" int se_rank_rows_init(void *workspace, int64_t workspace_bytes, se_stream_t stream)

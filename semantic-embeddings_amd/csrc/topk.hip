@@ -11,6 +11,9 @@
 #include "se_common.h"
 #include <math.h>
 #include <stdlib.h>
+#include <string.h>
+#include <mutex>
+#include <vector>
 
 namespace se {
 
@@ -484,7 +487,7 @@ struct FusedPlan {
     int cap;        // candidate list capacity per query
 };
 
-static FusedPlan fused_plan(int64_t n, int64_t ldg, int k)
+static FusedPlan fused_plan_compute(int64_t n, int64_t ldg, int k)
 {
     FusedPlan p = {false, 0, 0, 0, 0, 0};
     int force = -1;                                                          // -DSE_TUNING build: SE_TOPK_FUSED=0 / 1 pins the path
@@ -528,6 +531,27 @@ static FusedPlan fused_plan(int64_t n, int64_t ldg, int k)
     if (const char *e = tuning_env("SE_TOPK_CAP")) cap = atoi(e);
     if (cap > TK_CAP || j < 1 || j > G) return p;
     p = {true, S, step, G, j, cap};
+    return p;
+}
+
+// The plan depends on (n, ldg, k) only; its binomial-tail loops cost ~0.8 ms of host time and a Python-level call used to run them
+// three times before the first kernel was enqueued.  Product build: a small table under a mutex (the tuning build re-derives it every
+// time -- its environment switches may change between calls).
+static FusedPlan fused_plan(int64_t n, int64_t ldg, int k)
+{
+    if (kTuning) return fused_plan_compute(n, ldg, k);
+    struct Entry { int64_t n, ldg; int k; FusedPlan p; };
+    static std::mutex mu;
+    static std::vector<Entry> *table = new std::vector<Entry>();      // guarded by mu (never destroyed: no static-destruction order to get wrong)
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        for (const Entry &e : *table)
+            if (e.n == n && e.ldg == ldg && e.k == k) return e.p;
+    }
+    const FusedPlan p = fused_plan_compute(n, ldg, k);
+    std::lock_guard<std::mutex> lock(mu);
+    if (table->size() >= 64) table->erase(table->begin());
+    table->push_back({n, ldg, k, p});
     return p;
 }
 
@@ -797,6 +821,241 @@ __global__ __launch_bounds__(TK_THREADS) void topk_fallback_kernel(const float *
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// bf16 pre-filter path of se_retrieve_topk (prefilter.hip holds the tile kernel).  Notation: d = the canonical fp32 distance (what
+// the caller gets), d~ = the distance the bf16 matrix-core pass computes, eps(q) >= |d~ - d| for every gallery item (pf_thr_kernel).
+//   1. sample pass (bf16) -> tau~(q) = j-th smallest group minimum of d~;  thr(q) = tau~ + 2 eps: every item with d <= tau~ + eps --
+//      a superset of what the exact-arithmetic threshold of the same sample would admit -- has d~ <= thr.
+//   2. filter pass (bf16): items with d~ <= thr(q) (or d~ NaN: irregular rows) -> candidate list (d~, gallery row).
+//   3. pf_refine_kernel, one wave per query:
+//        kth~ = k-th smallest d~ of the list;  B = min(kth~ + 2 eps, thr);  R = {d~ <= B} + {d~ NaN}      (|R| ~ k + a 2 eps window)
+//        exact fp32 FMA chain (K-blocks included) for every item of R, sort on (key, index), d_k = k-th smallest exact distance
+//        accept iff d_k <= B - eps: an item outside R has d~ > B, hence d > B - eps >= d_k -- it is not among the k nearest, ties
+//        included.  (With B = kth~ + 2 eps this always holds: the k items with d~ <= kth~ have d <= kth~ + eps.)
+//      Everything else -- short / overflowing lists, |R| > RF_MAX, B cut by thr -- is flagged and redone by topk_fallback_kernel.
+// The output is the head of the canonical ranking, bit for bit, whatever the filter computed: it only decides where to look.
+// ------------------------------------------------------------------------------------------------
+constexpr int RF_MAX = 1024;            // exact recomputations per query the refinement takes
+constexpr int RF_WAVES = 4;
+constexpr int PF_K_MAX = RF_MAX / 2;
+
+// thr / eps per query from the group minima of the sample pass.  hq, rq: norm of the query's bf16 image / of its rounding residual
+// (upper bounds, NaN for irregular rows); gctl[0..1]: float bits of the maxima of the same two norms over the gallery.
+//   |a.b - a~.b~| = |a~.rb + ra.b~ + ra.rb| <= hq RG + rq HG + rq RG                      (Cauchy-Schwarz on the ACTUAL residuals)
+//   matrix-core accumulation: each v_mfma_f32_32x32x16_bf16 is assumed to return C + sum of its 16 products with an absolute error
+//     <= 2^-18 (|C| + sum |products|) -- 17 addends aligned to the largest and truncated to 24 bits would give 17 * 2^-23; IEEE
+//     rounding of the exact sum 2^-24.  kp / 16 instructions, |C| and the products bounded by hq HG.     [assumption A1, tested on the GPU]
+//   the canonical chain itself: |chain - a.b| <= (d + nkb + 2) 2^-24 sum |a_k b_k| <= ... (hq + rq)(HG + RG)
+//   denormal bf16 inputs / fp32 outputs flushed by the matrix core: <= kp 2^-126 (hq + HG + 1)
+//   Euclidean epilogue fl(fl(sa + sb) - 2 v): 2 eps_v + 2^-21 ((hq + rq) + (HG + RG))^2
+__global__ __launch_bounds__(256) void pf_thr_kernel(const float *__restrict__ gm, int64_t gm_ld, int64_t Q, int G, int j, const float *__restrict__ qn,
+                                                     const float *__restrict__ qr, const unsigned *__restrict__ gctl, int metric, int d, int kp,
+                                                     int nkb, float *__restrict__ thr, float *__restrict__ eps)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (q >= Q) return;
+    uint32_t v[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int e = lane * 4 + r;
+        v[r] = e < G ? canon_key(gm[q * gm_ld + e]) : 0xFFFFFFFFu;
+    }
+    wave_bitonic_sort<uint32_t, 4>(v, lane);
+    const int want = j - 1;
+    if (lane == (want >> 2)) {
+        const uint32_t key = (want & 3) == 0 ? v[0] : ((want & 3) == 1 ? v[1] : ((want & 3) == 2 ? v[2] : v[3]));
+        const float tau = key == 0xFFFFFFFFu ? __builtin_nanf("") : key_to_float(key);
+        const float hq = qn[q], rq = qr[q], HG = __uint_as_float(gctl[0]), RG = __uint_as_float(gctl[1]);
+        const float e_round = hq * RG + rq * HG + rq * RG;
+        const float e_acc = (float)(kp / 16) * 3.8147e-6f * 1.01f * (hq * HG);
+        const float e_chain = (float)(d + nkb + 2) * 5.9605e-8f * 1.01f * ((hq + rq) * (HG + RG));
+        const float e_flush = (float)kp * 1.1755e-38f * (hq + HG + 1.0f);
+        float e = (e_round + e_acc + e_chain + e_flush) * 1.01f;
+        if (metric == SE_METRIC_EUCLID) {
+            const float s = (hq + rq) + (HG + RG);
+            e = (2.0f * e + 4.7684e-7f * 1.05f * s * s) * 1.01f;
+        }
+        eps[q] = e;                           // NaN for an irregular query: nothing passes, the query is redone exactly
+        thr[q] = tau + 2.05f * e;
+    }
+}
+
+// exact canonical dot product of gallery row `g` with the (wave-uniform) query row: fmaf chain over k ascending, restarted per K-block,
+// block sums added in order -- what the fp32 MFMA tiles and topk_fallback_kernel compute, bit for bit
+template <bool VEC>
+__device__ __forceinline__ float rf_chain(const float *__restrict__ g, const float *__restrict__ qv, const KBlocks &kbs)
+{
+    float tot = 0.f;
+    int beg = 0;
+    for (int kb = 0; kb < kbs.n; kb++) {
+        const int end = beg + kbs.len[kb];
+        float acc = 0.f;
+        int kk = beg;
+        if (VEC) {
+            for (; kk < end && (kk & 3); kk++) acc = __builtin_fmaf(g[kk], qv[kk], acc);
+            for (; kk + 32 <= end; kk += 32) {
+                float4 x[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) x[i] = *(const float4 *)(g + kk + 4 * i);
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    acc = __builtin_fmaf(x[i].x, qv[kk + 4 * i], acc);
+                    acc = __builtin_fmaf(x[i].y, qv[kk + 4 * i + 1], acc);
+                    acc = __builtin_fmaf(x[i].z, qv[kk + 4 * i + 2], acc);
+                    acc = __builtin_fmaf(x[i].w, qv[kk + 4 * i + 3], acc);
+                }
+            }
+            for (; kk + 4 <= end; kk += 4) {
+                const float4 x = *(const float4 *)(g + kk);
+                acc = __builtin_fmaf(x.x, qv[kk], acc);
+                acc = __builtin_fmaf(x.y, qv[kk + 1], acc);
+                acc = __builtin_fmaf(x.z, qv[kk + 2], acc);
+                acc = __builtin_fmaf(x.w, qv[kk + 3], acc);
+            }
+        }
+        for (; kk < end; kk++) acc = __builtin_fmaf(g[kk], qv[kk], acc);
+        tot = kb == 0 ? acc : tot + acc;
+        beg = end;
+    }
+    return tot;
+}
+
+template <int METRIC, bool VEC>
+__global__ __launch_bounds__(RF_WAVES * 64) void pf_refine_kernel(const uint2 *__restrict__ lists, const unsigned *__restrict__ rowcnt, int64_t cap, int64_t Q,
+                                                                  const float *__restrict__ thr, const float *__restrict__ eps,
+                                                                  const float *__restrict__ queries, int64_t ldq, const float *__restrict__ gallery,
+                                                                  int64_t ldg, const float *__restrict__ sqq, const float *__restrict__ sqg,
+                                                                  KBlocks kbs, int64_t col_offset, int k, float *__restrict__ out_d,
+                                                                  int32_t *__restrict__ out_i, unsigned *__restrict__ nflag, unsigned *__restrict__ stats)
+{
+    __shared__ uint32_t hist_all[RF_WAVES][256];
+    __shared__ uint32_t sel_all[RF_WAVES][RF_MAX];
+    __shared__ uint64_t comp_all[RF_WAVES][RF_MAX];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t *hist = hist_all[wave], *sel = sel_all[wave];
+    uint64_t *comp = comp_all[wave];
+    for (int64_t row = (int64_t)blockIdx.x * RF_WAVES + wave; row < Q; row += (int64_t)gridDim.x * RF_WAVES) {
+        const int64_t urow = __builtin_amdgcn_readfirstlane((int)row);          // (Q < 2^31: the launcher checks)
+        const unsigned total = rowcnt[urow];
+        bool ok = total >= (unsigned)k && total <= (unsigned)cap;
+        const uint2 *lst = lists + urow * cap;
+        uint32_t m = 0;
+        float B = 0.f;
+        const float e_q = eps[urow], thr_q = thr[urow];
+        if (ok) {
+            // ---- k-th smallest d~ key (NaN keys = 0xFFFFFFFF sort last): 4 passes of 8 bits over the list ----
+            uint32_t prefix = 0, pmask = 0, remaining = (uint32_t)k;
+#pragma unroll 1
+            for (int shift = 24; shift >= 0; shift -= 8) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) hist[lane * 4 + i] = 0;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                for (unsigned e = lane; e < total; e += 64) {
+                    const uint32_t key = canon_key(__uint_as_float(lst[e].x));
+                    if ((key & pmask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                uint32_t c[4], local = 0;
+#pragma unroll
+                for (int i = 0; i < 4; i++) { c[i] = hist[lane * 4 + i]; local += c[i]; }
+                uint32_t incl = local;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const uint32_t t = __shfl_up(incl, off, 64);
+                    if (lane >= off) incl += t;
+                }
+                uint32_t run = incl - local, digit = 0, rem = 0;
+                const bool mine = remaining > run && remaining <= incl;             // exactly one lane
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const bool hit = mine && remaining > run && remaining <= run + c[i];
+                    digit = hit ? (uint32_t)(lane * 4 + i) : digit;
+                    rem = hit ? remaining - run : rem;
+                    run += c[i];
+                }
+                const int src = __ffsll((long long)__ballot(mine)) - 1;
+                digit = (uint32_t)__shfl((int)digit, src, 64);
+                remaining = (uint32_t)__shfl((int)rem, src, 64);
+                prefix |= digit << shift;
+                pmask |= 255u << shift;
+            }
+            const uint32_t kth = prefix;
+            ok = kth != 0xFFFFFFFFu && e_q == e_q;                                  // fewer than k finite d~, or an irregular query
+            if (ok) {
+                const float b1 = key_to_float(kth) + 2.05f * e_q;
+                B = b1 < thr_q ? b1 : thr_q;
+                const uint32_t bkey = canon_key(B);
+                // ---- R: entries with d~ <= B, plus every NaN d~ ----
+                for (unsigned e0 = 0; e0 < total; e0 += 64) {
+                    const unsigned e = e0 + lane;
+                    const uint2 c = lst[e < total ? e : 0];
+                    const uint32_t key = canon_key(__uint_as_float(c.x));
+                    const bool take = e < total && (key <= bkey || key == 0xFFFFFFFFu);
+                    const uint64_t bm = __ballot(take);
+                    const uint32_t pos = m + __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
+                    if (take && pos < (uint32_t)RF_MAX) sel[pos] = c.y;
+                    m += (uint32_t)__popcll(bm);
+                }
+                ok = m <= (uint32_t)RF_MAX;
+            }
+        }
+        if (ok) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            // ---- exact distances of R: one lane per candidate, the canonical fmaf chain over its gallery row ----
+            const float *qv = queries + urow * ldq;
+            const float sq_q = METRIC == SE_METRIC_EUCLID ? sqq[urow] : 0.f;
+            for (uint32_t e0 = 0; e0 < m; e0 += 64) {
+                const uint32_t e = e0 + lane;
+                const uint32_t gi = sel[e < m ? e : m - 1];
+                const float tot = rf_chain<VEC>(gallery + (int64_t)gi * ldg, qv, kbs);
+                float v;
+                if (METRIC == SE_METRIC_COSINE) v = -tot;
+                else v = (sqg[gi] + sq_q) - 2.0f * tot;
+                if (e < m) comp[e] = ((uint64_t)canon_key(v) << 32) | gi;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            // ---- sort R on (key, index); accept iff the k-th exact distance is <= B - eps ----
+            uint32_t kkey = 0;
+#define RF_SORT_OUT(P2)                                                                        \
+    {                                                                                          \
+        uint64_t sv[P2];                                                                       \
+        _Pragma("unroll") for (int r = 0; r < P2; r++) {                                       \
+            const int e = lane * P2 + r;                                                       \
+            sv[r] = e < (int)m ? comp[e] : ~0ull;                                              \
+        }                                                                                      \
+        wave_bitonic_sort<uint64_t, P2>(sv, lane);                                             \
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");                                 \
+        _Pragma("unroll") for (int r = 0; r < P2; r++) {                                       \
+            const int e = lane * P2 + r;                                                       \
+            if (e < k) comp[e] = sv[r];                                                        \
+        }                                                                                      \
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");                                 \
+    }
+            if (m <= 64) RF_SORT_OUT(1)
+            else if (m <= 128) RF_SORT_OUT(2)
+            else if (m <= 256) RF_SORT_OUT(4)
+            else if (m <= 512) RF_SORT_OUT(8)
+            else RF_SORT_OUT(16)
+#undef RF_SORT_OUT
+            kkey = (uint32_t)(comp[k - 1] >> 32);
+            const float dk = kkey == 0xFFFFFFFFu ? __builtin_nanf("") : key_to_float(kkey);
+            ok = dk <= B - 1.01f * e_q;                     // false for NaN
+            if (ok) {
+                for (int r = lane; r < k; r += 64) {
+                    const uint64_t c = comp[r];
+                    out_d[urow * k + r] = key_to_float((uint32_t)(c >> 32));
+                    out_i[urow * k + r] = (int32_t)(col_offset + (int64_t)(uint32_t)c);
+                }
+                if (stats && lane == 0) { atomicAdd(&stats[0], m); atomicAdd(&stats[1], total); }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
+        if (!ok && lane == 0) { out_i[urow * k] = TK_REDO; atomicAdd(&nflag[1], 1u); }
+    }
+}
+
 }  // namespace se
 
 using namespace se;
@@ -816,11 +1075,25 @@ static int64_t topk_qtile(int64_t q, int64_t n)
 // fused path: query rows per pass (candidate lists + group minima of <= 4 GiB) and the workspace layout
 struct FusedLayout {
     int64_t qt, off_tau, off_cnt, off_gm, off_lists, off_scratch, total;
+    // bf16 pre-filter path only
+    int64_t cap, off_eps, off_ctl, off_gimg, off_gnrm, off_gres, off_qimg, off_qnrm, off_qres;
+    int kp;
 };
-static FusedLayout fused_layout(int64_t q, int64_t n, const FusedPlan &p)
+static bool prefilter_wanted(const FusedPlan &p, int k)
 {
-    FusedLayout L;
-    const int64_t per_row = (int64_t)p.cap * 8 + (int64_t)p.G * 4 + 8;
+    if (!p.ok || k > PF_K_MAX) return false;
+    if (const char *e = tuning_env("SE_TOPK_PREFILTER")) return atoi(e) != 0;      // -DSE_TUNING build: 0 pins the fp32 fused passes
+    return true;
+}
+static FusedLayout fused_layout(int64_t q, int64_t n, int64_t d, const FusedPlan &p, bool pf)
+{
+    FusedLayout L = {};
+    L.cap = p.cap;
+    if (pf) {   // the bf16 thresholds admit a window of 4 eps more than the exact ones the plan was made for
+        L.cap = align256((int64_t)p.cap * 3 / 2);
+        if (const char *e = tuning_env("SE_TOPK_CAP")) L.cap = atoi(e);
+    }
+    const int64_t per_row = L.cap * 8 + (int64_t)p.G * 4 + 16;
     int64_t qt = ((int64_t)4 << 30) / per_row / 128 * 128;
     if (qt < 128) qt = 128;
     if (qt > q) qt = q;
@@ -829,17 +1102,104 @@ static FusedLayout fused_layout(int64_t q, int64_t n, const FusedPlan &p)
     L.off_cnt = align256(qt * 4);
     L.off_gm = L.off_cnt + align256(qt * 4 + 16);       // [qt] candidate counts + 4 control words (flagged-query counters)
     L.off_lists = L.off_gm + align256(qt * p.G * 4);
-    L.off_scratch = L.off_lists + align256(qt * p.cap * 8);
+    L.off_scratch = L.off_lists + align256(qt * L.cap * 8);
     L.total = L.off_scratch + align256((int64_t)FB_GRID * n * 4);
+    if (pf) {
+        L.kp = pf_padded_dim(d);
+        L.off_eps = L.total;                                   L.total += align256(qt * 4);
+        L.off_ctl = L.total;                                   L.total += 256;
+        L.off_gnrm = L.total;                                  L.total += align256(n * 4);
+        L.off_gres = L.total;                                  L.total += align256(n * 4);
+        L.off_qnrm = L.total;                                  L.total += align256(qt * 4);
+        L.off_qres = L.total;                                  L.total += align256(qt * 4);
+        L.off_gimg = L.total;                                  L.total += align256(n * (int64_t)L.kp * 2);
+        L.off_qimg = L.total;                                  L.total += align256(qt * (int64_t)L.kp * 2);
+    }
     return L;
 }
 
-extern "C" int64_t se_retrieve_topk_workspace_bytes(int64_t q, int64_t n, int64_t ldg, int k)
+extern "C" int64_t se_retrieve_topk_workspace_bytes(int64_t q, int64_t n, int64_t d, int64_t ldg, int k)
 {
-    if (q <= 0 || n <= 0) return 0;
+    if (q <= 0 || n <= 0 || d <= 0) return 0;
     const FusedPlan p = fused_plan(n, ldg, k);
-    if (p.ok) return fused_layout(q, n, p).total;
+    if (p.ok) return fused_layout(q, n, d, p, prefilter_wanted(p, k)).total;
     return topk_qtile(q, n) * ((n + 3) / 4 * 4) * 4;          // slab rows on a 16-byte pitch (16-byte row stores of the distance kernel)
+}
+
+// the bf16 pre-filter path of one query tile (see the block comment above pf_thr_kernel)
+static int retrieve_topk_prefilter(const float *queries, int64_t ldq, const float *gallery, int64_t ldg, const float *sqq, const float *sqg,
+                                   int64_t q, int64_t n, int64_t d, int metric, const KBlocks &kbs, int64_t col_offset, int k, float *out_d,
+                                   int32_t *out_i, char *ws, const FusedPlan &p, const FusedLayout &L, hipStream_t s)
+{
+    float *thr = (float *)(ws + L.off_tau), *eps = (float *)(ws + L.off_eps);
+    unsigned *rowcnt = (unsigned *)(ws + L.off_cnt), *ctl = (unsigned *)(ws + L.off_ctl);
+    float *gm = (float *)(ws + L.off_gm);
+    uint2 *lists = (uint2 *)(ws + L.off_lists);
+    float *scratch = (float *)(ws + L.off_scratch);
+    uint16_t *gimg = (uint16_t *)(ws + L.off_gimg), *qimg = (uint16_t *)(ws + L.off_qimg);
+    float *gnrm = (float *)(ws + L.off_gnrm), *gres = (float *)(ws + L.off_gres), *qnrm = (float *)(ws + L.off_qnrm), *qres = (float *)(ws + L.off_qres);
+    const int kp = L.kp;
+    const int P = next_pow2(k);
+    const size_t lds_sel = (size_t)P * 8 + (TK_NB + TK_WAVES + 1 + 4) * sizeof(uint32_t);
+    const bool vec = (ldg % 4 == 0) && ((((uintptr_t)gallery) & 15) == 0);
+    // ---- gallery image (once per call) ----
+    SE_HIP_CHECK(hipMemsetAsync(ctl, 0, 256, s));
+    if (const int rc = pf_convert(gallery, ldg, n, d, gimg, gnrm, gres, ctl, s)) return rc;
+    for (int64_t q0 = 0; q0 < q; q0 += L.qt) {
+        const int64_t rows = (q - q0 < L.qt) ? (q - q0) : L.qt;
+        const float *qs = queries + q0 * ldq;
+        const float *sq = sqq ? sqq + q0 : nullptr;
+        // all-pairs call: every item is query and gallery item -- one image, upper-triangle walk, both orientations filtered
+        const bool sym = (qs == gallery) && (ldq == ldg) && (rows == n) && (metric != SE_METRIC_EUCLID || sq == sqg) && n > 128 &&
+                         !tuning_env("SE_TOPK_NOSYM");
+        const uint16_t *qi = gimg;
+        const float *qn = gnrm, *qr = gres;
+        if (!sym) {
+            if (const int rc = pf_convert(qs, ldq, rows, d, qimg, qnrm, qres, ctl + 4, s)) return rc;
+            qi = qimg; qn = qnrm; qr = qres;
+        }
+        unsigned *nflag = rowcnt + rows;                               // [1] queries handed to the exact kernel; [2..3] statistics (tuning)
+        SE_HIP_CHECK(hipMemsetAsync(rowcnt, 0, (size_t)rows * 4 + 16, s));
+        PfPassArgs pa = {gm, p.G, thr, rowcnt, lists, L.cap, p.step, nullptr, 0};
+        int rc = pf_pass(PF_EPI_GROUPMIN, false, metric, gimg, p.step * (int64_t)kp, qi, kp, sqg, sq, p.S, rows, kp, pa, s);
+        if (rc != SE_OK) return rc;
+        hipLaunchKernelGGL(pf_thr_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, gm, (int64_t)p.G, rows, p.G, p.j, qn, qr, ctl, metric, (int)d, kp,
+                           kbs.n, thr, eps);
+        SE_LAUNCH_CHECK();
+        pa.sqa_stride = 1;
+        rc = pf_pass(PF_EPI_FILTER, sym, metric, gimg, kp, qi, kp, sqg, sq, n, rows, kp, pa, s);
+        if (rc != SE_OK) return rc;
+        const bool verbose = kTuning && tuning_env("SE_TOPK_VERBOSE");
+        const int64_t rgrid = (rows + RF_WAVES - 1) / RF_WAVES < 8192 ? (rows + RF_WAVES - 1) / RF_WAVES : 8192;
+#define SE_RF_LAUNCH(M, V) hipLaunchKernelGGL((pf_refine_kernel<M, V>), dim3((unsigned)rgrid), dim3(RF_WAVES * 64), 0, s, lists, rowcnt, L.cap, rows, thr, eps, qs, ldq, \
+                                              gallery, ldg, sq, sqg, kbs, col_offset, k, out_d + q0 * k, out_i + q0 * k, nflag, verbose ? nflag + 2 : nullptr)
+        if (metric == SE_METRIC_COSINE) { if (vec) SE_RF_LAUNCH(SE_METRIC_COSINE, true); else SE_RF_LAUNCH(SE_METRIC_COSINE, false); }
+        else { if (vec) SE_RF_LAUNCH(SE_METRIC_EUCLID, true); else SE_RF_LAUNCH(SE_METRIC_EUCLID, false); }
+#undef SE_RF_LAUNCH
+        SE_LAUNCH_CHECK();
+        if (verbose) {   // -DSE_TUNING build only: synchronises and reports how the lists came out
+            SE_HIP_CHECK(hipStreamSynchronize(s));
+            unsigned h[4], hc[8];
+            SE_HIP_CHECK(hipMemcpy(h, nflag, sizeof(h), hipMemcpyDeviceToHost));
+            SE_HIP_CHECK(hipMemcpy(hc, ctl, sizeof(hc), hipMemcpyDeviceToHost));
+            const double okq = (double)rows - (double)h[1];
+            float gmaxn, gmaxr;
+            memcpy(&gmaxn, &hc[0], 4); memcpy(&gmaxr, &hc[1], 4);
+            fprintf(stderr, "[se_retrieve_topk] prefilter: n=%lld d=%lld kp=%d k=%d S=%d G=%d j=%d cap=%lld rows=%lld sym=%d redo=%u mean_candidates=%.1f "
+                            "mean_recomputed=%.1f gallery_max_norm=%.4g max_residual=%.4g irregular_rows=%u\n",
+                    (long long)n, (long long)d, kp, k, p.S, p.G, p.j, (long long)L.cap, (long long)rows, (int)sym, h[1],
+                    okq > 0 ? (double)h[3] / okq : 0.0, okq > 0 ? (double)h[2] / okq : 0.0, (double)gmaxn, (double)gmaxr, hc[2]);
+        }
+        const int64_t fgrid = rows < FB_GRID ? rows : FB_GRID;
+        if (metric == SE_METRIC_COSINE)
+            hipLaunchKernelGGL(topk_fallback_kernel<SE_METRIC_COSINE>, dim3((unsigned)fgrid), dim3(TK_THREADS), lds_sel, s, qs, ldq, gallery, ldg, sq, sqg,
+                               rows, (int)n, (int)d, kbs, col_offset, k, P, scratch, out_d + q0 * k, out_i + q0 * k, nflag);
+        else
+            hipLaunchKernelGGL(topk_fallback_kernel<SE_METRIC_EUCLID>, dim3((unsigned)fgrid), dim3(TK_THREADS), lds_sel, s, qs, ldq, gallery, ldg, sq, sqg,
+                               rows, (int)n, (int)d, kbs, col_offset, k, P, scratch, out_d + q0 * k, out_i + q0 * k, nflag);
+        SE_LAUNCH_CHECK();
+    }
+    return SE_OK;
 }
 
 extern "C" int se_retrieve_topk(const float *queries, int64_t ldq, const float *gallery, int64_t ldg,
@@ -847,7 +1207,7 @@ extern "C" int se_retrieve_topk(const float *queries, int64_t ldq, const float *
                                 int metric, const int32_t *kblocks, int nkb, int64_t col_offset, int k,
                                 float *out_d, int32_t *out_i, void *workspace, int64_t workspace_bytes, se_stream_t stream)
 {
-    if (q < 0 || n <= 0 || d <= 0 || n > 0x7FFFFFFFll) return fail(SE_ERR_INVALID, "se_retrieve_topk: bad shape");
+    if (q < 0 || n <= 0 || d <= 0 || n > 0x7FFFFFFFll || q > 0x7FFFFFFFll) return fail(SE_ERR_INVALID, "se_retrieve_topk: bad shape");
     if (k < 1 || k > SE_TOPK_MAX || k > n) return fail(SE_ERR_INVALID, "se_retrieve_topk: need 1 <= k <= min(n, %d), got k=%d n=%lld", SE_TOPK_MAX, k, (long long)n);
     if (q == 0) return SE_OK;
     if (!queries || !gallery || !out_d || !out_i || ldq < d || ldg < d) return fail(SE_ERR_INVALID, "se_retrieve_topk: bad argument");
@@ -856,10 +1216,14 @@ extern "C" int se_retrieve_topk(const float *queries, int64_t ldq, const float *
     KBlocks kbs;
     bool multi = false;
     if (const int rc = make_kblocks("se_retrieve_topk", kblocks, nkb, d, kbs, multi)) return rc;
-    const int64_t need = se_retrieve_topk_workspace_bytes(q, n, ldg, k);
-    if (!workspace || workspace_bytes < need) return fail(SE_ERR_WORKSPACE, "se_retrieve_topk: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)need);
     hipStream_t s = (hipStream_t)stream;
     const FusedPlan p = fused_plan(n, ldg, k);
+    const bool pf = prefilter_wanted(p, k);
+    const FusedLayout L = p.ok ? fused_layout(q, n, d, p, pf) : FusedLayout{};
+    const int64_t need = p.ok ? L.total : topk_qtile(q, n) * ((n + 3) / 4 * 4) * 4;
+    if (!workspace || workspace_bytes < need) return fail(SE_ERR_WORKSPACE, "se_retrieve_topk: workspace %lld < %lld bytes", (long long)workspace_bytes, (long long)need);
+    if (p.ok && (((uintptr_t)workspace) & 255) != 0) return fail(SE_ERR_INVALID, "se_retrieve_topk: workspace must be 256-byte aligned");
+    if (pf) return retrieve_topk_prefilter(queries, ldq, gallery, ldg, sqq, sqg, q, n, d, metric, kbs, col_offset, k, out_d, out_i, (char *)workspace, p, L, s);
 
     if (!p.ok) {   // ---- small problems: [rows, n] distance slab -> se_topk_rows, query tile by query tile ----
         const int64_t qt = topk_qtile(q, n);
@@ -876,8 +1240,7 @@ extern "C" int se_retrieve_topk(const float *queries, int64_t ldq, const float *
         return SE_OK;
     }
 
-    // ---- fused path ----
-    const FusedLayout L = fused_layout(q, n, p);
+    // ---- fused path, fp32 passes (k > 512, or pinned by the tuning build) ----
     char *ws = (char *)workspace;
     float *tau = (float *)(ws + L.off_tau);
     unsigned *rowcnt = (unsigned *)(ws + L.off_cnt);
@@ -938,3 +1301,36 @@ extern "C" int se_retrieve_topk(const float *queries, int64_t ldq, const float *
     }
     return SE_OK;
 }
+
+#ifdef SE_TUNING
+// -DSE_TUNING build only (tests of the error bound of the bf16 pre-filter; not part of include/sehip.h): d~ of every (gallery row,
+// query) pair as the pre-filter's tile loop computes it -> out_dt [n, ldo >= q], and eps(query) as pf_thr_kernel derives it -> out_eps [q].
+//   workspace: 2 (n + q) pf_padded_dim(d) + 16 (n + q) + 4 q + 4096 bytes, 256-byte aligned.
+extern "C" int se_tuning_prefilter_probe(const float *queries, int64_t ldq, const float *gallery, int64_t ldg, const float *sqq, const float *sqg,
+                                         int64_t q, int64_t n, int64_t d, int metric, int nkb, float *out_dt, int64_t ldo, float *out_eps,
+                                         void *workspace, int64_t workspace_bytes, se_stream_t stream)
+{
+    hipStream_t s = (hipStream_t)stream;
+    const int kp = pf_padded_dim(d);
+    char *w = (char *)workspace;
+    unsigned *ctl = (unsigned *)w;                      w += 256;
+    float *gnrm = (float *)w;                           w += align256(n * 4);
+    float *gres = (float *)w;                           w += align256(n * 4);
+    float *qnrm = (float *)w;                           w += align256(q * 4);
+    float *qres = (float *)w;                           w += align256(q * 4);
+    float *gm = (float *)w;                             w += align256(q * 4);      // one "group minimum" per query: +inf -> tau is irrelevant here
+    float *thr = (float *)w;                            w += align256(q * 4);
+    uint16_t *gimg = (uint16_t *)w;                     w += align256(n * (int64_t)kp * 2);
+    uint16_t *qimg = (uint16_t *)w;                     w += align256(q * (int64_t)kp * 2);
+    if (w - (char *)workspace > workspace_bytes) return fail(SE_ERR_WORKSPACE, "se_tuning_prefilter_probe: workspace too small");
+    SE_HIP_CHECK(hipMemsetAsync(ctl, 0, 256, s));
+    SE_HIP_CHECK(hipMemsetAsync(gm, 0, (size_t)q * 4, s));
+    if (const int rc = pf_convert(gallery, ldg, n, d, gimg, gnrm, gres, ctl, s)) return rc;
+    if (const int rc = pf_convert(queries, ldq, q, d, qimg, qnrm, qres, ctl + 4, s)) return rc;
+    PfPassArgs pa = {nullptr, 0, nullptr, nullptr, nullptr, 0, 1, out_dt, ldo};
+    if (const int rc = pf_pass(PF_EPI_STORE, false, metric, gimg, kp, qimg, kp, sqg, sqq, n, q, kp, pa, s)) return rc;
+    hipLaunchKernelGGL(pf_thr_kernel, dim3((unsigned)((q + 3) / 4)), dim3(256), 0, s, gm, (int64_t)1, q, 1, 1, qnrm, qres, ctl, metric, (int)d, kp, nkb, thr, out_eps);
+    SE_LAUNCH_CHECK();
+    return SE_OK;
+}
+#endif

@@ -110,7 +110,7 @@ def lib():
     L.se_topk_rows.argtypes = [vp, c_i64, c_i64, c_i64, c_i64, c_int, vp, vp, vp]
     L.se_topk_merge.argtypes = [vp, vp, c_int, c_i64, c_int, vp, vp, vp]
     L.se_topk_merge_packed.argtypes = [vp, c_int, c_i64, c_int, vp, vp, vp]
-    L.se_retrieve_topk_workspace_bytes.argtypes = [c_i64, c_i64, c_i64, c_int]
+    L.se_retrieve_topk_workspace_bytes.argtypes = [c_i64, c_i64, c_i64, c_i64, c_int]
     L.se_retrieve_topk_workspace_bytes.restype = c_i64
     L.se_retrieve_topk.argtypes = [vp, c_i64, vp, c_i64, vp, vp, c_i64, c_i64, c_i64, c_int,
                                    ctypes.POINTER(ctypes.c_int32), c_int, c_i64, c_int, vp, vp, vp, c_i64, vp]

@@ -463,7 +463,7 @@ def retrieve_topk(queries, gallery, k, metric=METRIC_COSINE, col_offset=0, sqq=N
         if od.dtype != torch.float32 or oi.dtype != torch.int32 or tuple(od.shape) != (q, k) or tuple(oi.shape) != (q, k) \
                 or not od.is_contiguous() or not oi.is_contiguous():
             raise SehipError("out must be contiguous (float32 [q, k], int32 [q, k]) tensors")
-    need = lib().se_retrieve_topk_workspace_bytes(q, n, gallery.stride(0), int(k))
+    need = lib().se_retrieve_topk_workspace_bytes(q, n, d, gallery.stride(0), int(k))
     ws = _workspace(need, queries.device)
     kb, nkb = _kblocks_arg(kblocks)
     check(lib().se_retrieve_topk(ptr(queries), queries.stride(0), ptr(gallery), gallery.stride(0), ptr(sqq), ptr(sqg),

@@ -111,6 +111,6 @@ def test_no_unsynchronised_function_local_state_in_the_library():
             continue
         for ln, line in enumerate(open(os.path.join(csrc, f)), 1):
             m = re.match(r"\s+static\s+(?!const\b|constexpr\b|thread_local\b|std::atomic|__device__|inline\b)(\w[\w:<> \*]*)\s+\w+.*[=;]", line)
-            if m and "(" not in line.split("=")[0]:
+            if m and "std::mutex" not in line and "guarded by mu" not in line and "(" not in line.split("=")[0]:
                 bad.append("%s:%d: %s" % (f, ln, line.strip()))
     assert not bad, bad

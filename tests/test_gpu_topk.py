@@ -157,8 +157,8 @@ def test_product_path_takes_fused_kernels_from_16384_rows(sehip, metric):
     if metric == 0:
         g = ro.canon_normalize_rows(g)
     qs = np.ascontiguousarray(g[:q])
-    need = sehip.lib().se_retrieve_topk_workspace_bytes(q, n, d, k)
-    assert need < q * n * 4 + 256 * n * 4 + (1 << 20), "fused layout expected (candidate lists, not a distance slab)"
+    need = sehip.lib().se_retrieve_topk_workspace_bytes(q, n, d, d, k)
+    assert need < q * n * 4 + 256 * n * 4 + 2 * (n + q) * 128 + (1 << 20), "fused layout expected (candidate lists, not a distance slab)"
     dd, ii = sehip.retrieve_topk(dev(qs), dev(g), k, metric=metric, col_offset=123)
     wd, wi = want_topk(qs, g, k, metric, None, 123)
     assert np.array_equal(ii.cpu().numpy(), wi)
@@ -202,8 +202,8 @@ def test_product_library_d1000_kblocks_large_gallery(sehip, metric):
     qs = (emb[yq] + 0.03 * rng.standard_normal((q, d))).astype(np.float32)
     if metric == 0:
         g, qs = ro.canon_normalize_rows(g), ro.canon_normalize_rows(qs)
-    need = sehip.lib().se_retrieve_topk_workspace_bytes(q, n, d, k)
-    assert need < q * n * 4 + 256 * n * 4 + (64 << 20), "fused layout expected (candidate lists, not a distance slab)"
+    need = sehip.lib().se_retrieve_topk_workspace_bytes(q, n, d, d, k)
+    assert need < q * n * 4 + 256 * n * 4 + 2 * (n + q) * 1024 + (1 << 20), "fused layout expected (candidate lists, not a distance slab)"
     dd, ii = sehip.retrieve_topk(dev(qs), dev(g), k, metric=metric, kblocks=kb, col_offset=n)
     rows = verify.sample_rows(q, n_random=12)
     det = verify.verify_topk_sample(qs, g, metric, k, dd, ii, rows, col_offset=n, kblocks=kb)
@@ -234,3 +234,140 @@ def test_topk_merge_packed_equals_separate_lists(sehip):
     wd, wi = ro.canon_topk_merge(d, i)
     assert np.array_equal(md.cpu().numpy(), wd) and np.array_equal(mi.cpu().numpy(), wi)
     assert np.array_equal(pd_.cpu().numpy(), wd) and np.array_equal(pi_.cpu().numpy(), wi)
+
+
+# ---------------------------------------------------------------- bf16 pre-filter (prefilter.hip + pf_refine_kernel)
+
+def test_fp32_fused_passes_stay_covered():
+    """SE_TOPK_PREFILTER=0 (tuning build) pins the fp32 form of the fused passes (what k > 512 takes in the product): reference heads
+    with K-blocks and the ragged cases, as before the bf16 pre-filter existed."""
+    run_with_tuning_lib(
+        "for p in T.GOLDEN:\n"
+        "    T.check_against_reference_head(sehip, p)\n", env={"SE_TOPK_FUSED": "1", "SE_TOPK_PREFILTER": "0"})
+    run_with_tuning_lib(FUSED_CASES + "os.environ['SE_TOPK_FUSED'] = '1'\nos.environ['SE_TOPK_PREFILTER'] = '0'\nrun_cases('fp32 fused')\n")
+
+
+PROBE = (
+    "import ctypes\n"
+    "from sehip._lib import lib, ptr, check\n"
+    "def probe(qs, g, metric, nkb=1):\n"
+    "    L = lib(); f = L.se_tuning_prefilter_probe\n"
+    "    i64, vp, ci = ctypes.c_int64, ctypes.c_void_p, ctypes.c_int\n"
+    "    f.argtypes = [vp, i64, vp, i64, vp, vp, i64, i64, i64, ci, ci, vp, i64, vp, vp, i64, vp]\n"
+    "    q, d = qs.shape; n = g.shape[0]; kp = (d + 63) // 64 * 64\n"
+    "    Q, G = torch.from_numpy(qs).cuda(), torch.from_numpy(g).cuda()\n"
+    "    sq = sehip.row_sqnorm(Q) if metric == 1 else None; sg = sehip.row_sqnorm(G) if metric == 1 else None\n"
+    "    out = torch.empty((n, q), dtype=torch.float32, device='cuda'); eps = torch.empty((q,), dtype=torch.float32, device='cuda')\n"
+    "    ws = torch.empty((2 * (n + q) * kp + 16 * (n + q) + 8 * q + 8192,), dtype=torch.uint8, device='cuda')\n"
+    "    check(f(ptr(Q), d, ptr(G), d, ptr(sq), ptr(sg), q, n, d, metric, nkb, ptr(out), q, ptr(eps), ptr(ws), ws.numel(),\n"
+    "            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), 'probe')\n"
+    "    torch.cuda.synchronize()\n"
+    "    return out.cpu().numpy(), eps.cpu().numpy()\n"
+    "def bf16_round(x):\n"
+    "    u = x.view(np.uint32).astype(np.uint64)\n"
+    "    u = (u + 0x7FFF + ((u >> 16) & 1)) >> 16 << 16\n"
+    "    return u.astype(np.uint32).view(np.float32)\n"
+)
+
+
+def test_prefilter_error_bound_holds_on_hardware():
+    """The pre-filter's correctness rests on |d~ - d| <= eps(query) for EVERY pair.  eps is derived from the operands' actual bf16
+    rounding residuals plus assumption A1 about the matrix core's accumulation (|error| <= 2^-18 (|C| + sum |products|) per
+    v_mfma_f32_32x32x16_bf16): measured here on gaussian, clustered, wide-dynamic-range and cancellation-heavy operands, both metrics,
+    D = 100 / 555 / 1000 -- (a) the bound holds with room, (b) A1 itself: the matrix core's result against the float64 dot product of
+    the SAME bf16-rounded operands is within 1/8 of what A1 allows."""
+    out = run_with_tuning_lib(
+        PROBE +
+        "rng = np.random.default_rng(12)\n"
+        "worst_bound = worst_a1 = 0.0\n"
+        "for d in (100, 555, 1000):\n"
+        "    n, q = 700, 200\n"
+        "    base = rng.standard_normal((n, d)).astype(np.float32)\n"
+        "    cases = {'gauss': base,\n"
+        "             'clustered': (base[rng.integers(0, 12, size=n)] + 0.02 * rng.standard_normal((n, d))).astype(np.float32),\n"
+        "             'dynamic': (base * np.exp2(rng.integers(-12, 12, size=(n, d)))).astype(np.float32),\n"
+        "             'cancel': np.concatenate([base[:, :d // 2], -base[:, :d - d // 2] * (1 + 1e-3 * rng.standard_normal((n, d - d // 2)))], axis=1).astype(np.float32)}\n"
+        "    for name, g in cases.items():\n"
+        "        for metric in (0, 1):\n"
+        "            gg = ro.canon_normalize_rows(g) if (metric == 0 and name != 'dynamic') else np.ascontiguousarray(g)\n"
+        "            qs = np.ascontiguousarray(gg[rng.permutation(n)[:q]])\n"
+        "            dt, eps = probe(qs, gg, metric)\n"
+        "            exact = ro.canon_pdist(qs, gg, metric)                      # [q, n]: the canonical fp32 chain\n"
+        "            err = np.abs(dt.T.astype(np.float64) - exact.astype(np.float64))\n"
+        "            assert np.isfinite(eps).all() and (eps > 0).all()\n"
+        "            ratio = float((err / eps[:, None].astype(np.float64)).max())\n"
+        "            assert ratio <= 1.0, (d, name, metric, ratio)\n"
+        "            worst_bound = max(worst_bound, ratio)\n"
+        "            if metric == 0:\n"
+        "                a, b = bf16_round(qs).astype(np.float64), bf16_round(gg).astype(np.float64)\n"
+        "                v64 = a @ b.T; s64 = np.abs(a) @ np.abs(b).T\n"
+        "                kp = (d + 63) // 64 * 64\n"
+        "                a1 = np.abs(-dt.T.astype(np.float64) - v64) / ((kp / 16) * 2.0 ** -18 * s64 + 1e-300)\n"
+        "                worst_a1 = max(worst_a1, float(a1.max()))\n"
+        "print('worst |d~ - d| / eps = %.4f; worst accumulation error / A1 allowance = %.5f' % (worst_bound, worst_a1))\n"
+        "assert worst_a1 <= 0.125\n")
+    print([ln for ln in out.splitlines() if ln.startswith("worst")])
+
+
+def test_prefilter_adversarial_near_duplicates_around_rank_k():
+    """A gallery built to defeat a filter that trusted its bf16 scores: hundreds of near-duplicates of every query whose distances
+    differ by single float32 ulps around rank k -- far below eps -- plus exact duplicates (tie groups straddling rank k).  The
+    refinement must recompute the whole eps window exactly and still return the canonical head, bit for bit; product library, no
+    switches, both metrics, K-blocks at D = 1000."""
+    import sehip as m
+    rng = np.random.default_rng(21)
+    for d, kb, metric in ((100, None, 0), (100, None, 1), (1000, [448, 276, 276], 0)):
+        n, q, k = 17000, 48, 251
+        g = rng.standard_normal((n, d)).astype(np.float32)
+        if metric == 0:
+            g = ro.canon_normalize_rows(g)
+        qs = np.ascontiguousarray(g[:q])
+        # rows 1000 .. 1000 + 48 * 330: 330 perturbed copies of each query, the perturbation a few float32 ulps of one coordinate
+        for i in range(q):
+            blk = g[1000 + i * 330: 1000 + (i + 1) * 330]
+            blk[:] = qs[i]
+            cols = rng.integers(0, d, size=330)
+            ulps = rng.integers(-6, 7, size=330)
+            v = blk[np.arange(330), cols].view(np.int32) + ulps
+            blk[np.arange(330), cols] = v.view(np.float32)
+            blk[::11] = qs[i]                                   # exact duplicates: ties broken by index
+        dd, ii = m.retrieve_topk(dev(qs), dev(g), k, metric=metric, kblocks=kb)
+        wd, wi = want_topk(qs, g, k, metric, kb)
+        assert np.array_equal(ii.cpu().numpy(), wi), (d, metric)
+        assert np.array_equal(dd.cpu().numpy(), wd), (d, metric)
+
+
+def test_prefilter_irregular_rows():
+    """Rows the bf16 bound says nothing about -- NaN / +-inf entries, magnitudes >= 2^60, all-zero rows, denormals -- in the gallery and
+    among the queries: their bf16 images are NaN, every d~ with them is NaN, NaN always becomes a candidate and the exact chain decides
+    (irregular queries are redone over the whole gallery).  Same bits as the oracle."""
+    run_with_tuning_lib(
+        "os.environ['SE_TOPK_FUSED'] = '1'\n"
+        "rng = np.random.default_rng(33)\n"
+        "n, d, k = 5000, 72, 60\n"
+        "g = rng.standard_normal((n, d)).astype(np.float32)\n"
+        "g[17, 3] = np.inf; g[18, 5] = -np.inf; g[19, 0] = np.nan; g[20] = 0.0; g[21, 7] = 3e30; g[22, 1] = -2e19; g[23] *= 1e-41\n"
+        "g[24, 3] = np.inf; g[24, 4] = -np.inf\n"
+        "qs = g[[0, 1, 17, 18, 19, 20, 21, 22, 23, 24, 4999]].copy()\n"
+        "qs[0, 2] = 1e-42\n"
+        "for metric in (0, 1):\n"
+        "    with np.errstate(all='ignore'):\n"
+        "        wd, wi = T.want_topk(qs, g, k, metric)\n"
+        "    dd, ii = sehip.retrieve_topk(torch.from_numpy(qs).cuda(), torch.from_numpy(g).cuda(), k, metric=metric)\n"
+        "    assert np.array_equal(ii.cpu().numpy(), wi), metric\n"
+        "    assert np.array_equal(dd.cpu().numpy(), wd, equal_nan=True), metric\n")
+
+
+def test_prefilter_statistics_at_full_size():
+    """What the pre-filter does at BASELINE configs[2] size (tuning build, SE_TOPK_VERBOSE): candidates per query the bf16 pass
+    admits, exact recomputations per query, queries sent to the exact fallback (< 1e-3 of them)."""
+    out = run_with_tuning_lib(
+        "os.environ['SE_TOPK_VERBOSE'] = '1'\n"
+        "x = torch.from_numpy(np.random.default_rng(0).standard_normal((50000, 100)).astype(np.float32)).cuda()\n"
+        "sehip.normalize_rows_(x)\n"
+        "d, i = sehip.retrieve_topk(x, x, 251, metric=0)\n"
+        "assert bool((i[:, 0] == torch.arange(50000, device='cuda', dtype=torch.int32)).all())\n")
+    line = [ln for ln in out.splitlines() if "prefilter:" in ln][-1]
+    print(line)
+    redo = int(line.split("redo=")[1].split()[0])
+    assert redo <= 50, line
