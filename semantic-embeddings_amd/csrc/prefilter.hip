@@ -1,21 +1,30 @@
-// prefilter.hip -- bf16 matrix-core PRE-FILTER of the fused distance + top-k (se_retrieve_topk; SURVEY.md section 7 hard part 2,
-// section 8d "fused top-k").
+// prefilter.hip -- half-precision matrix-core PRE-FILTER of the fused distance + top-k (se_retrieve_topk; SURVEY.md section 7 hard
+// part 2, section 8d "fused top-k").
 //
 // Replaces nothing of the reference by itself: it decides WHICH of the Q x N distances of evaluate_retrieval.py:57-63 are worth
 // computing exactly.  Every distance that reaches a caller still comes from the canonical fp32 FMA chain (topk.hip recomputes each
 // surviving candidate with it), so the output stays bit-identical -- the filter only has to BOUND distances.
 //
-//   d~(q, g)  = distance computed from bf16-rounded operands on v_mfma_f32_32x32x16_bf16 (2.5 PFLOP/s dense, 16x the fp32 pipe)
+//   d~(q, g)  = distance computed from fp16 images of the operands on v_mfma_f32_32x32x16_f16 (2.5 PFLOP/s dense, 16x the fp32 pipe)
 //   |d~ - d| <= eps(q)        rigorous, from the operands' actual rounding residuals (pf_convert_kernel) -- DESIGN.md section 5.3
 //
+// Why fp16 and not bf16: the filter's window is 2 eps wide and every item inside it costs one exact recomputation = one 4 D-byte
+// gallery row out of HBM.  fp16 keeps 11 significant bits against bf16's 8 (eps 8x smaller); its narrow exponent range is dealt
+// with by ONE power-of-two scale per operand matrix (largest regular magnitude -> [2^13, 2^14): no overflow; exact to undo) and by
+// flushing scaled values below 2^-14 to zero in the image ourselves, so the matrix core never sees a denormal input and the
+// residual norm accounts for the flush exactly.  (First version, bf16: 554 exact recomputations per query at D = 1000, k = 251.)
+//
 // Kernels:
-//   pf_convert_kernel   fp32 rows -> bf16 rows padded to a multiple of 64 columns (zeros), + per row: the norm of the bf16 image and the
-//                       norm of the rounding residual x - bf16(x) (both rounded up), + the maxima over all rows (atomicMax on the float
-//                       bits).  Rows that are not "regular" (a non-finite entry, or a magnitude >= 2^60) get an all-NaN bf16 image: every
-//                       d~ with such a row is NaN and NaN always passes the filter, so the exact path decides about them.
+//   pf_maxabs_kernel    largest regular magnitude of a matrix -> its scale exponent.
+//   pf_convert_kernel   fp32 rows -> fp16 rows (x 2^e, padded with zeros to a multiple of 128 columns) + per row: the norm of the image
+//                       (unscaled units) and the norm of the residual x - image (both rounded up) + the maxima over all rows.  Rows that
+//                       are not "regular" (a non-finite entry, or a magnitude >= 2^60) get an all-NaN image: every d~ with such a row is
+//                       NaN, NaN always passes the filter, the exact path decides about them.
 //   pf_tile_kernel      the tile loop: persistent 256-thread workgroups (2 x 2 waves, 64 x 64 outputs per wave = 2 x 2 MFMA blocks),
-//                       128 x 128 tiles, K-chunks of 64 bf16 (128 bytes per row) staged through LDS with a software-pipelined
-//                       global -> register prefetch; rows = gallery, columns = queries.  Epilogues:
+//                       128 x 128 tiles, K-chunks of 128 halves (256 bytes per row) staged through LDS with a software-pipelined
+//                       global -> register prefetch (16 x 16 bytes per thread in flight: at 16x the fp32 MFMA rate a chunk's matrix
+//                       work no longer covers a global round trip, the chunk has to be long); rows = gallery, columns = queries.
+//                       Epilogues:
 //                         PF_GROUPMIN  sample pass: minimum of each lane's 16 values per block -> gm[query, group]
 //                         PF_FILTER    values <= thr[query] (or NaN) appended to the query's candidate list as (d~ bits, gallery row);
 //                                      all-pairs calls walk the upper triangle and filter every off-diagonal tile in BOTH orientations --
@@ -26,14 +35,15 @@
 
 namespace se {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float pf_f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int PF_BM = 128, PF_BN = 128, PF_BK = 64;        // tile, K-chunk (bf16 elements)
+constexpr int PF_BM = 128, PF_BN = 128, PF_BK = 128;       // tile, K-chunk (fp16 elements)
 constexpr int PF_THREADS = 256;
-constexpr int PF_ROWB = PF_BK * 2;                          // bytes of one operand row of a chunk (128)
-constexpr int PF_PITCH = PF_ROWB + 16;                      // LDS row pitch in bytes: 36 dwords -> conflict-free ds_read_b128 over 16 rows
-constexpr int PF_NLOAD = PF_BM * PF_ROWB / 16 / PF_THREADS; // 16-byte pieces per operand per thread (4)
+constexpr int PF_ROWB = PF_BK * 2;                          // bytes of one operand row of a chunk (256)
+constexpr int PF_PITCH = PF_ROWB + 16;                      // LDS row pitch in bytes: 68 dwords -> conflict-free ds_read_b128 over 16 rows
+constexpr int PF_NLOAD = PF_BM * PF_ROWB / 16 / PF_THREADS; // 16-byte pieces per operand per thread (8)
+constexpr int PF_PPR = PF_ROWB / 16;                        // pieces per row (16)
 constexpr int PF_WGS_PER_CU = 2;
 constexpr int PF_GROUP_M = 16;
 
@@ -48,13 +58,52 @@ struct PfArgs {
 };
 
 // ---- conversion ---------------------------------------------------------------------------------------------------------------
-// ctl words (uint32, float bits, combined with atomicMax: all values are >= 0): [0] max row norm of the bf16 image,
-// [1] max residual norm, [2] number of irregular rows
+// ctl words of one operand matrix (uint32; float bits are combined with atomicMax: all values are >= 0):
+//   [0] max row norm of the image  [1] max residual norm  [2] number of irregular rows  [3] largest regular magnitude  [4] scale exponent e
+constexpr float PF_REG_LIMIT = 1.152921504606846976e18f;     // 2^60: magnitudes from here on make a row irregular
+
+__global__ __launch_bounds__(256) void pf_maxabs_kernel(const float *__restrict__ x, int64_t ldx, int64_t n, int d, unsigned *__restrict__ ctl)
+{
+    __shared__ float wmax[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float m = 0.f;
+    for (int64_t r = (int64_t)blockIdx.x * 4 + wave; r < n; r += (int64_t)gridDim.x * 4) {
+        const float *xr = x + r * ldx;
+        for (int c = lane; c < d; c += 64) {
+            const float a = __builtin_fabsf(xr[c]);
+            m = (a < PF_REG_LIMIT && a > m) ? a : m;               // NaN / inf / huge entries do not set the scale
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { const float o = __shfl_xor(m, off, 64); m = o > m ? o : m; }
+    if (lane == 0) wmax[wave] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = wmax[0];
+        for (int i = 1; i < 4; i++) m = wmax[i] > m ? wmax[i] : m;
+        atomicMax(&ctl[3], __float_as_uint(m));
+    }
+}
+
+// scale exponent: largest regular magnitude m = f 2^ex (f in [0.5, 1)) -> m 2^e in [2^13, 2^14)
+__device__ __forceinline__ int pf_scale_exp(float m)
+{
+    if (!(m > 0.f)) return 0;
+    int ex;
+    (void)frexpf(m, &ex);
+    int e = 14 - ex;
+    return e < -120 ? -120 : (e > 120 ? 120 : e);
+}
+
 __global__ __launch_bounds__(256) void pf_convert_kernel(const float *__restrict__ x, int64_t ldx, int64_t n, int d, int kp,
                                                          uint16_t *__restrict__ out, float *__restrict__ nrm, float *__restrict__ res,
                                                          unsigned *__restrict__ ctl)
 {
+    __shared__ float wm_n[4], wm_r[4];
+    __shared__ unsigned wm_b[4];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int e = pf_scale_exp(__uint_as_float(ctl[3]));
+    const float sc = ldexpf(1.0f, e), isc = ldexpf(1.0f, -e);
     float wmax_n = 0.f, wmax_r = 0.f;
     unsigned wbad = 0;
     for (int64_t r = (int64_t)blockIdx.x * 4 + wave; r < n; r += (int64_t)gridDim.x * 4) {
@@ -65,16 +114,19 @@ __global__ __launch_bounds__(256) void pf_convert_kernel(const float *__restrict
         for (int c0 = lane * 4; c0 < kp; c0 += 256) {
             float v[4];
 #pragma unroll
-            for (int e = 0; e < 4; e++) v[e] = (c0 + e < d) ? xr[c0 + e] : 0.f;
+            for (int i = 0; i < 4; i++) v[i] = (c0 + i < d) ? xr[c0 + i] : 0.f;
             uint16_t h[4];
 #pragma unroll
-            for (int e = 0; e < 4; e++) {
-                h[e] = f32_to_bf16(v[e]);
-                const float hv = bf16_to_f32(h[e]);
-                const float rv = v[e] - hv;                                 // exact (Sterbenz-like: hv is v rounded to 8 bits)
+            for (int i = 0; i < 4; i++) {
+                const float xs = v[i] * sc;
+                _Float16 hh = (_Float16)xs;                                       // round to nearest even
+                if (__builtin_fabsf(xs) < 6.103515625e-05f) hh = (_Float16)0.f;   // below fp16's normal range: flushed HERE, never a denormal input
+                const float hv = (float)hh * isc;                                 // the image in the operand's own units (exact: power-of-two scale)
+                const float rv = v[i] - hv;
                 sn = __builtin_fmaf(hv, hv, sn);
                 sr = __builtin_fmaf(rv, rv, sr);
-                bad = bad || !(__builtin_fabsf(v[e]) < 1.152921504606846976e18f);   // NaN, inf or |v| >= 2^60
+                bad = bad || !(__builtin_fabsf(v[i]) < PF_REG_LIMIT);             // NaN, inf or |v| >= 2^60
+                h[i] = __builtin_bit_cast(uint16_t, hh);
             }
             *(uint2 *)(orow + c0) = make_uint2((uint32_t)h[0] | ((uint32_t)h[1] << 16), (uint32_t)h[2] | ((uint32_t)h[3] << 16));
         }
@@ -85,7 +137,7 @@ __global__ __launch_bounds__(256) void pf_convert_kernel(const float *__restrict
         float nn = sqrtf(sn) * 1.002f + 1e-37f, rr = sqrtf(sr) * 1.002f + 1e-37f;
         if (any_bad) {
             nn = rr = __builtin_nanf("");
-            for (int c0 = lane * 4; c0 < kp; c0 += 256) *(uint2 *)(orow + c0) = make_uint2(0x7FC07FC0u, 0x7FC07FC0u);   // all-NaN image
+            for (int c0 = lane * 4; c0 < kp; c0 += 256) *(uint2 *)(orow + c0) = make_uint2(0x7E007E00u, 0x7E007E00u);   // all-NaN image (fp16 quiet NaN)
             wbad += (lane == 0);
         } else {
             wmax_n = nn > wmax_n ? nn : wmax_n;
@@ -93,10 +145,17 @@ __global__ __launch_bounds__(256) void pf_convert_kernel(const float *__restrict
         }
         if (lane == 0) { nrm[r] = nn; res[r] = rr; }
     }
-    if (lane == 0) {
-        atomicMax(&ctl[0], __float_as_uint(wmax_n));
-        atomicMax(&ctl[1], __float_as_uint(wmax_r));
-        if (wbad) atomicAdd(&ctl[2], wbad);
+    // one set of atomics per workgroup (per wave they serialised on three addresses: 0.75 ms for 50,000 short rows)
+    if (lane == 0) { wm_n[wave] = wmax_n; wm_r[wave] = wmax_r; wm_b[wave] = wbad; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float a = wm_n[0], b = wm_r[0];
+        unsigned c = wm_b[0];
+        for (int i = 1; i < 4; i++) { a = wm_n[i] > a ? wm_n[i] : a; b = wm_r[i] > b ? wm_r[i] : b; c += wm_b[i]; }
+        atomicMax(&ctl[0], __float_as_uint(a));
+        atomicMax(&ctl[1], __float_as_uint(b));
+        if (c) atomicAdd(&ctl[2], c);
+        if (blockIdx.x == 0) ctl[4] = (unsigned)e;
     }
 }
 
@@ -134,7 +193,7 @@ __device__ __forceinline__ void pf_tile_coords(uint32_t t, int tiles_m, int tile
     tn_out = (int)col_t;
 }
 
-// global -> registers: chunk [k0, k0 + 64) of rows [row0, row0 + 128) of a bf16 matrix with pitch `ld` elements (multiple of 64 columns,
+// global -> registers: chunk [k0, k0 + 128) of rows [row0, row0 + 128) of an fp16 matrix with pitch `ld` elements (multiple of 128 columns,
 // 16-byte aligned rows).  Rows beyond nrows are clamped (read twice, ignored by the epilogues): no masking anywhere in the loop.
 __device__ __forceinline__ void pf_load(uint4 (&v)[PF_NLOAD], const uint16_t *__restrict__ src, uint32_t ld, int64_t row0, int64_t nrows, int k0)
 {
@@ -144,7 +203,7 @@ __device__ __forceinline__ void pf_load(uint4 (&v)[PF_NLOAD], const uint16_t *__
 #pragma unroll
     for (int i = 0; i < PF_NLOAD; i++) {
         const int p = tid + i * PF_THREADS;
-        const int r = p >> 3, c = p & 7;
+        const int r = p / PF_PPR, c = p % PF_PPR;
         const int rc = r < rows_here ? r : rows_here - 1;
         v[i] = *(const uint4 *)(base + ((uint32_t)rc * ld * 2u + (uint32_t)k0 * 2u + (uint32_t)c * 16u));
     }
@@ -156,14 +215,15 @@ __device__ __forceinline__ void pf_stage(char *lds, const uint4 (&v)[PF_NLOAD])
 #pragma unroll
     for (int i = 0; i < PF_NLOAD; i++) {
         const int p = tid + i * PF_THREADS;
-        *(uint4 *)(lds + (p >> 3) * PF_PITCH + (p & 7) * 16) = v[i];
+        *(uint4 *)(lds + (p / PF_PPR) * PF_PITCH + (p % PF_PPR) * 16) = v[i];
     }
 }
 
 template <int METRIC, bool SYM, int EPI>
 __global__ __launch_bounds__(PF_THREADS, PF_WGS_PER_CU) void pf_tile_kernel(
     const uint16_t *__restrict__ A, uint32_t lda, const uint16_t *__restrict__ B, uint32_t ldb, const float *__restrict__ sqa,
-    const float *__restrict__ sqb, int64_t NA, int64_t NB, int nchunks, int tiles_m, int tiles_n, int64_t ntiles, PfArgs fa)
+    const float *__restrict__ sqb, int64_t NA, int64_t NB, int nchunks, int tiles_m, int tiles_n, int64_t ntiles, const unsigned *__restrict__ ctl_a,
+    const unsigned *__restrict__ ctl_b, PfArgs fa)
 {
     static_assert(EPI != PF_GROUPMIN || !SYM, "the sample pass walks the general tile order");
     extern __shared__ __attribute__((aligned(16))) char pf_smem[];
@@ -198,6 +258,7 @@ __global__ __launch_bounds__(PF_THREADS, PF_WGS_PER_CU) void pf_tile_kernel(
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1;        // 2 x 2 waves, 64 x 64 outputs each
+    const float unscale = ldexpf(1.0f, -((int)ctl_a[4] + (int)ctl_b[4]));     // the images carry 2^ea, 2^eb: exact to undo
     const int col = lane & 31, hi = lane >> 5;
 
     pf_f32x16 acc[2][2];
@@ -240,17 +301,18 @@ __global__ __launch_bounds__(PF_THREADS, PF_WGS_PER_CU) void pf_tile_kernel(
             pf_load(ra, A, lda, m0, NA, nc * PF_BK);
             pf_load(rb, B, ldb, n0, NB, nc * PF_BK);
         }
-        // ---- MFMA over the chunk in LDS: 4 steps of k = 16 ----
+        // ---- MFMA over the chunk in LDS: 8 steps of k = 16 ----
 #pragma unroll
         for (int s = 0; s < PF_BK / 16; s++) {
-            bf16x8 a0 = __builtin_bit_cast(bf16x8, *(const uint4 *)(pa + s * 32));
-            bf16x8 a1 = __builtin_bit_cast(bf16x8, *(const uint4 *)(pa + 32 * PF_PITCH + s * 32));
-            bf16x8 b0 = __builtin_bit_cast(bf16x8, *(const uint4 *)(pb + s * 32));
-            bf16x8 b1 = __builtin_bit_cast(bf16x8, *(const uint4 *)(pb + 32 * PF_PITCH + s * 32));
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+            if (s == PF_BK / 32) asm volatile("" ::: "memory");       // two groups of 4 steps: all 32 operand reads hoisted at once cost 128 registers
+            f16x8 a0 = __builtin_bit_cast(f16x8, *(const uint4 *)(pa + s * 32));
+            f16x8 a1 = __builtin_bit_cast(f16x8, *(const uint4 *)(pa + 32 * PF_PITCH + s * 32));
+            f16x8 b0 = __builtin_bit_cast(f16x8, *(const uint4 *)(pb + s * 32));
+            f16x8 b1 = __builtin_bit_cast(f16x8, *(const uint4 *)(pb + 32 * PF_PITCH + s * 32));
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc[1][1], 0, 0, 0);
         }
         // the next chunk's operands are waited for HERE (value barriers: no use of a loaded register in front of the MFMA phase)
 #pragma unroll
@@ -267,7 +329,7 @@ __global__ __launch_bounds__(PF_THREADS, PF_WGS_PER_CU) void pf_tile_kernel(
             const bool full_rows = rows_here == PF_BM;
             const int lr0 = wm * 64 + 4 * hi;
 #define PF_SA(MI_, R) (METRIC == SE_METRIC_EUCLID ? tSqRow[lr0 + (MI_) * 32 + ((R) & 3) + 8 * ((R) >> 2)] : 0.f)
-#define PF_VAL(MI_, J, R) pf_finish<METRIC>(acc[MI_][J][R], PF_SA(MI_, R), sbq)
+#define PF_VAL(MI_, J, R) pf_finish<METRIC>(acc[MI_][J][R] * unscale, PF_SA(MI_, R), sbq)
             if (EPI == PF_STORE) {
 #pragma unroll
                 for (int j = 0; j < 2; j++) {
@@ -365,38 +427,48 @@ __global__ __launch_bounds__(PF_THREADS, PF_WGS_PER_CU) void pf_tile_kernel(
                     //      R = mi*32 + (r&3) + 8*(r>>2) + 4*h.  Counts -> one returning atomic per lane, ONE wait, then the stores. ----
                     const int gc0 = wn * 64 + col;                              // this lane's gallery column of block j: gc0 + 32 j
                     unsigned mycnt = 0;
-                    // thresholds / norms of this lane's query rows come out of the tile's side arrays at the point of use
+                    // thresholds / norms of this lane's 2 x 16 query rows come out of the tile's side arrays one 32-row block at a time
+                    // (16 + 16 live registers; a compiler fence between the blocks keeps the second block's reads behind the first's use)
                     float sbc[2];
 #pragma unroll
                     for (int j = 0; j < 2; j++) sbc[j] = METRIC == SE_METRIC_EUCLID ? tSqCol[gc0 + 32 * j] : 0.f;
-#define PF_THR2(MI_, R) tThrRow[lr0 + (MI_) * 32 + ((R) & 3) + 8 * ((R) >> 2)]
-#define PF_VAL2(MI_, J, R) pf_finish<METRIC>(acc[MI_][J][R], PF_SA(MI_, R), sbc[J])
-#define PF_PASS2(V, MI_, J, R) ((((V) <= PF_THR2(MI_, R)) || ((V) != (V))) && (gc0 + 32 * (J) < cols_here))
+                    const bool c0ok = gc0 < cols_here, c1ok = gc0 + 32 < cols_here;
+#define PF_ROWS2(MI_)                                                                                                        \
+    float t2[16], s2[16];                                                                                                    \
+    _Pragma("unroll") for (int r = 0; r < 16; r++) {                                                                         \
+        t2[r] = tThrRow[lr0 + (MI_) * 32 + (r & 3) + 8 * (r >> 2)];                                                          \
+        s2[r] = METRIC == SE_METRIC_EUCLID ? tSqRow[lr0 + (MI_) * 32 + (r & 3) + 8 * (r >> 2)] : 0.f;                        \
+    }
+#define PF_VAL2(MI_, J, R) pf_finish<METRIC>(acc[MI_][J][R] * unscale, s2[R], sbc[J])
+#define PF_PASS2(V, R, OK) ((((V) <= t2[R]) || ((V) != (V))) && (OK))
 #pragma unroll
-                    for (int mi = 0; mi < 2; mi++)
+                    for (int mi = 0; mi < 2; mi++) {
+                        asm volatile("" ::: "memory");
+                        PF_ROWS2(mi)
 #pragma unroll
                         for (int r = 0; r < 16; r++) {
-                            asm volatile("" ::: "memory");      // keep the side-array reads at their use: hoisted, 32 of them cost 32 live registers
                             const float v0 = PF_VAL2(mi, 0, r), v1 = PF_VAL2(mi, 1, r);
-                            const uint64_t b0 = __ballot(PF_PASS2(v0, mi, 0, r)), b1 = __ballot(PF_PASS2(v1, mi, 1, r));
+                            const uint64_t b0 = __ballot(PF_PASS2(v0, r, c0ok)), b1 = __ballot(PF_PASS2(v1, r, c1ok));
                             const unsigned clo = (unsigned)__popc((uint32_t)b0) + (unsigned)__popc((uint32_t)b1);
                             const unsigned chi = (unsigned)__popc((uint32_t)(b0 >> 32)) + (unsigned)__popc((uint32_t)(b1 >> 32));
                             const int R0 = mi * 32 + (r & 3) + 8 * (r >> 2);
                             mycnt = lane == R0 ? clo : mycnt;
                             mycnt = lane == R0 + 4 ? chi : mycnt;
                         }
+                    }
                     // lane R reserves for query row  cur_m0 + wm*64 + R
                     const int myrow = wm * 64 + lane;
                     unsigned myslot = 0;
                     if (mycnt) myslot = atomicAdd(&fa.rowcnt[cur_m0 + myrow], mycnt);
                     asm volatile("" : "+v"(myslot));
 #pragma unroll
-                    for (int mi = 0; mi < 2; mi++)
+                    for (int mi = 0; mi < 2; mi++) {
+                        asm volatile("" ::: "memory");
+                        PF_ROWS2(mi)
 #pragma unroll
                         for (int r = 0; r < 16; r++) {
-                            asm volatile("" ::: "memory");
                             const float v0 = PF_VAL2(mi, 0, r), v1 = PF_VAL2(mi, 1, r);
-                            const bool p0 = PF_PASS2(v0, mi, 0, r), p1 = PF_PASS2(v1, mi, 1, r);
+                            const bool p0 = PF_PASS2(v0, r, c0ok), p1 = PF_PASS2(v1, r, c1ok);
                             const uint64_t b0 = __ballot(p0), b1 = __ballot(p1);
                             if ((b0 | b1) == 0ull) continue;                                     // uniform: most rows of most tiles
                             const int R0 = mi * 32 + (r & 3) + 8 * (r >> 2);
@@ -417,9 +489,10 @@ __global__ __launch_bounds__(PF_THREADS, PF_WGS_PER_CU) void pf_tile_kernel(
                                 if (slot < (unsigned)fa.cap) lst[slot] = make_uint2(__float_as_uint(v1), (uint32_t)(cur_n0 + gc0 + 32));
                             }
                         }
+                    }
+#undef PF_ROWS2
 #undef PF_VAL2
 #undef PF_PASS2
-#undef PF_THR2
                 }
             }
 #undef PF_VAL
@@ -457,7 +530,7 @@ static int pf_num_cus()
 
 template <int METRIC, bool SYM, int EPI>
 static int pf_launch3(const uint16_t *a, int64_t lda, const uint16_t *b, int64_t ldb, const float *sqa, const float *sqb, int64_t na, int64_t nb,
-                      int kp, const PfArgs &fa, hipStream_t s)
+                      int kp, const unsigned *ctl_a, const unsigned *ctl_b, const PfArgs &fa, hipStream_t s)
 {
     const int tiles_m = (int)((na + PF_BM - 1) / PF_BM), tiles_n = (int)((nb + PF_BN - 1) / PF_BN);
     const int64_t ntiles = SYM ? ((int64_t)tiles_n * (tiles_n + 1) / 2) : ((int64_t)tiles_m * tiles_n);
@@ -473,7 +546,7 @@ static int pf_launch3(const uint16_t *a, int64_t lda, const uint16_t *b, int64_t
     auto kern = pf_tile_kernel<METRIC, SYM, EPI>;
     SE_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(PF_THREADS), lds, s, a, (uint32_t)lda, b, (uint32_t)ldb, sqa, sqb, na, nb, kp / PF_BK,
-                       tiles_m, tiles_n, ntiles, fa);
+                       tiles_m, tiles_n, ntiles, ctl_a, ctl_b, fa);
     SE_LAUNCH_CHECK();
     return SE_OK;
 }
@@ -481,13 +554,13 @@ static int pf_launch3(const uint16_t *a, int64_t lda, const uint16_t *b, int64_t
 
 template <int METRIC>
 static int pf_launch2(int epi, bool sym, const uint16_t *a, int64_t lda, const uint16_t *b, int64_t ldb, const float *sqa, const float *sqb,
-                      int64_t na, int64_t nb, int kp, const PfArgs &fa, hipStream_t s)
+                      int64_t na, int64_t nb, int kp, const unsigned *ca, const unsigned *cb, const PfArgs &fa, hipStream_t s)
 {
-    if (epi == PF_GROUPMIN) return pf_launch3<METRIC, false, PF_GROUPMIN>(a, lda, b, ldb, sqa, sqb, na, nb, kp, fa, s);
-    if (epi == PF_FILTER) return sym ? pf_launch3<METRIC, true, PF_FILTER>(a, lda, b, ldb, sqa, sqb, na, nb, kp, fa, s)
-                                      : pf_launch3<METRIC, false, PF_FILTER>(a, lda, b, ldb, sqa, sqb, na, nb, kp, fa, s);
+    if (epi == PF_GROUPMIN) return pf_launch3<METRIC, false, PF_GROUPMIN>(a, lda, b, ldb, sqa, sqb, na, nb, kp, ca, cb, fa, s);
+    if (epi == PF_FILTER) return sym ? pf_launch3<METRIC, true, PF_FILTER>(a, lda, b, ldb, sqa, sqb, na, nb, kp, ca, cb, fa, s)
+                                      : pf_launch3<METRIC, false, PF_FILTER>(a, lda, b, ldb, sqa, sqb, na, nb, kp, ca, cb, fa, s);
 #ifdef SE_TUNING
-    if (epi == PF_STORE) return pf_launch3<METRIC, false, PF_STORE>(a, lda, b, ldb, sqa, sqb, na, nb, kp, fa, s);
+    if (epi == PF_STORE) return pf_launch3<METRIC, false, PF_STORE>(a, lda, b, ldb, sqa, sqb, na, nb, kp, ca, cb, fa, s);
 #endif
     return fail(SE_ERR_UNSUPPORTED, "pre-filter pass %d", epi);
 }
@@ -499,20 +572,22 @@ int pf_convert(const float *x, int64_t ldx, int64_t n, int64_t d, uint16_t *out,
 {
     const int kp = pf_padded_dim(d);
     int64_t grid = (n + 3) / 4;
-    if (grid > 256 * 32) grid = 256 * 32;
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(pf_maxabs_kernel, dim3((unsigned)grid), dim3(256), 0, s, x, ldx, n, (int)d, ctl);
+    SE_LAUNCH_CHECK();
     hipLaunchKernelGGL(pf_convert_kernel, dim3((unsigned)grid), dim3(256), 0, s, x, ldx, n, (int)d, kp, out, nrm, res, ctl);
     SE_LAUNCH_CHECK();
     return SE_OK;
 }
 
 int pf_pass(int epi, bool sym, int metric, const uint16_t *gallery, int64_t lda, const uint16_t *queries, int64_t ldq, const float *sqg,
-            const float *sqq, int64_t n_a, int64_t n_q, int kp, const PfPassArgs &pa, hipStream_t s)
+            const float *sqq, int64_t n_a, int64_t n_q, int kp, const unsigned *ctl_g, const unsigned *ctl_q, const PfPassArgs &pa, hipStream_t s)
 {
     PfArgs fa;
     fa.gm = pa.gm; fa.gm_ld = pa.gm_ld; fa.thr = pa.thr; fa.rowcnt = pa.rowcnt; fa.lists = pa.lists; fa.cap = pa.cap;
     fa.sqa_stride = pa.sqa_stride; fa.out = pa.out; fa.ldo = pa.ldo;
-    if (metric == SE_METRIC_COSINE) return pf_launch2<SE_METRIC_COSINE>(epi, sym, gallery, lda, queries, ldq, sqg, sqq, n_a, n_q, kp, fa, s);
-    if (metric == SE_METRIC_EUCLID) return pf_launch2<SE_METRIC_EUCLID>(epi, sym, gallery, lda, queries, ldq, sqg, sqq, n_a, n_q, kp, fa, s);
+    if (metric == SE_METRIC_COSINE) return pf_launch2<SE_METRIC_COSINE>(epi, sym, gallery, lda, queries, ldq, sqg, sqq, n_a, n_q, kp, ctl_g, ctl_q, fa, s);
+    if (metric == SE_METRIC_EUCLID) return pf_launch2<SE_METRIC_EUCLID>(epi, sym, gallery, lda, queries, ldq, sqg, sqq, n_a, n_q, kp, ctl_g, ctl_q, fa, s);
     return fail(SE_ERR_UNSUPPORTED, "pre-filter pass: metric %d", metric);
 }
 

@@ -107,17 +107,19 @@ int64_t pdist_max_ld();
 // ---- bf16 pre-filter of the fused distance + top-k (prefilter.hip; driver and exact refinement: topk.hip) ----
 constexpr int PF_EPI_GROUPMIN = 1, PF_EPI_FILTER = 2, PF_EPI_STORE = 3;
 struct PfPassArgs {
-    float *gm; int64_t gm_ld;          // sample pass: [queries, gm_ld] group minima of d~
+    float *gm; int64_t gm_ld;          // sample pass: [queries, gm_ld] group minima of d~ (d~: the half-precision distance)
     const float *thr;                  // filter pass: [queries] thresholds (NaN: only NaN values pass)
     unsigned *rowcnt; uint2 *lists; int64_t cap;
     int64_t sqa_stride;
     float *out; int64_t ldo;           // PF_EPI_STORE (tuning build): d~ matrix [gallery rows, queries]
 };
 int pf_padded_dim(int64_t d);
-// fp32 rows -> bf16 rows [n, pf_padded_dim(d)] + per-row norm of the bf16 image / of the rounding residual (upper bounds; NaN for
-// irregular rows, whose image is all NaN) + ctl[0..2] = max image norm bits, max residual norm bits, irregular rows (caller zeroes ctl)
+// fp32 rows -> scaled fp16 rows [n, pf_padded_dim(d)] + per-row norm of the image / of the rounding residual (upper bounds; NaN for
+// irregular rows, whose image is all NaN) + ctl[0..4] = max image norm bits, max residual norm bits, irregular rows, largest regular
+// magnitude bits, scale exponent (caller zeroes the 8-word ctl block)
 int pf_convert(const float *x, int64_t ldx, int64_t n, int64_t d, uint16_t *out, float *nrm, float *res, unsigned *ctl, hipStream_t s);
+// ctl_g / ctl_q: the ctl blocks pf_convert filled for the two operand matrices (word 4 = the image's scale exponent)
 int pf_pass(int epi, bool sym, int metric, const uint16_t *gallery, int64_t lda, const uint16_t *queries, int64_t ldq, const float *sqg,
-            const float *sqq, int64_t n_a, int64_t n_q, int kp, const PfPassArgs &pa, hipStream_t s);
+            const float *sqq, int64_t n_a, int64_t n_q, int kp, const unsigned *ctl_g, const unsigned *ctl_q, const PfPassArgs &pa, hipStream_t s);
 
 }  // namespace se

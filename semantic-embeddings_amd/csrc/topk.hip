@@ -843,11 +843,11 @@ constexpr int PF_K_MAX = RF_MAX / 2;
 // thr / eps per query from the group minima of the sample pass.  hq, rq: norm of the query's bf16 image / of its rounding residual
 // (upper bounds, NaN for irregular rows); gctl[0..1]: float bits of the maxima of the same two norms over the gallery.
 //   |a.b - a~.b~| = |a~.rb + ra.b~ + ra.rb| <= hq RG + rq HG + rq RG                      (Cauchy-Schwarz on the ACTUAL residuals)
-//   matrix-core accumulation: each v_mfma_f32_32x32x16_bf16 is assumed to return C + sum of its 16 products with an absolute error
-//     <= 2^-18 (|C| + sum |products|) -- 17 addends aligned to the largest and truncated to 24 bits would give 17 * 2^-23; IEEE
-//     rounding of the exact sum 2^-24.  kp / 16 instructions, |C| and the products bounded by hq HG.     [assumption A1, tested on the GPU]
+//   matrix-core accumulation: each v_mfma_f32_32x32x16_f16 is assumed to return C + sum of its 16 products with an absolute error
+//     <= 2^-20 (|C| + sum |products|) -- IEEE rounding of the exact sum would give 2^-24; measured on gfx950 over adversarial operands
+//     (tests/test_gpu_topk.py): 2^-24.4 worst case.  kp / 16 instructions, |C| and the products bounded by hq HG.   [assumption A1, tested on the GPU]
 //   the canonical chain itself: |chain - a.b| <= (d + nkb + 2) 2^-24 sum |a_k b_k| <= ... (hq + rq)(HG + RG)
-//   denormal bf16 inputs / fp32 outputs flushed by the matrix core: <= kp 2^-126 (hq + HG + 1)
+//   fp32 denormal outputs flushed by the matrix core: <= kp 2^-126 (hq + HG + 1) (denormal fp16 INPUTS do not exist: the images flush them)
 //   Euclidean epilogue fl(fl(sa + sb) - 2 v): 2 eps_v + 2^-21 ((hq + rq) + (HG + RG))^2
 __global__ __launch_bounds__(256) void pf_thr_kernel(const float *__restrict__ gm, int64_t gm_ld, int64_t Q, int G, int j, const float *__restrict__ qn,
                                                      const float *__restrict__ qr, const unsigned *__restrict__ gctl, int metric, int d, int kp,
@@ -869,7 +869,7 @@ __global__ __launch_bounds__(256) void pf_thr_kernel(const float *__restrict__ g
         const float tau = key == 0xFFFFFFFFu ? __builtin_nanf("") : key_to_float(key);
         const float hq = qn[q], rq = qr[q], HG = __uint_as_float(gctl[0]), RG = __uint_as_float(gctl[1]);
         const float e_round = hq * RG + rq * HG + rq * RG;
-        const float e_acc = (float)(kp / 16) * 3.8147e-6f * 1.01f * (hq * HG);
+        const float e_acc = (float)(kp / 16) * 9.5368e-7f * 1.01f * (hq * HG);
         const float e_chain = (float)(d + nkb + 2) * 5.9605e-8f * 1.01f * ((hq + rq) * (HG + RG));
         const float e_flush = (float)kp * 1.1755e-38f * (hq + HG + 1.0f);
         float e = (e_round + e_acc + e_chain + e_flush) * 1.01f;
@@ -1154,20 +1154,22 @@ static int retrieve_topk_prefilter(const float *queries, int64_t ldq, const floa
                          !tuning_env("SE_TOPK_NOSYM");
         const uint16_t *qi = gimg;
         const float *qn = gnrm, *qr = gres;
+        const unsigned *qc = ctl;
         if (!sym) {
-            if (const int rc = pf_convert(qs, ldq, rows, d, qimg, qnrm, qres, ctl + 4, s)) return rc;
-            qi = qimg; qn = qnrm; qr = qres;
+            SE_HIP_CHECK(hipMemsetAsync(ctl + 8, 0, 32, s));
+            if (const int rc = pf_convert(qs, ldq, rows, d, qimg, qnrm, qres, ctl + 8, s)) return rc;
+            qi = qimg; qn = qnrm; qr = qres; qc = ctl + 8;
         }
         unsigned *nflag = rowcnt + rows;                               // [1] queries handed to the exact kernel; [2..3] statistics (tuning)
         SE_HIP_CHECK(hipMemsetAsync(rowcnt, 0, (size_t)rows * 4 + 16, s));
         PfPassArgs pa = {gm, p.G, thr, rowcnt, lists, L.cap, p.step, nullptr, 0};
-        int rc = pf_pass(PF_EPI_GROUPMIN, false, metric, gimg, p.step * (int64_t)kp, qi, kp, sqg, sq, p.S, rows, kp, pa, s);
+        int rc = pf_pass(PF_EPI_GROUPMIN, false, metric, gimg, p.step * (int64_t)kp, qi, kp, sqg, sq, p.S, rows, kp, ctl, qc, pa, s);
         if (rc != SE_OK) return rc;
         hipLaunchKernelGGL(pf_thr_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, gm, (int64_t)p.G, rows, p.G, p.j, qn, qr, ctl, metric, (int)d, kp,
                            kbs.n, thr, eps);
         SE_LAUNCH_CHECK();
         pa.sqa_stride = 1;
-        rc = pf_pass(PF_EPI_FILTER, sym, metric, gimg, kp, qi, kp, sqg, sq, n, rows, kp, pa, s);
+        rc = pf_pass(PF_EPI_FILTER, sym, metric, gimg, kp, qi, kp, sqg, sq, n, rows, kp, ctl, qc, pa, s);
         if (rc != SE_OK) return rc;
         const bool verbose = kTuning && tuning_env("SE_TOPK_VERBOSE");
         const int64_t rgrid = (rows + RF_WAVES - 1) / RF_WAVES < 8192 ? (rows + RF_WAVES - 1) / RF_WAVES : 8192;
@@ -1326,9 +1328,9 @@ extern "C" int se_tuning_prefilter_probe(const float *queries, int64_t ldq, cons
     SE_HIP_CHECK(hipMemsetAsync(ctl, 0, 256, s));
     SE_HIP_CHECK(hipMemsetAsync(gm, 0, (size_t)q * 4, s));
     if (const int rc = pf_convert(gallery, ldg, n, d, gimg, gnrm, gres, ctl, s)) return rc;
-    if (const int rc = pf_convert(queries, ldq, q, d, qimg, qnrm, qres, ctl + 4, s)) return rc;
+    if (const int rc = pf_convert(queries, ldq, q, d, qimg, qnrm, qres, ctl + 8, s)) return rc;
     PfPassArgs pa = {nullptr, 0, nullptr, nullptr, nullptr, 0, 1, out_dt, ldo};
-    if (const int rc = pf_pass(PF_EPI_STORE, false, metric, gimg, kp, qimg, kp, sqg, sqq, n, q, kp, pa, s)) return rc;
+    if (const int rc = pf_pass(PF_EPI_STORE, false, metric, gimg, kp, qimg, kp, sqg, sqq, n, q, kp, ctl, ctl + 8, pa, s)) return rc;
     hipLaunchKernelGGL(pf_thr_kernel, dim3((unsigned)((q + 3) / 4)), dim3(256), 0, s, gm, (int64_t)1, q, 1, 1, qnrm, qres, ctl, metric, (int)d, kp, nkb, thr, out_eps);
     SE_LAUNCH_CHECK();
     return SE_OK;
