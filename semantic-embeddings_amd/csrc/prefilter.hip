@@ -45,7 +45,6 @@ constexpr int PF_PITCH = PF_ROWB + 16;                      // LDS row pitch in 
 constexpr int PF_NLOAD = PF_BM * PF_ROWB / 16 / PF_THREADS; // 16-byte pieces per operand per thread (8)
 constexpr int PF_PPR = PF_ROWB / 16;                        // pieces per row (16)
 constexpr int PF_WGS_PER_CU = 2;
-constexpr int PF_GROUP_M = 16;
 
 constexpr int PF_GROUPMIN = PF_EPI_GROUPMIN, PF_FILTER = PF_EPI_FILTER, PF_STORE = PF_EPI_STORE;
 
@@ -55,6 +54,7 @@ struct PfArgs {
     unsigned *rowcnt; uint2 *lists; int64_t cap;
     int64_t sqa_stride;                // Euclidean epilogue: |a|^2 of gallery row r is sqa[r * sqa_stride]
     float *out; int64_t ldo;           // PF_STORE
+    unsigned long long *prof;          // tuning build: phase cycle counters (SE_PF_PROFILE=1)
 };
 
 // ---- conversion ---------------------------------------------------------------------------------------------------------------
@@ -168,31 +168,6 @@ __device__ __forceinline__ float pf_finish(float v, float sa, float sb)
     return v;
 }
 
-// linear tile index -> tile origin (same walks as pdist_mfma.hip: "16 tile-rows deep" grouped order / upper triangle row-major)
-template <bool SYM>
-__device__ __forceinline__ void pf_tile_coords(uint32_t t, int tiles_m, int tiles_n, int &tm_out, int &tn_out)
-{
-    if (SYM) {
-        const double T = (double)tiles_n;
-        int32_t tm = (int32_t)(((2.0 * T + 1.0) - sqrt((2.0 * T + 1.0) * (2.0 * T + 1.0) - 8.0 * (double)t)) * 0.5);
-        if (tm < 0) tm = 0;
-        if (tm > tiles_m - 1) tm = tiles_m - 1;
-        while (tm > 0 && (uint32_t)tm * (uint32_t)tiles_n - (uint32_t)tm * (uint32_t)(tm - 1) / 2u > t) tm--;
-        while ((uint32_t)(tm + 1) * (uint32_t)tiles_n - (uint32_t)(tm + 1) * (uint32_t)tm / 2u <= t) tm++;
-        const uint32_t off = (uint32_t)tm * (uint32_t)tiles_n - (uint32_t)tm * (uint32_t)(tm - 1) / 2u;
-        tm_out = tm;
-        tn_out = (int)((uint32_t)tm + (t - off));
-        return;
-    }
-    const uint32_t per_group = (uint32_t)PF_GROUP_M * (uint32_t)tiles_n;
-    const uint32_t group = t / per_group, in_g = t - group * per_group;
-    const uint32_t first_m = group * PF_GROUP_M;
-    const uint32_t gsz = ((uint32_t)tiles_m - first_m < (uint32_t)PF_GROUP_M) ? ((uint32_t)tiles_m - first_m) : (uint32_t)PF_GROUP_M;
-    const uint32_t col_t = in_g / gsz;
-    tm_out = (int)(first_m + (in_g - col_t * gsz));
-    tn_out = (int)col_t;
-}
-
 // global -> registers: chunk [k0, k0 + 128) of rows [row0, row0 + 128) of an fp16 matrix with pitch `ld` elements (multiple of 128 columns,
 // 16-byte aligned rows).  Rows beyond nrows are clamped (read twice, ignored by the epilogues): no masking anywhere in the loop.
 __device__ __forceinline__ void pf_load(uint4 (&v)[PF_NLOAD], const uint16_t *__restrict__ src, uint32_t ld, int64_t row0, int64_t nrows, int k0)
@@ -219,47 +194,63 @@ __device__ __forceinline__ void pf_stage(char *lds, const uint4 (&v)[PF_NLOAD])
     }
 }
 
-template <int METRIC, bool SYM, int EPI>
+// ---- tile loop ------------------------------------------------------------------------------------------------------------------
+// Work is cut into JOBS = (query tile, gallery sub-range): a workgroup keeps ONE tile of 128 queries and walks the gallery tiles
+// t0 + j, t0 + j + gj, ... of one of `parts` contiguous gallery ranges.  Why query-stationary:
+//   * a query's candidates of one job are appended by ONE workgroup: the slot counters live in LDS (a returning LDS atomic instead of
+//     a global round trip in every tile epilogue) and the job's sub-list [query][sub-list][cap] fills front to back from one XCD, so its
+//     lines are completed in that XCD's L2 instead of being written 8 bytes at a time from eight L2s;
+//   * all-pairs calls need no mirrored pass (the first version walked the upper triangle and filtered every tile in both orientations:
+//     two global atomic round trips per tile, 3.2 ms of a 4.4 ms call at 50k x 50k x 100 with the matrix pipe 1 % busy; the matrix
+//     work saved was that 1 %).
+// Which jobs run TOGETHER is what the L2 sees.  The workgroups resident on one XCD (blockIdx % 8 selects the XCD) form a gi x gj
+// grid and take one SUPER-JOB = (gi consecutive query tiles) x (one gallery range) at a time: workgroup (i, j) owns query tile i and the
+// gallery tiles j, j + gj, ... -- at any moment the XCD works on gi query panels and gj gallery tiles, every panel is streamed by gj
+// (resp. gi) workgroups at about the same K position, and only 1 / gi (1 / gj) of those reads leave the L2.  (One workgroup per query
+// tile walking a whole range alone -- the first query-stationary version -- made every workgroup stream a private query panel out of
+// Infinity Cache: 31.8 ms for the D = 1000 shard against 25.7 ms of the grouped order it replaced.)
+// A query's list therefore consists of parts * gj sub-lists.
+struct PfJob { int sj, p, tn, t, t1; };
+
+__device__ __forceinline__ bool pf_next_job(PfJob &jb, int step, int nsq, int nsuper, int gi, int gj, int i, int j, int tiles_m, int tiles_n, int tpp)
+{
+    // advance to this workgroup's next super-job in which it has a query tile AND at least one gallery tile
+    for (int sj = jb.sj + step; sj < nsuper; sj += 8) {
+        const int p = sj / nsq, tq = sj - p * nsq;
+        const int tn = tq * gi + i;
+        const int t0 = p * tpp;
+        const int t1 = t0 + tpp < tiles_m ? t0 + tpp : tiles_m;
+        if (tn < tiles_n && t0 + j < t1) { jb.sj = sj; jb.p = p; jb.tn = tn; jb.t = t0 + j; jb.t1 = t1; return true; }
+    }
+    return false;
+}
+
+template <int METRIC, int EPI>
 __global__ __launch_bounds__(PF_THREADS, PF_WGS_PER_CU) void pf_tile_kernel(
     const uint16_t *__restrict__ A, uint32_t lda, const uint16_t *__restrict__ B, uint32_t ldb, const float *__restrict__ sqa,
-    const float *__restrict__ sqb, int64_t NA, int64_t NB, int nchunks, int tiles_m, int tiles_n, int64_t ntiles, const unsigned *__restrict__ ctl_a,
-    const unsigned *__restrict__ ctl_b, PfArgs fa)
+    const float *__restrict__ sqb, int64_t NA, int64_t NB, int nchunks, int tiles_m, int tiles_n, int parts, int tpp, int gi, int gj,
+    const unsigned *__restrict__ ctl_a, const unsigned *__restrict__ ctl_b, PfArgs fa)
 {
-    static_assert(EPI != PF_GROUPMIN || !SYM, "the sample pass walks the general tile order");
     extern __shared__ __attribute__((aligned(16))) char pf_smem[];
     char *sA = pf_smem, *sB = pf_smem + PF_BM * PF_PITCH;
-    // per-tile side arrays (filled together with the tile's first chunk, i.e. between the two barriers in front of its first MFMA phase,
-    // and read by its epilogue): thresholds of the tile's query columns / (all-pairs) query rows, |.|^2 of its gallery rows / query columns
-    float *tThrCol = (float *)(pf_smem + (PF_BM + PF_BN) * PF_PITCH), *tThrRow = tThrCol + PF_BN, *tSqRow = tThrRow + PF_BM, *tSqCol = tSqRow + PF_BM;
-#define PF_SIDE(M0, N0)                                                                                              \
-    if (EPI != PF_STORE || METRIC == SE_METRIC_EUCLID) {                                                             \
-        const int t_ = threadIdx.x;                                                                                  \
-        if (t_ < PF_BN) {                                                                                            \
-            const int64_t qc_ = (N0) + t_;                                                                           \
-            const bool ok_ = qc_ < NB;                                                                               \
-            if (EPI == PF_FILTER) tThrCol[t_] = ok_ ? fa.thr[qc_] : -__builtin_inff();                               \
-            if (METRIC == SE_METRIC_EUCLID) tSqCol[t_] = sqb[ok_ ? qc_ : NB - 1];                                    \
-        } else {                                                                                                     \
-            const int64_t gr_ = (M0) + (t_ - PF_BN);                                                                 \
-            const bool ok_ = gr_ < NA;                                                                               \
-            if (EPI == PF_FILTER && SYM) tThrRow[t_ - PF_BN] = ok_ ? fa.thr[gr_] : -__builtin_inff();                \
-            if (METRIC == SE_METRIC_EUCLID) tSqRow[t_ - PF_BN] = sqa[(ok_ ? gr_ : NA - 1) * fa.sqa_stride];          \
-        }                                                                                                            \
-    }
+    // side arrays.  Per job (query columns): tCmpCol = the constant the raw accumulator is compared with, tSqCol = |q|^2, jobCnt = slot counters;
+    // per tile (gallery rows): tSqRow = |g|^2, tCmpRow = its share of the Euclidean compare constant
+    float *tCmpCol = (float *)(pf_smem + (PF_BM + PF_BN) * PF_PITCH), *tSqCol = tCmpCol + PF_BN, *tSqRow = tSqCol + PF_BN, *tCmpRow = tSqRow + PF_BM;
+    unsigned *jobCnt = (unsigned *)(tCmpRow + PF_BM);
 
-    // ---- this workgroup's tile list: XCD-contiguous band, round-robin inside the XCD ----
-    const int64_t b = blockIdx.x, G = gridDim.x;
-    const int64_t xcd = b & 7, qq = ntiles >> 3, rr = ntiles & 7;
-    const int64_t band_beg = (xcd < rr) ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq;
-    const int64_t band_len = qq + (xcd < rr ? 1 : 0);
-    const int64_t wg_in_xcd = b >> 3, wgs_per_xcd = (G + 7 - xcd) >> 3;
-    const int64_t my_tiles = (band_len > wg_in_xcd) ? (band_len - wg_in_xcd + wgs_per_xcd - 1) / wgs_per_xcd : 0;
-    if (my_tiles == 0) return;
+    const int xcd = blockIdx.x & 7, slot_in_xcd = blockIdx.x >> 3;
+    const int gi_i = slot_in_xcd / gj, gj_j = slot_in_xcd - gi_i * gj;
+    const int nsq = (tiles_n + gi - 1) / gi, nsuper = nsq * parts;
+    const int nsub = parts * gj;                                    // sub-lists per query
+    PfJob cur = {xcd - 8, 0, 0, 0, 0};
+    if (gi_i >= gi || !pf_next_job(cur, 8, nsq, nsuper, gi, gj, gi_i, gj_j, tiles_m, tiles_n, tpp)) return;
+    PfJob nx = cur;
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1;        // 2 x 2 waves, 64 x 64 outputs each
-    const float unscale = ldexpf(1.0f, -((int)ctl_a[4] + (int)ctl_b[4]));     // the images carry 2^ea, 2^eb: exact to undo
     const int col = lane & 31, hi = lane >> 5;
+    const int esum = (int)ctl_a[4] + (int)ctl_b[4];
+    const float unscale = ldexpf(1.0f, -esum), rescale = ldexpf(1.0f, esum);     // the images carry 2^ea, 2^eb: exact to undo
 
     pf_f32x16 acc[2][2];
 #pragma unroll
@@ -273,38 +264,70 @@ __global__ __launch_bounds__(PF_THREADS, PF_WGS_PER_CU) void pf_tile_kernel(
     const char *pb = sB + (wn * 64 + col) * PF_PITCH + hi * 16;
 
     uint4 ra[PF_NLOAD], rb[PF_NLOAD];
-    int tm, tn;
-    pf_tile_coords<SYM>((uint32_t)(band_beg + wg_in_xcd), tiles_m, tiles_n, tm, tn);
-    int64_t m0 = (int64_t)tm * PF_BM, n0 = (int64_t)tn * PF_BN;
-    pf_load(ra, A, lda, m0, NA, 0);
-    pf_load(rb, B, ldb, n0, NB, 0);
+    pf_load(ra, A, lda, (int64_t)cur.t * PF_BM, NA, 0);
+    pf_load(rb, B, ldb, (int64_t)cur.tn * PF_BN, NB, 0);
 
-    const int64_t total = my_tiles * nchunks;
+    // Compare constants: a value passes when d~ <= thr (or d~ is NaN).  With a = the raw accumulator (a 2^-esum = the dot product):
+    //   cosine     d~ = -a 2^-esum <= thr                     <=>  a >= -thr 2^esum                       =: tCmpCol[q]
+    //   Euclidean  d~ = (sg + sq) - 2 a 2^-esum <= thr        <=>  a >= (sq - thr) 2^(esum-1) + sg 2^(esum-1)  =: tCmpCol[q] + tCmpRow[g]
+    // (powers of two: exact; the one rounding of the Euclidean sum is covered by the 0.05 eps the thresholds carry above the 2 eps needed).
+    // "not less than" is true for NaN accumulators (irregular rows); a NaN / invalid threshold becomes +inf: nothing but NaN passes.
+#define PF_JOB_SIDE(TN_)                                                                                             \
+    if (threadIdx.x < PF_BN) {                                                                                       \
+        const int64_t qc_ = (int64_t)(TN_) * PF_BN + threadIdx.x;                                                    \
+        const bool ok_ = qc_ < NB;                                                                                   \
+        const float sq_ = METRIC == SE_METRIC_EUCLID ? sqb[ok_ ? qc_ : NB - 1] : 0.f;                                \
+        if (EPI == PF_FILTER) {                                                                                      \
+            const float th_ = ok_ ? fa.thr[qc_] : __builtin_nanf("");                                                \
+            float c_ = METRIC == SE_METRIC_EUCLID ? (sq_ - th_) * (0.5f * rescale) : -th_ * rescale;                 \
+            tCmpCol[threadIdx.x] = c_ == c_ ? c_ : __builtin_inff();                                                 \
+            jobCnt[threadIdx.x] = 0;                                                                                 \
+        }                                                                                                            \
+        if (METRIC == SE_METRIC_EUCLID) tSqCol[threadIdx.x] = sq_;                                                   \
+    }
+#define PF_TILE_SIDE(T_)                                                                                             \
+    if (METRIC == SE_METRIC_EUCLID && threadIdx.x >= PF_BN) {                                                        \
+        const int64_t gr_ = (int64_t)(T_) * PF_BM + (threadIdx.x - PF_BN);                                           \
+        const float sg_ = sqa[(gr_ < NA ? gr_ : NA - 1) * fa.sqa_stride];                                            \
+        tSqRow[threadIdx.x - PF_BN] = sg_;                                                                           \
+        tCmpRow[threadIdx.x - PF_BN] = sg_ * (0.5f * rescale);                                                       \
+    }
+#ifdef SE_TUNING
+    uint64_t t_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_last = fa.prof ? __builtin_amdgcn_s_memtime() : 0;
+#define PF_T(i) if (fa.prof) { const uint64_t now = __builtin_amdgcn_s_memtime(); t_acc[i] += now - t_last; t_last = now; }
+#else
+#define PF_T(i)
+#endif
     int c = 0;
-    uint32_t tile_i = 0;
-    int64_t cur_m0 = m0, cur_n0 = n0;
     pf_stage(sA, ra);
     pf_stage(sB, rb);
-    PF_SIDE(m0, n0)
+    PF_JOB_SIDE(cur.tn)
+    PF_TILE_SIDE(cur.t)
     __syncthreads();
+    bool more = true;
 #pragma unroll 1
-    for (int64_t it = 0; it < total; it++) {
-        // ---- request the next chunk (same tile or first chunk of the next tile) ----
+    while (more) {
+        PF_T(0)
+        // ---- request the next chunk: same tile, next tile of the job, or first tile of this workgroup's next job ----
         const bool last_chunk = (c + 1 == nchunks);
-        const bool have_next = it + 1 < total;
-        if (have_next) {
-            const int nc = last_chunk ? 0 : c + 1;
-            if (nc == 0) {
-                pf_tile_coords<SYM>((uint32_t)(band_beg + wg_in_xcd) + (tile_i + 1u) * (uint32_t)wgs_per_xcd, tiles_m, tiles_n, tm, tn);
-                m0 = (int64_t)tm * PF_BM; n0 = (int64_t)tn * PF_BN;
+        bool have_next = true, job_ends = false;
+        int nc = c + 1;
+        if (last_chunk) {
+            nc = 0;
+            nx.t = cur.t + gj;
+            if (nx.t >= cur.t1) {
+                job_ends = true;
+                have_next = pf_next_job(nx, 8, nsq, nsuper, gi, gj, gi_i, gj_j, tiles_m, tiles_n, tpp);
             }
-            pf_load(ra, A, lda, m0, NA, nc * PF_BK);
-            pf_load(rb, B, ldb, n0, NB, nc * PF_BK);
         }
+        if (have_next) {
+            pf_load(ra, A, lda, (int64_t)nx.t * PF_BM, NA, nc * PF_BK);
+            pf_load(rb, B, ldb, (int64_t)nx.tn * PF_BN, NB, nc * PF_BK);
+        }
+        PF_T(1)
         // ---- MFMA over the chunk in LDS: 8 steps of k = 16 ----
 #pragma unroll
         for (int s = 0; s < PF_BK / 16; s++) {
-            if (s == PF_BK / 32) asm volatile("" ::: "memory");       // two groups of 4 steps: all 32 operand reads hoisted at once cost 128 registers
             f16x8 a0 = __builtin_bit_cast(f16x8, *(const uint4 *)(pa + s * 32));
             f16x8 a1 = __builtin_bit_cast(f16x8, *(const uint4 *)(pa + 32 * PF_PITCH + s * 32));
             f16x8 b0 = __builtin_bit_cast(f16x8, *(const uint4 *)(pb + s * 32));
@@ -314,16 +337,18 @@ __global__ __launch_bounds__(PF_THREADS, PF_WGS_PER_CU) void pf_tile_kernel(
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc[1][1], 0, 0, 0);
         }
+        PF_T(2)
         // the next chunk's operands are waited for HERE (value barriers: no use of a loaded register in front of the MFMA phase)
 #pragma unroll
         for (int i = 0; i < PF_NLOAD; i++) {
             asm volatile("" : "+v"(ra[i].x), "+v"(ra[i].y), "+v"(ra[i].z), "+v"(ra[i].w));
             asm volatile("" : "+v"(rb[i].x), "+v"(rb[i].y), "+v"(rb[i].z), "+v"(rb[i].w));
         }
-
+        PF_T(3)
         if (last_chunk) {
             // ---- tile finished.  acc[mi][j][r]: gallery row  cur_m0 + wm*64 + mi*32 + (r&3) + 8*(r>>2) + 4*hi,
             //                                      query       cur_n0 + wn*64 + j*32 + col ----
+            const int64_t cur_m0 = (int64_t)cur.t * PF_BM, cur_n0 = (int64_t)cur.tn * PF_BN;
             const int rows_here = (int)((NA - cur_m0 < PF_BM) ? (NA - cur_m0) : PF_BM);
             const int cols_here = (int)((NB - cur_n0 < PF_BN) ? (NB - cur_n0) : PF_BN);
             const bool full_rows = rows_here == PF_BM;
@@ -367,133 +392,70 @@ __global__ __launch_bounds__(PF_THREADS, PF_WGS_PER_CU) void pf_tile_kernel(
                     }
                 }
             } else {
-                // ---- PF_FILTER, orientation 1: lanes = queries (tile columns), registers = gallery rows ----
-                int64_t qgj[2];
-                float thrj[2], sbqj[2];
-                unsigned cntj[2], slotj[2];
+                // ---- PF_FILTER.  Lanes = queries (tile columns), registers = gallery rows: 2 queries x 32 values per lane, ~1 % of them
+                //      candidates.  The scan costs TWO vector instructions per value and nothing else:
+                //        v_cmp_nlt_f32  vcc, acc, c        (the raw accumulator against the query's constant; true for NaN)
+                //        v_addc_co_u32  mask, mask, mask   (mask = 2 mask + vcc)
+                //      -> a 32-bit pass mask per (lane, query), value i = mi * 16 + r at bit 31 - i.  Slots of the job's sub-list come from
+                //      ONE returning LDS atomic per (lane, query).  The rare candidates are then visited bit by bit: registers cannot be
+                //      indexed per lane, so the wave's accumulators are dumped into the operand LDS (free between this tile's last MFMA
+                //      and the next stage; 16 ds_write_b128 per lane, lane-private rows of 64 + 4 dwords) and read back by index.
+                //      (Before: a compare, an exec-mask block and a branch per VALUE, ~50 cycles each: 67 % of the kernel at D = 100.) ----
+                uint32_t mask[2] = {0u, 0u};
 #pragma unroll
                 for (int j = 0; j < 2; j++) {
-                    const int lc = wn * 64 + j * 32 + col;
-                    const bool qok = lc < cols_here;
-                    qgj[j] = cur_n0 + (qok ? lc : cols_here - 1);
-                    thrj[j] = tThrCol[lc];
-                    sbqj[j] = METRIC == SE_METRIC_EUCLID ? tSqCol[lc] : 0.f;
-                }
-#define PF_PASS1(V, J, LR) ((((V) <= thrj[J]) || ((V) != (V))) && (full_rows || (LR) < rows_here) && (wn * 64 + (J) * 32 + col < cols_here))
-#pragma unroll
-                for (int j = 0; j < 2; j++) {
-                    const float sbq = sbqj[j];
-                    unsigned cnt = 0;
+                    const float cq = tCmpCol[wn * 64 + j * 32 + col];
 #pragma unroll
                     for (int mi = 0; mi < 2; mi++)
 #pragma unroll
                         for (int r = 0; r < 16; r++) {
-                            const int lr = lr0 + mi * 32 + (r & 3) + 8 * (r >> 2);
-                            const float v = PF_VAL(mi, j, r);
-                            cnt += PF_PASS1(v, j, lr) ? 1u : 0u;
+                            float cmpv = cq;
+                            if (METRIC == SE_METRIC_EUCLID) cmpv = cq + tCmpRow[lr0 + mi * 32 + (r & 3) + 8 * (r >> 2)];
+                            asm volatile("v_cmp_nlt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mask[j]) : "v"(acc[mi][j][r]), "v"(cmpv) : "vcc");
                         }
-                    cntj[j] = cnt;
                 }
+                if (!full_rows) {       // last gallery tile: rows beyond the gallery were clamped reads
+                    uint32_t vm = 0u;
+#pragma unroll
+                    for (int i = 0; i < 32; i++) vm |= (lr0 + (i >> 4) * 32 + (i & 3) + 8 * ((i >> 2) & 3) < rows_here) ? (0x80000000u >> i) : 0u;
+                    mask[0] &= vm; mask[1] &= vm;
+                }
+                unsigned slotj[2];
 #pragma unroll
                 for (int j = 0; j < 2; j++) {
+                    if (wn * 64 + j * 32 + col >= cols_here) mask[j] = 0u;
                     slotj[j] = 0;
-                    if (cntj[j]) slotj[j] = atomicAdd(&fa.rowcnt[qgj[j]], cntj[j]);
+                    if (mask[j]) slotj[j] = atomicAdd(&jobCnt[wn * 64 + j * 32 + col], (unsigned)__popc(mask[j]));
                 }
-                asm volatile("" : "+v"(slotj[0]), "+v"(slotj[1]));     // ONE wait for both reservations
+                PF_T(4)
+                __syncthreads();       // every wave is done with the operands of the last chunk: their LDS becomes the dump
+                float *mine = (float *)pf_smem + threadIdx.x * 68;
+#pragma unroll
+                for (int j = 0; j < 2; j++)
+#pragma unroll
+                    for (int mi = 0; mi < 2; mi++)
+#pragma unroll
+                        for (int g = 0; g < 4; g++)
+                            *(float4 *)(mine + j * 32 + mi * 16 + g * 4) = make_float4(acc[mi][j][4 * g], acc[mi][j][4 * g + 1], acc[mi][j][4 * g + 2], acc[mi][j][4 * g + 3]);
+                PF_T(5)
 #pragma unroll
                 for (int j = 0; j < 2; j++) {
-                    if (cntj[j]) {
-                        const float sbq = sbqj[j];
-                        unsigned slot = slotj[j];
-                        uint2 *lst = fa.lists + qgj[j] * fa.cap;
-#pragma unroll
-                        for (int mi = 0; mi < 2; mi++)
-#pragma unroll
-                            for (int r = 0; r < 16; r++) {
-                                const int lr = lr0 + mi * 32 + (r & 3) + 8 * (r >> 2);
-                                const float v = PF_VAL(mi, j, r);
-                                if (PF_PASS1(v, j, lr)) {
-                                    if (slot < (unsigned)fa.cap) lst[slot] = make_uint2(__float_as_uint(v), (uint32_t)(cur_m0 + lr));
-                                    slot++;
-                                }
-                            }
+                    uint32_t m = mask[j];
+                    unsigned slot = slotj[j];
+                    const int lc = wn * 64 + j * 32 + col;
+                    uint2 *lst = fa.lists + ((cur_n0 + lc) * (int64_t)nsub + (cur.p * gj + gj_j)) * fa.cap;
+                    const float sbq = METRIC == SE_METRIC_EUCLID ? tSqCol[lc] : 0.f;
+                    while (m) {
+                        const int i = __builtin_clz(m);                                   // value index: mi = i >> 4, r = i & 15
+                        m &= ~(0x80000000u >> i);
+                        const int lr = lr0 + (i >> 4) * 32 + (i & 3) + 8 * ((i >> 2) & 3);
+                        const float a = mine[j * 32 + i];
+                        const float v = pf_finish<METRIC>(a * unscale, METRIC == SE_METRIC_EUCLID ? tSqRow[lr] : 0.f, sbq);
+                        if (slot < (unsigned)fa.cap) lst[slot] = make_uint2(__float_as_uint(v), (uint32_t)(cur_m0 + lr));
+                        slot++;
                     }
                 }
-#undef PF_PASS1
-                if (SYM && cur_m0 != cur_n0) {
-                    // ---- orientation 2 (all-pairs call, off-diagonal tile): queries = tile ROWS, gallery items = tile columns.  Per
-                    //      register r a 64-lane ballot holds the verdicts of TWO query rows (lanes 0-31: row ..+0, lanes 32-63: row ..+4)
-                    //      x 32 gallery columns.  Row R of the wave's 64 rows is owned by lane R for the slot reservation:
-                    //      R = mi*32 + (r&3) + 8*(r>>2) + 4*h.  Counts -> one returning atomic per lane, ONE wait, then the stores. ----
-                    const int gc0 = wn * 64 + col;                              // this lane's gallery column of block j: gc0 + 32 j
-                    unsigned mycnt = 0;
-                    // thresholds / norms of this lane's 2 x 16 query rows come out of the tile's side arrays one 32-row block at a time
-                    // (16 + 16 live registers; a compiler fence between the blocks keeps the second block's reads behind the first's use)
-                    float sbc[2];
-#pragma unroll
-                    for (int j = 0; j < 2; j++) sbc[j] = METRIC == SE_METRIC_EUCLID ? tSqCol[gc0 + 32 * j] : 0.f;
-                    const bool c0ok = gc0 < cols_here, c1ok = gc0 + 32 < cols_here;
-#define PF_ROWS2(MI_)                                                                                                        \
-    float t2[16], s2[16];                                                                                                    \
-    _Pragma("unroll") for (int r = 0; r < 16; r++) {                                                                         \
-        t2[r] = tThrRow[lr0 + (MI_) * 32 + (r & 3) + 8 * (r >> 2)];                                                          \
-        s2[r] = METRIC == SE_METRIC_EUCLID ? tSqRow[lr0 + (MI_) * 32 + (r & 3) + 8 * (r >> 2)] : 0.f;                        \
-    }
-#define PF_VAL2(MI_, J, R) pf_finish<METRIC>(acc[MI_][J][R] * unscale, s2[R], sbc[J])
-#define PF_PASS2(V, R, OK) ((((V) <= t2[R]) || ((V) != (V))) && (OK))
-#pragma unroll
-                    for (int mi = 0; mi < 2; mi++) {
-                        asm volatile("" ::: "memory");
-                        PF_ROWS2(mi)
-#pragma unroll
-                        for (int r = 0; r < 16; r++) {
-                            const float v0 = PF_VAL2(mi, 0, r), v1 = PF_VAL2(mi, 1, r);
-                            const uint64_t b0 = __ballot(PF_PASS2(v0, r, c0ok)), b1 = __ballot(PF_PASS2(v1, r, c1ok));
-                            const unsigned clo = (unsigned)__popc((uint32_t)b0) + (unsigned)__popc((uint32_t)b1);
-                            const unsigned chi = (unsigned)__popc((uint32_t)(b0 >> 32)) + (unsigned)__popc((uint32_t)(b1 >> 32));
-                            const int R0 = mi * 32 + (r & 3) + 8 * (r >> 2);
-                            mycnt = lane == R0 ? clo : mycnt;
-                            mycnt = lane == R0 + 4 ? chi : mycnt;
-                        }
-                    }
-                    // lane R reserves for query row  cur_m0 + wm*64 + R
-                    const int myrow = wm * 64 + lane;
-                    unsigned myslot = 0;
-                    if (mycnt) myslot = atomicAdd(&fa.rowcnt[cur_m0 + myrow], mycnt);
-                    asm volatile("" : "+v"(myslot));
-#pragma unroll
-                    for (int mi = 0; mi < 2; mi++) {
-                        asm volatile("" ::: "memory");
-                        PF_ROWS2(mi)
-#pragma unroll
-                        for (int r = 0; r < 16; r++) {
-                            const float v0 = PF_VAL2(mi, 0, r), v1 = PF_VAL2(mi, 1, r);
-                            const bool p0 = PF_PASS2(v0, r, c0ok), p1 = PF_PASS2(v1, r, c1ok);
-                            const uint64_t b0 = __ballot(p0), b1 = __ballot(p1);
-                            if ((b0 | b1) == 0ull) continue;                                     // uniform: most rows of most tiles
-                            const int R0 = mi * 32 + (r & 3) + 8 * (r >> 2);
-                            const unsigned base_lo = (unsigned)__builtin_amdgcn_readlane((int)myslot, R0);
-                            const unsigned base_hi = (unsigned)__builtin_amdgcn_readlane((int)myslot, R0 + 4);
-                            // position inside this row's reservation: block 0's passing lanes (of my half) first, then block 1's
-                            const uint32_t h0 = hi ? (uint32_t)(b0 >> 32) : (uint32_t)b0, h1 = hi ? (uint32_t)(b1 >> 32) : (uint32_t)b1;
-                            const uint32_t below = (1u << col) - 1u;
-                            const unsigned base = hi ? base_hi : base_lo;
-                            const int64_t qrow = cur_m0 + wm * 64 + R0 + 4 * hi;
-                            uint2 *lst = fa.lists + qrow * fa.cap;
-                            if (p0) {
-                                const unsigned slot = base + (unsigned)__popc(h0 & below);
-                                if (slot < (unsigned)fa.cap) lst[slot] = make_uint2(__float_as_uint(v0), (uint32_t)(cur_n0 + gc0));
-                            }
-                            if (p1) {
-                                const unsigned slot = base + (unsigned)__popc(h0) + (unsigned)__popc(h1 & below);
-                                if (slot < (unsigned)fa.cap) lst[slot] = make_uint2(__float_as_uint(v1), (uint32_t)(cur_n0 + gc0 + 32));
-                            }
-                        }
-                    }
-#undef PF_ROWS2
-#undef PF_VAL2
-#undef PF_PASS2
-                }
+                PF_T(6)
             }
 #undef PF_VAL
 #undef PF_SA
@@ -504,17 +466,34 @@ __global__ __launch_bounds__(PF_THREADS, PF_WGS_PER_CU) void pf_tile_kernel(
 #pragma unroll
                     for (int r = 0; r < 16; r++) acc[mi][j][r] = 0.f;
         }
-        __syncthreads();   // every wave has finished reading this chunk out of LDS
+        __syncthreads();   // every wave has finished reading this chunk out of LDS (and, at a tile's end, its epilogue)
+        PF_T(10)
+        if (last_chunk && job_ends && EPI == PF_FILTER && threadIdx.x < PF_BN) {
+            // the job is complete: its slot counters -> rowcnt[query][sub-list] (counts above the capacity mark an overflow: the query is redone)
+            const int64_t qc = (int64_t)cur.tn * PF_BN + threadIdx.x;
+            if (qc < NB) fa.rowcnt[qc * nsub + (cur.p * gj + gj_j)] = jobCnt[threadIdx.x];
+        }
         if (have_next) {
-            cur_m0 = m0; cur_n0 = n0;
             pf_stage(sA, ra);
             pf_stage(sB, rb);
-            if (last_chunk) { PF_SIDE(m0, n0) }
+            if (last_chunk) {
+                if (job_ends) { PF_JOB_SIDE(nx.tn) }
+                PF_TILE_SIDE(nx.t)
+                cur = nx;
+            }
         }
         __syncthreads();
         c = last_chunk ? 0 : c + 1;
-        tile_i += last_chunk ? 1u : 0u;
+        more = have_next;
+        PF_T(11)
     }
+#ifdef SE_TUNING
+    if (fa.prof && threadIdx.x == 0)
+        for (int i = 0; i < 12; i++) atomicAdd(&fa.prof[i], (unsigned long long)t_acc[i]);
+#endif
+#undef PF_T
+#undef PF_JOB_SIDE
+#undef PF_TILE_SIDE
 }
 
 static int pf_num_cus()
@@ -528,39 +507,87 @@ static int pf_num_cus()
     return cus;
 }
 
-template <int METRIC, bool SYM, int EPI>
-static int pf_launch3(const uint16_t *a, int64_t lda, const uint16_t *b, int64_t ldb, const float *sqa, const float *sqb, int64_t na, int64_t nb,
-                      int kp, const unsigned *ctl_a, const unsigned *ctl_b, const PfArgs &fa, hipStream_t s)
+static int64_t pf_grid()
 {
-    const int tiles_m = (int)((na + PF_BM - 1) / PF_BM), tiles_n = (int)((nb + PF_BN - 1) / PF_BN);
-    const int64_t ntiles = SYM ? ((int64_t)tiles_n * (tiles_n + 1) / 2) : ((int64_t)tiles_m * tiles_n);
-    if (ntiles >= ((int64_t)1 << 31) || (int64_t)PF_GROUP_M * tiles_n >= ((int64_t)1 << 31) || (SYM && tiles_n > 65535))
-        return fail(SE_ERR_UNSUPPORTED, "se_retrieve_topk: %lld pre-filter tiles exceed the 32-bit tile counter", (long long)ntiles);
+    int64_t grid = (int64_t)pf_num_cus() * PF_WGS_PER_CU;
+    return grid / 8 * 8 > 0 ? grid / 8 * 8 : 8;
+}
+
+// geometry of a pass over n_a gallery rows x n_q queries: the gi x gj grid of workgroups per XCD (gi query tiles x gj interleaved
+// gallery tile sequences per super-job) and the number of contiguous gallery ranges `parts` (>= ~4 super-job rounds per XCD)
+PfGeom pf_geometry(int64_t n_a, int64_t n_q, int want_parts)
+{
+    const int64_t tiles_m = (n_a + PF_BM - 1) / PF_BM, tiles_n = (n_q + PF_BN - 1) / PF_BN;
+    const int per_xcd = (int)(pf_grid() / 8);
+    PfGeom g;
+    g.gi = 8;
+    while (g.gi > 1 && (g.gi > tiles_n || per_xcd % g.gi)) g.gi >>= 1;          // few queries: fewer query tiles side by side, more gallery sequences
+    g.gj = per_xcd / g.gi;
+    if (g.gj > tiles_m) g.gj = (int)tiles_m;
+    if (g.gj < 1) g.gj = 1;
+    const int64_t nsq = (tiles_n + g.gi - 1) / g.gi;
+    int64_t parts = want_parts > 0 ? want_parts : (4 * 8 + nsq - 1) / nsq;
+    if (const char *e = tuning_env("SE_PF_PARTS")) parts = atoi(e);
+    const int64_t max_parts = tiles_m / g.gj > 0 ? tiles_m / g.gj : 1;             // every range holds >= gj tiles
+    if (parts > max_parts) parts = max_parts;
+    if (parts * g.gj > 256) parts = 256 / g.gj > 0 ? 256 / g.gj : 1;
+    if (parts < 1) parts = 1;
+    g.parts = (int)parts;
+    g.tpp = (int)((tiles_m + parts - 1) / parts);
+    g.parts = (int)((tiles_m + g.tpp - 1) / g.tpp);
+    return g;
+}
+
+template <int METRIC, int EPI>
+static int pf_launch3(const uint16_t *a, int64_t lda, const uint16_t *b, int64_t ldb, const float *sqa, const float *sqb, int64_t na, int64_t nb,
+                      int kp, const PfGeom &g, const unsigned *ctl_a, const unsigned *ctl_b, const PfArgs &fa, hipStream_t s)
+{
+    const int64_t tiles_m = (na + PF_BM - 1) / PF_BM, tiles_n = (nb + PF_BN - 1) / PF_BN;
+    if (g.gi < 1 || g.gj < 1 || g.parts < 1 || (int64_t)g.tpp * g.parts < tiles_m || g.gj > g.tpp)
+        return fail(SE_ERR_INVALID, "pre-filter pass: geometry %d x %d, %d parts of %d tiles does not cover %lld gallery tiles", g.gi, g.gj, g.parts, g.tpp, (long long)tiles_m);
+    if (tiles_m * tiles_n >= ((int64_t)1 << 31))
+        return fail(SE_ERR_UNSUPPORTED, "se_retrieve_topk: %lld pre-filter tiles exceed the 32-bit tile counter", (long long)(tiles_m * tiles_n));
     if (lda * 2 * PF_BM >= ((int64_t)1 << 32) || ldb * 2 * PF_BN >= ((int64_t)1 << 32))
         return fail(SE_ERR_UNSUPPORTED, "se_retrieve_topk: pre-filter row pitch too large for 32-bit tile offsets");
-    const size_t lds = (size_t)(PF_BM + PF_BN) * PF_PITCH + (size_t)(2 * PF_BM + 2 * PF_BN) * sizeof(float);
-    int64_t grid = (int64_t)pf_num_cus() * PF_WGS_PER_CU;
-    grid = grid / 8 * 8;
-    if (grid > ntiles) grid = ntiles;
-    if (grid < 1) grid = 1;
-    auto kern = pf_tile_kernel<METRIC, SYM, EPI>;
+    const size_t lds = (size_t)(PF_BM + PF_BN) * PF_PITCH + (size_t)(2 * PF_BM + 3 * PF_BN) * sizeof(float);
+    const int64_t grid = (int64_t)8 * g.gi * g.gj;
+    auto kern = pf_tile_kernel<METRIC, EPI>;
     SE_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    PfArgs fb = fa;
+    fb.prof = nullptr;
+    static const bool profile = tuning_env("SE_PF_PROFILE") != nullptr;   // -DSE_TUNING build only: allocates, synchronises, prints
+    if (profile) {
+        SE_HIP_CHECK(hipMalloc((void **)&fb.prof, 12 * sizeof(unsigned long long)));
+        SE_HIP_CHECK(hipMemsetAsync(fb.prof, 0, 12 * sizeof(unsigned long long), s));
+    }
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(PF_THREADS), lds, s, a, (uint32_t)lda, b, (uint32_t)ldb, sqa, sqb, na, nb, kp / PF_BK,
-                       tiles_m, tiles_n, ntiles, ctl_a, ctl_b, fa);
+                       (int)tiles_m, (int)tiles_n, g.parts, g.tpp, g.gi, g.gj, ctl_a, ctl_b, fb);
     SE_LAUNCH_CHECK();
+    if (profile) {
+        unsigned long long h[12];
+        SE_HIP_CHECK(hipStreamSynchronize(s));
+        SE_HIP_CHECK(hipMemcpy(h, fb.prof, sizeof(h), hipMemcpyDeviceToHost));
+        SE_HIP_CHECK(hipFree(fb.prof));
+        static const char *names[12] = {"loop-top", "prefetch-issue", "mfma", "wait-loads", "scan+reserve", "barrier+dump", "candidates", "-", "-", "-", "barrier",
+                                        "stage+barrier"};
+        double tot = 0;
+        for (int i = 0; i < 12; i++) tot += (double)h[i];
+        fprintf(stderr, "[pf_tile_kernel profile] metric=%d epi=%d grid=%lld (8 x %d x %d) tiles=%lld x %lld chunks=%d parts=%d:", METRIC, EPI, (long long)grid,
+                g.gi, g.gj, (long long)tiles_m, (long long)tiles_n, kp / PF_BK, g.parts);
+        for (int i = 0; i < 12; i++) if (names[i][0] != '-') fprintf(stderr, " %s %.1f%%", names[i], 100.0 * (double)h[i] / tot);
+        fprintf(stderr, "  (%.0f cycles per tile per workgroup)\n", tot / (double)(tiles_m * tiles_n));
+    }
     return SE_OK;
 }
-#undef PF_SIDE
 
 template <int METRIC>
-static int pf_launch2(int epi, bool sym, const uint16_t *a, int64_t lda, const uint16_t *b, int64_t ldb, const float *sqa, const float *sqb,
-                      int64_t na, int64_t nb, int kp, const unsigned *ca, const unsigned *cb, const PfArgs &fa, hipStream_t s)
+static int pf_launch2(int epi, const uint16_t *a, int64_t lda, const uint16_t *b, int64_t ldb, const float *sqa, const float *sqb,
+                      int64_t na, int64_t nb, int kp, const PfGeom &g, const unsigned *ca, const unsigned *cb, const PfArgs &fa, hipStream_t s)
 {
-    if (epi == PF_GROUPMIN) return pf_launch3<METRIC, false, PF_GROUPMIN>(a, lda, b, ldb, sqa, sqb, na, nb, kp, ca, cb, fa, s);
-    if (epi == PF_FILTER) return sym ? pf_launch3<METRIC, true, PF_FILTER>(a, lda, b, ldb, sqa, sqb, na, nb, kp, ca, cb, fa, s)
-                                      : pf_launch3<METRIC, false, PF_FILTER>(a, lda, b, ldb, sqa, sqb, na, nb, kp, ca, cb, fa, s);
+    if (epi == PF_GROUPMIN) return pf_launch3<METRIC, PF_GROUPMIN>(a, lda, b, ldb, sqa, sqb, na, nb, kp, g, ca, cb, fa, s);
+    if (epi == PF_FILTER) return pf_launch3<METRIC, PF_FILTER>(a, lda, b, ldb, sqa, sqb, na, nb, kp, g, ca, cb, fa, s);
 #ifdef SE_TUNING
-    if (epi == PF_STORE) return pf_launch3<METRIC, false, PF_STORE>(a, lda, b, ldb, sqa, sqb, na, nb, kp, ca, cb, fa, s);
+    if (epi == PF_STORE) return pf_launch3<METRIC, PF_STORE>(a, lda, b, ldb, sqa, sqb, na, nb, kp, g, ca, cb, fa, s);
 #endif
     return fail(SE_ERR_UNSUPPORTED, "pre-filter pass %d", epi);
 }
@@ -580,14 +607,15 @@ int pf_convert(const float *x, int64_t ldx, int64_t n, int64_t d, uint16_t *out,
     return SE_OK;
 }
 
-int pf_pass(int epi, bool sym, int metric, const uint16_t *gallery, int64_t lda, const uint16_t *queries, int64_t ldq, const float *sqg,
+int pf_pass(int epi, const PfGeom *geom, int metric, const uint16_t *gallery, int64_t lda, const uint16_t *queries, int64_t ldq, const float *sqg,
             const float *sqq, int64_t n_a, int64_t n_q, int kp, const unsigned *ctl_g, const unsigned *ctl_q, const PfPassArgs &pa, hipStream_t s)
 {
     PfArgs fa;
     fa.gm = pa.gm; fa.gm_ld = pa.gm_ld; fa.thr = pa.thr; fa.rowcnt = pa.rowcnt; fa.lists = pa.lists; fa.cap = pa.cap;
-    fa.sqa_stride = pa.sqa_stride; fa.out = pa.out; fa.ldo = pa.ldo;
-    if (metric == SE_METRIC_COSINE) return pf_launch2<SE_METRIC_COSINE>(epi, sym, gallery, lda, queries, ldq, sqg, sqq, n_a, n_q, kp, ctl_g, ctl_q, fa, s);
-    if (metric == SE_METRIC_EUCLID) return pf_launch2<SE_METRIC_EUCLID>(epi, sym, gallery, lda, queries, ldq, sqg, sqq, n_a, n_q, kp, ctl_g, ctl_q, fa, s);
+    fa.sqa_stride = pa.sqa_stride; fa.out = pa.out; fa.ldo = pa.ldo; fa.prof = nullptr;
+    const PfGeom g = geom ? *geom : pf_geometry(n_a, n_q, 1);
+    if (metric == SE_METRIC_COSINE) return pf_launch2<SE_METRIC_COSINE>(epi, gallery, lda, queries, ldq, sqg, sqq, n_a, n_q, kp, g, ctl_g, ctl_q, fa, s);
+    if (metric == SE_METRIC_EUCLID) return pf_launch2<SE_METRIC_EUCLID>(epi, gallery, lda, queries, ldq, sqg, sqq, n_a, n_q, kp, g, ctl_g, ctl_q, fa, s);
     return fail(SE_ERR_UNSUPPORTED, "pre-filter pass: metric %d", metric);
 }
 

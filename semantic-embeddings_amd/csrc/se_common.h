@@ -109,7 +109,7 @@ constexpr int PF_EPI_GROUPMIN = 1, PF_EPI_FILTER = 2, PF_EPI_STORE = 3;
 struct PfPassArgs {
     float *gm; int64_t gm_ld;          // sample pass: [queries, gm_ld] group minima of d~ (d~: the half-precision distance)
     const float *thr;                  // filter pass: [queries] thresholds (NaN: only NaN values pass)
-    unsigned *rowcnt; uint2 *lists; int64_t cap;
+    unsigned *rowcnt; uint2 *lists; int64_t cap;     // cap: entries per (query, sub-list)
     int64_t sqa_stride;
     float *out; int64_t ldo;           // PF_EPI_STORE (tuning build): d~ matrix [gallery rows, queries]
 };
@@ -119,7 +119,13 @@ int pf_padded_dim(int64_t d);
 // magnitude bits, scale exponent (caller zeroes the 8-word ctl block)
 int pf_convert(const float *x, int64_t ldx, int64_t n, int64_t d, uint16_t *out, float *nrm, float *res, unsigned *ctl, hipStream_t s);
 // ctl_g / ctl_q: the ctl blocks pf_convert filled for the two operand matrices (word 4 = the image's scale exponent)
-int pf_pass(int epi, bool sym, int metric, const uint16_t *gallery, int64_t lda, const uint16_t *queries, int64_t ldq, const float *sqg,
+// geometry of a pass (prefilter.hip): the workgroups resident on an XCD form a gi x gj grid and take (gi query tiles) x (one of `parts`
+// contiguous gallery ranges of `tpp` tiles) at a time, workgroup (i, j) walking the range's tiles j, j + gj, ...  A query's candidates of
+// (range p, sequence j) go to sub-list p * gj + j:  lists[(query * nsub + sub) * cap ...], their number to rowcnt[query * nsub + sub],
+// nsub = parts * gj.  want_parts = 0: as many ranges as keep every XCD busy for >= ~4 rounds.
+struct PfGeom { int gi, gj, parts, tpp; };
+PfGeom pf_geometry(int64_t n_a, int64_t n_q, int want_parts);
+int pf_pass(int epi, const PfGeom *geom, int metric, const uint16_t *gallery, int64_t lda, const uint16_t *queries, int64_t ldq, const float *sqg,
             const float *sqq, int64_t n_a, int64_t n_q, int kp, const unsigned *ctl_g, const unsigned *ctl_q, const PfPassArgs &pa, hipStream_t s);
 
 }  // namespace se

@@ -923,7 +923,7 @@ __device__ __forceinline__ float rf_chain(const float *__restrict__ g, const flo
 }
 
 template <int METRIC, bool VEC>
-__global__ __launch_bounds__(RF_WAVES * 64) void pf_refine_kernel(const uint2 *__restrict__ lists, const unsigned *__restrict__ rowcnt, int64_t cap, int64_t Q,
+__global__ __launch_bounds__(RF_WAVES * 64) void pf_refine_kernel(const uint2 *__restrict__ lists, const unsigned *__restrict__ rowcnt, int64_t cap, int parts, int64_t Q,
                                                                   const float *__restrict__ thr, const float *__restrict__ eps,
                                                                   const float *__restrict__ queries, int64_t ldq, const float *__restrict__ gallery,
                                                                   int64_t ldg, const float *__restrict__ sqq, const float *__restrict__ sqg,
@@ -938,9 +938,17 @@ __global__ __launch_bounds__(RF_WAVES * 64) void pf_refine_kernel(const uint2 *_
     uint64_t *comp = comp_all[wave];
     for (int64_t row = (int64_t)blockIdx.x * RF_WAVES + wave; row < Q; row += (int64_t)gridDim.x * RF_WAVES) {
         const int64_t urow = __builtin_amdgcn_readfirstlane((int)row);          // (Q < 2^31: the launcher checks)
-        const unsigned total = rowcnt[urow];
-        bool ok = total >= (unsigned)k && total <= (unsigned)cap;
-        const uint2 *lst = lists + urow * cap;
+        // the query's candidates: `parts` sub-lists (one per gallery range of the filter pass) of up to `cap` entries each
+        const uint2 *lst = lists + urow * parts * cap;
+        const unsigned *cnts = rowcnt + urow * parts;
+        unsigned total = 0;
+        bool ok = true;
+        for (int p = 0; p < parts; p++) {
+            const unsigned c = cnts[p];
+            ok = ok && c <= (unsigned)cap;
+            total += c;
+        }
+        ok = ok && total >= (unsigned)k;
         uint32_t m = 0;
         float B = 0.f;
         const float e_q = eps[urow], thr_q = thr[urow];
@@ -952,9 +960,13 @@ __global__ __launch_bounds__(RF_WAVES * 64) void pf_refine_kernel(const uint2 *_
 #pragma unroll
                 for (int i = 0; i < 4; i++) hist[lane * 4 + i] = 0;
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                for (unsigned e = lane; e < total; e += 64) {
-                    const uint32_t key = canon_key(__uint_as_float(lst[e].x));
-                    if ((key & pmask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+                for (int p = 0; p < parts; p++) {
+                    const uint2 *lp = lst + p * cap;
+                    const unsigned cp = cnts[p];
+                    for (unsigned e = lane; e < cp; e += 64) {
+                        const uint32_t key = canon_key(__uint_as_float(lp[e].x));
+                        if ((key & pmask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+                    }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 uint32_t c[4], local = 0;
@@ -988,15 +1000,19 @@ __global__ __launch_bounds__(RF_WAVES * 64) void pf_refine_kernel(const uint2 *_
                 B = b1 < thr_q ? b1 : thr_q;
                 const uint32_t bkey = canon_key(B);
                 // ---- R: entries with d~ <= B, plus every NaN d~ ----
-                for (unsigned e0 = 0; e0 < total; e0 += 64) {
-                    const unsigned e = e0 + lane;
-                    const uint2 c = lst[e < total ? e : 0];
-                    const uint32_t key = canon_key(__uint_as_float(c.x));
-                    const bool take = e < total && (key <= bkey || key == 0xFFFFFFFFu);
-                    const uint64_t bm = __ballot(take);
-                    const uint32_t pos = m + __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
-                    if (take && pos < (uint32_t)RF_MAX) sel[pos] = c.y;
-                    m += (uint32_t)__popcll(bm);
+                for (int p = 0; p < parts; p++) {
+                    const uint2 *lp = lst + p * cap;
+                    const unsigned cp = cnts[p];
+                    for (unsigned e0 = 0; e0 < cp; e0 += 64) {
+                        const unsigned e = e0 + lane;
+                        const uint2 c = lp[e < cp ? e : 0];
+                        const uint32_t key = canon_key(__uint_as_float(c.x));
+                        const bool take = e < cp && (key <= bkey || key == 0xFFFFFFFFu);
+                        const uint64_t bm = __ballot(take);
+                        const uint32_t pos = m + __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
+                        if (take && pos < (uint32_t)RF_MAX) sel[pos] = c.y;
+                        m += (uint32_t)__popcll(bm);
+                    }
                 }
                 ok = m <= (uint32_t)RF_MAX;
             }
@@ -1075,7 +1091,9 @@ static int64_t topk_qtile(int64_t q, int64_t n)
 // fused path: query rows per pass (candidate lists + group minima of <= 4 GiB) and the workspace layout
 struct FusedLayout {
     int64_t qt, off_tau, off_cnt, off_gm, off_lists, off_scratch, total;
-    // bf16 pre-filter path only
+    // pre-filter path only (parts: sub-lists per query, cap: entries per sub-list, geom: the filter pass's job geometry)
+    int parts;
+    PfGeom geom;
     int64_t cap, off_eps, off_ctl, off_gimg, off_gnrm, off_gres, off_qimg, off_qnrm, off_qres;
     int kp;
 };
@@ -1089,20 +1107,30 @@ static FusedLayout fused_layout(int64_t q, int64_t n, int64_t d, const FusedPlan
 {
     FusedLayout L = {};
     L.cap = p.cap;
-    if (pf) {   // the bf16 thresholds admit a window of 4 eps more than the exact ones the plan was made for
-        L.cap = align256((int64_t)p.cap * 3 / 2);
-        if (const char *e = tuning_env("SE_TOPK_CAP")) L.cap = atoi(e);
+    L.parts = 1;
+    int64_t qt;
+    if (pf) {
+        // the half-precision thresholds admit a window of 4 eps more than the exact ones the plan was made for: 1.5x the planned total,
+        // cut into the filter pass's gallery parts (+ room for the relative fluctuation of a small share)
+        L.geom = pf_geometry(n, q, 0);
+        L.parts = L.geom.parts * L.geom.gj;
+        const int64_t total_cap = align256((int64_t)p.cap * 3 / 2);
+        L.cap = (total_cap / L.parts + 32 + 15) / 16 * 16;
+        if (const char *e = tuning_env("SE_TOPK_CAP")) L.cap = atoi(e) / L.parts > 0 ? atoi(e) / L.parts : 1;
+        const int64_t per_row = L.parts * (L.cap * 8 + 4) + (int64_t)p.G * 4 + 16;
+        qt = ((int64_t)4 << 30) / per_row / 128 * 128;
+    } else {
+        const int64_t per_row = L.cap * 8 + (int64_t)p.G * 4 + 16;
+        qt = ((int64_t)4 << 30) / per_row / 128 * 128;
     }
-    const int64_t per_row = L.cap * 8 + (int64_t)p.G * 4 + 16;
-    int64_t qt = ((int64_t)4 << 30) / per_row / 128 * 128;
     if (qt < 128) qt = 128;
     if (qt > q) qt = q;
     L.qt = qt;
     L.off_tau = 0;
     L.off_cnt = align256(qt * 4);
-    L.off_gm = L.off_cnt + align256(qt * 4 + 16);       // [qt] candidate counts + 4 control words (flagged-query counters)
+    L.off_gm = L.off_cnt + align256(qt * L.parts * 4 + 16);       // [qt (x parts)] candidate counts + 4 control words (flagged-query counters)
     L.off_lists = L.off_gm + align256(qt * p.G * 4);
-    L.off_scratch = L.off_lists + align256(qt * L.cap * 8);
+    L.off_scratch = L.off_lists + align256(qt * L.parts * L.cap * 8);
     L.total = L.off_scratch + align256((int64_t)FB_GRID * n * 4);
     if (pf) {
         L.kp = pf_padded_dim(d);
@@ -1149,9 +1177,8 @@ static int retrieve_topk_prefilter(const float *queries, int64_t ldq, const floa
         const int64_t rows = (q - q0 < L.qt) ? (q - q0) : L.qt;
         const float *qs = queries + q0 * ldq;
         const float *sq = sqq ? sqq + q0 : nullptr;
-        // all-pairs call: every item is query and gallery item -- one image, upper-triangle walk, both orientations filtered
-        const bool sym = (qs == gallery) && (ldq == ldg) && (rows == n) && (metric != SE_METRIC_EUCLID || sq == sqg) && n > 128 &&
-                         !tuning_env("SE_TOPK_NOSYM");
+        // all-pairs call: every item is query and gallery item -- one image serves both sides
+        const bool sym = (qs == gallery) && (ldq == ldg) && (rows == n) && (metric != SE_METRIC_EUCLID || sq == sqg);
         const uint16_t *qi = gimg;
         const float *qn = gnrm, *qr = gres;
         const unsigned *qc = ctl;
@@ -1160,20 +1187,20 @@ static int retrieve_topk_prefilter(const float *queries, int64_t ldq, const floa
             if (const int rc = pf_convert(qs, ldq, rows, d, qimg, qnrm, qres, ctl + 8, s)) return rc;
             qi = qimg; qn = qnrm; qr = qres; qc = ctl + 8;
         }
-        unsigned *nflag = rowcnt + rows;                               // [1] queries handed to the exact kernel; [2..3] statistics (tuning)
-        SE_HIP_CHECK(hipMemsetAsync(rowcnt, 0, (size_t)rows * 4 + 16, s));
+        unsigned *nflag = rowcnt + rows * L.parts;                     // [1] queries handed to the exact kernel; [2..3] statistics (tuning)
+        SE_HIP_CHECK(hipMemsetAsync(rowcnt, 0, (size_t)rows * L.parts * 4 + 16, s));
         PfPassArgs pa = {gm, p.G, thr, rowcnt, lists, L.cap, p.step, nullptr, 0};
-        int rc = pf_pass(PF_EPI_GROUPMIN, false, metric, gimg, p.step * (int64_t)kp, qi, kp, sqg, sq, p.S, rows, kp, ctl, qc, pa, s);
+        int rc = pf_pass(PF_EPI_GROUPMIN, nullptr, metric, gimg, p.step * (int64_t)kp, qi, kp, sqg, sq, p.S, rows, kp, ctl, qc, pa, s);
         if (rc != SE_OK) return rc;
         hipLaunchKernelGGL(pf_thr_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, gm, (int64_t)p.G, rows, p.G, p.j, qn, qr, ctl, metric, (int)d, kp,
                            kbs.n, thr, eps);
         SE_LAUNCH_CHECK();
         pa.sqa_stride = 1;
-        rc = pf_pass(PF_EPI_FILTER, sym, metric, gimg, kp, qi, kp, sqg, sq, n, rows, kp, ctl, qc, pa, s);
+        rc = pf_pass(PF_EPI_FILTER, &L.geom, metric, gimg, kp, qi, kp, sqg, sq, n, rows, kp, ctl, qc, pa, s);
         if (rc != SE_OK) return rc;
         const bool verbose = kTuning && tuning_env("SE_TOPK_VERBOSE");
         const int64_t rgrid = (rows + RF_WAVES - 1) / RF_WAVES < 8192 ? (rows + RF_WAVES - 1) / RF_WAVES : 8192;
-#define SE_RF_LAUNCH(M, V) hipLaunchKernelGGL((pf_refine_kernel<M, V>), dim3((unsigned)rgrid), dim3(RF_WAVES * 64), 0, s, lists, rowcnt, L.cap, rows, thr, eps, qs, ldq, \
+#define SE_RF_LAUNCH(M, V) hipLaunchKernelGGL((pf_refine_kernel<M, V>), dim3((unsigned)rgrid), dim3(RF_WAVES * 64), 0, s, lists, rowcnt, L.cap, L.parts, rows, thr, eps, qs, ldq, \
                                               gallery, ldg, sq, sqg, kbs, col_offset, k, out_d + q0 * k, out_i + q0 * k, nflag, verbose ? nflag + 2 : nullptr)
         if (metric == SE_METRIC_COSINE) { if (vec) SE_RF_LAUNCH(SE_METRIC_COSINE, true); else SE_RF_LAUNCH(SE_METRIC_COSINE, false); }
         else { if (vec) SE_RF_LAUNCH(SE_METRIC_EUCLID, true); else SE_RF_LAUNCH(SE_METRIC_EUCLID, false); }
@@ -1187,9 +1214,9 @@ static int retrieve_topk_prefilter(const float *queries, int64_t ldq, const floa
             const double okq = (double)rows - (double)h[1];
             float gmaxn, gmaxr;
             memcpy(&gmaxn, &hc[0], 4); memcpy(&gmaxr, &hc[1], 4);
-            fprintf(stderr, "[se_retrieve_topk] prefilter: n=%lld d=%lld kp=%d k=%d S=%d G=%d j=%d cap=%lld rows=%lld sym=%d redo=%u mean_candidates=%.1f "
+            fprintf(stderr, "[se_retrieve_topk] prefilter: n=%lld d=%lld kp=%d k=%d S=%d G=%d j=%d parts=%d cap=%lld rows=%lld sym=%d redo=%u mean_candidates=%.1f "
                             "mean_recomputed=%.1f gallery_max_norm=%.4g max_residual=%.4g irregular_rows=%u\n",
-                    (long long)n, (long long)d, kp, k, p.S, p.G, p.j, (long long)L.cap, (long long)rows, (int)sym, h[1],
+                    (long long)n, (long long)d, kp, k, p.S, p.G, p.j, L.parts, (long long)L.cap, (long long)rows, (int)sym, h[1],
                     okq > 0 ? (double)h[3] / okq : 0.0, okq > 0 ? (double)h[2] / okq : 0.0, (double)gmaxn, (double)gmaxr, hc[2]);
         }
         const int64_t fgrid = rows < FB_GRID ? rows : FB_GRID;
@@ -1330,7 +1357,7 @@ extern "C" int se_tuning_prefilter_probe(const float *queries, int64_t ldq, cons
     if (const int rc = pf_convert(gallery, ldg, n, d, gimg, gnrm, gres, ctl, s)) return rc;
     if (const int rc = pf_convert(queries, ldq, q, d, qimg, qnrm, qres, ctl + 8, s)) return rc;
     PfPassArgs pa = {nullptr, 0, nullptr, nullptr, nullptr, 0, 1, out_dt, ldo};
-    if (const int rc = pf_pass(PF_EPI_STORE, false, metric, gimg, kp, qimg, kp, sqg, sqq, n, q, kp, ctl, ctl + 8, pa, s)) return rc;
+    if (const int rc = pf_pass(PF_EPI_STORE, nullptr, metric, gimg, kp, qimg, kp, sqg, sqq, n, q, kp, ctl, ctl + 8, pa, s)) return rc;
     hipLaunchKernelGGL(pf_thr_kernel, dim3((unsigned)((q + 3) / 4)), dim3(256), 0, s, gm, (int64_t)1, q, 1, 1, qnrm, qres, ctl, metric, (int)d, kp, nkb, thr, out_eps);
     SE_LAUNCH_CHECK();
     return SE_OK;
