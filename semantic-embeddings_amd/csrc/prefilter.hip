@@ -38,13 +38,17 @@ namespace se {
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float pf_f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int PF_BM = 128, PF_BN = 128, PF_BK = 128;       // tile, K-chunk (fp16 elements)
-constexpr int PF_THREADS = 256;
+#ifndef SE_PF_BM
+#define SE_PF_BM 128      // 256: 512-thread workgroups, one per CU (measured: 28.8 vs 26.6 ms on the D = 1000 shard -- with one workgroup per CU
+#endif                    // every wave is in the same phase at the same time and nothing overlaps the load bursts)
+constexpr int PF_BM = SE_PF_BM, PF_BN = 128, PF_BK = 128;   // tile (gallery rows x queries), K-chunk (fp16 elements)
+constexpr int PF_THREADS = PF_BM * 2;                       // (PF_BM / 64) x 2 waves of 64 x 64 outputs
 constexpr int PF_ROWB = PF_BK * 2;                          // bytes of one operand row of a chunk (256)
 constexpr int PF_PITCH = PF_ROWB + 16;                      // LDS row pitch in bytes: 68 dwords -> conflict-free ds_read_b128 over 16 rows
-constexpr int PF_NLOAD = PF_BM * PF_ROWB / 16 / PF_THREADS; // 16-byte pieces per operand per thread (8)
-constexpr int PF_PPR = PF_ROWB / 16;                        // pieces per row (16)
-constexpr int PF_WGS_PER_CU = 2;
+constexpr int PF_PPR = PF_ROWB / 16;                        // 16-byte pieces per row (16)
+constexpr int PF_NLOAD_A = PF_BM * PF_PPR / PF_THREADS;     // pieces per thread: gallery operand (8)
+constexpr int PF_NLOAD_B = PF_BN * PF_PPR / PF_THREADS;     // query operand (4)
+constexpr int PF_WGS_PER_CU = 256 / PF_BM;                  // 8 waves per CU, <= 256 registers each
 
 constexpr int PF_GROUPMIN = PF_EPI_GROUPMIN, PF_FILTER = PF_EPI_FILTER, PF_STORE = PF_EPI_STORE;
 
@@ -168,15 +172,17 @@ __device__ __forceinline__ float pf_finish(float v, float sa, float sb)
     return v;
 }
 
-// global -> registers: chunk [k0, k0 + 128) of rows [row0, row0 + 128) of an fp16 matrix with pitch `ld` elements (multiple of 128 columns,
-// 16-byte aligned rows).  Rows beyond nrows are clamped (read twice, ignored by the epilogues): no masking anywhere in the loop.
-__device__ __forceinline__ void pf_load(uint4 (&v)[PF_NLOAD], const uint16_t *__restrict__ src, uint32_t ld, int64_t row0, int64_t nrows, int k0)
+// global -> registers: chunk [k0, k0 + 128) of rows [row0, row0 + NL * 32) of an fp16 matrix with pitch `ld` elements (multiple of 128 columns,
+// 16-byte aligned rows; NL pieces per thread = NL * 32 rows).  Rows beyond nrows are clamped (read twice, ignored by the epilogues): no masking anywhere in the loop.
+template <int NL>
+__device__ __forceinline__ void pf_load(uint4 (&v)[NL], const uint16_t *__restrict__ src, uint32_t ld, int64_t row0, int64_t nrows, int k0)
 {
+    constexpr int ROWS = NL * PF_THREADS / PF_PPR;
     const int tid = threadIdx.x;
     const char *base = (const char *)(src + row0 * (int64_t)ld);       // uniform
-    const int rows_here = (int)((nrows - row0 < PF_BM) ? (nrows - row0) : PF_BM);
+    const int rows_here = (int)((nrows - row0 < ROWS) ? (nrows - row0) : ROWS);
 #pragma unroll
-    for (int i = 0; i < PF_NLOAD; i++) {
+    for (int i = 0; i < NL; i++) {
         const int p = tid + i * PF_THREADS;
         const int r = p / PF_PPR, c = p % PF_PPR;
         const int rc = r < rows_here ? r : rows_here - 1;
@@ -184,11 +190,30 @@ __device__ __forceinline__ void pf_load(uint4 (&v)[PF_NLOAD], const uint16_t *__
     }
 }
 
-__device__ __forceinline__ void pf_stage(char *lds, const uint4 (&v)[PF_NLOAD])
+// pieces [first, first + CNT) of the same chunk (loads dealt over the MFMA steps)
+template <int NL, int CNT>
+__device__ __forceinline__ void pf_load_part(uint4 (&v)[NL], int first, const uint16_t *__restrict__ src, uint32_t ld, int64_t row0, int64_t nrows, int k0)
+{
+    constexpr int ROWS = NL * PF_THREADS / PF_PPR;
+    const int tid = threadIdx.x;
+    const char *base = (const char *)(src + row0 * (int64_t)ld);
+    const int rows_here = (int)((nrows - row0 < ROWS) ? (nrows - row0) : ROWS);
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        if (i < first || i >= first + CNT) continue;
+        const int p = tid + i * PF_THREADS;
+        const int r = p / PF_PPR, c = p % PF_PPR;
+        const int rc = r < rows_here ? r : rows_here - 1;
+        v[i] = *(const uint4 *)(base + ((uint32_t)rc * ld * 2u + (uint32_t)k0 * 2u + (uint32_t)c * 16u));
+    }
+}
+
+template <int NL>
+__device__ __forceinline__ void pf_stage(char *lds, const uint4 (&v)[NL])
 {
     const int tid = threadIdx.x;
 #pragma unroll
-    for (int i = 0; i < PF_NLOAD; i++) {
+    for (int i = 0; i < NL; i++) {
         const int p = tid + i * PF_THREADS;
         *(uint4 *)(lds + (p / PF_PPR) * PF_PITCH + (p % PF_PPR) * 16) = v[i];
     }
@@ -237,6 +262,8 @@ __global__ __launch_bounds__(PF_THREADS, PF_WGS_PER_CU) void pf_tile_kernel(
     // per tile (gallery rows): tSqRow = |g|^2, tCmpRow = its share of the Euclidean compare constant
     float *tCmpCol = (float *)(pf_smem + (PF_BM + PF_BN) * PF_PITCH), *tSqCol = tCmpCol + PF_BN, *tSqRow = tSqCol + PF_BN, *tCmpRow = tSqRow + PF_BM;
     unsigned *jobCnt = (unsigned *)(tCmpRow + PF_BM);
+    static_assert(PF_THREADS * 36 * 4 <= (PF_BM + PF_BN) * PF_PITCH, "the epilogue's half dump must fit the operand LDS");
+    static_assert(PF_BN + PF_BM <= PF_THREADS, "side arrays are filled by one thread per entry");
 
     const int xcd = blockIdx.x & 7, slot_in_xcd = blockIdx.x >> 3;
     const int gi_i = slot_in_xcd / gj, gj_j = slot_in_xcd - gi_i * gj;
@@ -247,7 +274,7 @@ __global__ __launch_bounds__(PF_THREADS, PF_WGS_PER_CU) void pf_tile_kernel(
     PfJob nx = cur;
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = wave >> 1, wn = wave & 1;        // 2 x 2 waves, 64 x 64 outputs each
+    const int wm = wave >> 1, wn = wave & 1;        // (PF_BM / 64) x 2 waves, 64 x 64 outputs each
     const int col = lane & 31, hi = lane >> 5;
     const int esum = (int)ctl_a[4] + (int)ctl_b[4];
     const float unscale = ldexpf(1.0f, -esum), rescale = ldexpf(1.0f, esum);     // the images carry 2^ea, 2^eb: exact to undo
@@ -263,9 +290,9 @@ __global__ __launch_bounds__(PF_THREADS, PF_WGS_PER_CU) void pf_tile_kernel(
     const char *pa = sA + (wm * 64 + col) * PF_PITCH + hi * 16;     // block mi: + mi * 32 rows; k16 step s: + s * 32 bytes
     const char *pb = sB + (wn * 64 + col) * PF_PITCH + hi * 16;
 
-    uint4 ra[PF_NLOAD], rb[PF_NLOAD];
-    pf_load(ra, A, lda, (int64_t)cur.t * PF_BM, NA, 0);
-    pf_load(rb, B, ldb, (int64_t)cur.tn * PF_BN, NB, 0);
+    uint4 ra[PF_NLOAD_A], rb[PF_NLOAD_B];
+    pf_load<PF_NLOAD_A>(ra, A, lda, (int64_t)cur.t * PF_BM, NA, 0);
+    pf_load<PF_NLOAD_B>(rb, B, ldb, (int64_t)cur.tn * PF_BN, NB, 0);
 
     // Compare constants: a value passes when d~ <= thr (or d~ is NaN).  With a = the raw accumulator (a 2^-esum = the dot product):
     //   cosine     d~ = -a 2^-esum <= thr                     <=>  a >= -thr 2^esum                       =: tCmpCol[q]
@@ -286,7 +313,7 @@ __global__ __launch_bounds__(PF_THREADS, PF_WGS_PER_CU) void pf_tile_kernel(
         if (METRIC == SE_METRIC_EUCLID) tSqCol[threadIdx.x] = sq_;                                                   \
     }
 #define PF_TILE_SIDE(T_)                                                                                             \
-    if (METRIC == SE_METRIC_EUCLID && threadIdx.x >= PF_BN) {                                                        \
+    if (METRIC == SE_METRIC_EUCLID && threadIdx.x >= PF_BN && threadIdx.x < PF_BN + PF_BM) {                         \
         const int64_t gr_ = (int64_t)(T_) * PF_BM + (threadIdx.x - PF_BN);                                           \
         const float sg_ = sqa[(gr_ < NA ? gr_ : NA - 1) * fa.sqa_stride];                                            \
         tSqRow[threadIdx.x - PF_BN] = sg_;                                                                           \
@@ -299,8 +326,8 @@ __global__ __launch_bounds__(PF_THREADS, PF_WGS_PER_CU) void pf_tile_kernel(
 #define PF_T(i)
 #endif
     int c = 0;
-    pf_stage(sA, ra);
-    pf_stage(sB, rb);
+    pf_stage<PF_NLOAD_A>(sA, ra);
+    pf_stage<PF_NLOAD_B>(sB, rb);
     PF_JOB_SIDE(cur.tn)
     PF_TILE_SIDE(cur.t)
     __syncthreads();
@@ -320,14 +347,26 @@ __global__ __launch_bounds__(PF_THREADS, PF_WGS_PER_CU) void pf_tile_kernel(
                 have_next = pf_next_job(nx, 8, nsq, nsuper, gi, gj, gi_i, gj_j, tiles_m, tiles_n, tpp);
             }
         }
-        if (have_next) {
-            pf_load(ra, A, lda, (int64_t)nx.t * PF_BM, NA, nc * PF_BK);
-            pf_load(rb, B, ldb, (int64_t)nx.tn * PF_BN, NB, nc * PF_BK);
+#ifndef SE_PF_SPREAD
+#define SE_PF_SPREAD 0
+#endif
+        if (have_next && !SE_PF_SPREAD) {
+            pf_load<PF_NLOAD_A>(ra, A, lda, (int64_t)nx.t * PF_BM, NA, nc * PF_BK);
+            pf_load<PF_NLOAD_B>(rb, B, ldb, (int64_t)nx.tn * PF_BN, NB, nc * PF_BK);
         }
         PF_T(1)
         // ---- MFMA over the chunk in LDS: 8 steps of k = 16 ----
 #pragma unroll
         for (int s = 0; s < PF_BK / 16; s++) {
+#if SE_PF_SPREAD
+            // experiment: the next chunk's loads dealt over the MFMA steps instead of one burst in front of them
+            if (have_next) {
+                constexpr int PA = PF_NLOAD_A / (PF_BK / 16) > 0 ? PF_NLOAD_A / (PF_BK / 16) : 1, PB = PF_NLOAD_B / (PF_BK / 16) > 0 ? PF_NLOAD_B / (PF_BK / 16) : 1;
+                pf_load_part<PF_NLOAD_A, PA>(ra, s * PA, A, lda, (int64_t)nx.t * PF_BM, NA, nc * PF_BK);
+                pf_load_part<PF_NLOAD_B, PB>(rb, s * PB, B, ldb, (int64_t)nx.tn * PF_BN, NB, nc * PF_BK);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#endif
             f16x8 a0 = __builtin_bit_cast(f16x8, *(const uint4 *)(pa + s * 32));
             f16x8 a1 = __builtin_bit_cast(f16x8, *(const uint4 *)(pa + 32 * PF_PITCH + s * 32));
             f16x8 b0 = __builtin_bit_cast(f16x8, *(const uint4 *)(pb + s * 32));
@@ -336,14 +375,16 @@ __global__ __launch_bounds__(PF_THREADS, PF_WGS_PER_CU) void pf_tile_kernel(
             acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, acc[0][1], 0, 0, 0);
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc[1][1], 0, 0, 0);
+#if SE_PF_SPREAD
+            __builtin_amdgcn_sched_barrier(0);
+#endif
         }
         PF_T(2)
         // the next chunk's operands are waited for HERE (value barriers: no use of a loaded register in front of the MFMA phase)
 #pragma unroll
-        for (int i = 0; i < PF_NLOAD; i++) {
-            asm volatile("" : "+v"(ra[i].x), "+v"(ra[i].y), "+v"(ra[i].z), "+v"(ra[i].w));
-            asm volatile("" : "+v"(rb[i].x), "+v"(rb[i].y), "+v"(rb[i].z), "+v"(rb[i].w));
-        }
+        for (int i = 0; i < PF_NLOAD_A; i++) asm volatile("" : "+v"(ra[i].x), "+v"(ra[i].y), "+v"(ra[i].z), "+v"(ra[i].w));
+#pragma unroll
+        for (int i = 0; i < PF_NLOAD_B; i++) asm volatile("" : "+v"(rb[i].x), "+v"(rb[i].y), "+v"(rb[i].z), "+v"(rb[i].w));
         PF_T(3)
         if (last_chunk) {
             // ---- tile finished.  acc[mi][j][r]: gallery row  cur_m0 + wm*64 + mi*32 + (r&3) + 8*(r>>2) + 4*hi,
@@ -388,7 +429,8 @@ __global__ __launch_bounds__(PF_THREADS, PF_WGS_PER_CU) void pf_tile_kernel(
                             any = any || ok;
                         }
                         if (!any) m = __builtin_nanf("");     // a group of NaNs only: sorted last by the threshold kernel
-                        if (qok) fa.gm[qg * fa.gm_ld + (cur_m0 / PF_BM) * 8 + (wm * 2 + mi) * 2 + hi] = m;
+                        const int64_t grp = (cur_m0 / PF_BM) * (PF_BM / 16) + (wm * 2 + mi) * 2 + hi;     // 16 gallery rows per group minimum
+                        if (qok && grp < fa.gm_ld) fa.gm[qg * fa.gm_ld + grp] = m;
                     }
                 }
             } else {
@@ -429,18 +471,17 @@ __global__ __launch_bounds__(PF_THREADS, PF_WGS_PER_CU) void pf_tile_kernel(
                 }
                 PF_T(4)
                 __syncthreads();       // every wave is done with the operands of the last chunk: their LDS becomes the dump
-                float *mine = (float *)pf_smem + threadIdx.x * 68;
-#pragma unroll
-                for (int j = 0; j < 2; j++)
-#pragma unroll
-                    for (int mi = 0; mi < 2; mi++)
-#pragma unroll
-                        for (int g = 0; g < 4; g++)
-                            *(float4 *)(mine + j * 32 + mi * 16 + g * 4) = make_float4(acc[mi][j][4 * g], acc[mi][j][4 * g + 1], acc[mi][j][4 * g + 2], acc[mi][j][4 * g + 3]);
+                float *mine = (float *)pf_smem + threadIdx.x * 36;          // lane-private row of 32 + 4 dwords, one query's values at a time
                 PF_T(5)
 #pragma unroll
                 for (int j = 0; j < 2; j++) {
                     uint32_t m = mask[j];
+                    if (j) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // (the row is private: no barrier between the two halves)
+#pragma unroll
+                    for (int mi = 0; mi < 2; mi++)
+#pragma unroll
+                        for (int g = 0; g < 4; g++)
+                            *(float4 *)(mine + mi * 16 + g * 4) = make_float4(acc[mi][j][4 * g], acc[mi][j][4 * g + 1], acc[mi][j][4 * g + 2], acc[mi][j][4 * g + 3]);
                     unsigned slot = slotj[j];
                     const int lc = wn * 64 + j * 32 + col;
                     uint2 *lst = fa.lists + ((cur_n0 + lc) * (int64_t)nsub + (cur.p * gj + gj_j)) * fa.cap;
@@ -449,7 +490,7 @@ __global__ __launch_bounds__(PF_THREADS, PF_WGS_PER_CU) void pf_tile_kernel(
                         const int i = __builtin_clz(m);                                   // value index: mi = i >> 4, r = i & 15
                         m &= ~(0x80000000u >> i);
                         const int lr = lr0 + (i >> 4) * 32 + (i & 3) + 8 * ((i >> 2) & 3);
-                        const float a = mine[j * 32 + i];
+                        const float a = mine[i];
                         const float v = pf_finish<METRIC>(a * unscale, METRIC == SE_METRIC_EUCLID ? tSqRow[lr] : 0.f, sbq);
                         if (slot < (unsigned)fa.cap) lst[slot] = make_uint2(__float_as_uint(v), (uint32_t)(cur_m0 + lr));
                         slot++;

@@ -949,6 +949,49 @@ __global__ __launch_bounds__(RF_WAVES * 64) void pf_refine_kernel(const uint2 *_
             total += c;
         }
         ok = ok && total >= (unsigned)k;
+        // ---- lists of up to RF_MAX entries are STAGED in LDS first, every load of the query in flight at once: the five passes below
+        //      otherwise each walk the sub-lists with dependent global loads (~80 serialised round trips per query: 0.8 of the kernel's
+        //      1.4 ms at 50k x 50k x 100).  Entry e of the concatenated list lives in sub-list p = the last one with pre[p] <= e. ----
+        const bool staged = ok && total <= (unsigned)RF_MAX;
+        uint2 *stg = (uint2 *)comp;
+        if (staged) {
+            uint32_t *pre = sel;                                     // (sel is free until the compaction below)
+            uint32_t run = 0;
+            for (int p0 = 0; p0 < parts; p0 += 64) {
+                const uint32_t c = p0 + lane < parts ? cnts[p0 + lane] : 0u;
+                uint32_t incl = c;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const uint32_t t = __shfl_up(incl, off, 64);
+                    if (lane >= off) incl += t;
+                }
+                if (p0 + lane < parts) pre[p0 + lane + 1] = run + incl;
+                run += (uint32_t)__shfl((int)incl, 63, 64);
+            }
+            if (lane == 0) pre[0] = 0;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            for (uint32_t base = 0; base < total; base += 512u) {        // 8 loads per lane in flight at a time (registers)
+                uint2 val[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const uint32_t e = base + (uint32_t)lane + 64u * i;
+                    int lo = 0, hi2 = parts - 1;                         // largest p with pre[p] <= e
+                    while (lo < hi2) {
+                        const int mid = (lo + hi2 + 1) >> 1;
+                        if (pre[mid] <= e) lo = mid; else hi2 = mid - 1;
+                    }
+                    const uint32_t ec = e < total ? e : 0u;
+                    const int pc = e < total ? lo : 0;
+                    val[i] = lst[(int64_t)pc * cap + (ec - (e < total ? pre[pc] : 0u))];
+                }
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const uint32_t e = base + (uint32_t)lane + 64u * i;
+                    if (e < total) stg[e] = val[i];
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
         uint32_t m = 0;
         float B = 0.f;
         const float e_q = eps[urow], thr_q = thr[urow];
@@ -960,12 +1003,19 @@ __global__ __launch_bounds__(RF_WAVES * 64) void pf_refine_kernel(const uint2 *_
 #pragma unroll
                 for (int i = 0; i < 4; i++) hist[lane * 4 + i] = 0;
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                for (int p = 0; p < parts; p++) {
-                    const uint2 *lp = lst + p * cap;
-                    const unsigned cp = cnts[p];
-                    for (unsigned e = lane; e < cp; e += 64) {
-                        const uint32_t key = canon_key(__uint_as_float(lp[e].x));
+                if (staged) {
+                    for (unsigned e = lane; e < total; e += 64) {
+                        const uint32_t key = canon_key(__uint_as_float(stg[e].x));
                         if ((key & pmask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+                    }
+                } else {
+                    for (int p = 0; p < parts; p++) {
+                        const uint2 *lp = lst + p * cap;
+                        const unsigned cp = cnts[p];
+                        for (unsigned e = lane; e < cp; e += 64) {
+                            const uint32_t key = canon_key(__uint_as_float(lp[e].x));
+                            if ((key & pmask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+                        }
                     }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -1000,6 +1050,20 @@ __global__ __launch_bounds__(RF_WAVES * 64) void pf_refine_kernel(const uint2 *_
                 B = b1 < thr_q ? b1 : thr_q;
                 const uint32_t bkey = canon_key(B);
                 // ---- R: entries with d~ <= B, plus every NaN d~ ----
+                if (staged) {
+                    // (sel doubled as the prefix array: every lane is past its last read of it -- the loop below writes it)
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    for (unsigned e0 = 0; e0 < total; e0 += 64) {
+                        const unsigned e = e0 + lane;
+                        const uint2 c = stg[e < total ? e : 0];
+                        const uint32_t key = canon_key(__uint_as_float(c.x));
+                        const bool take = e < total && (key <= bkey || key == 0xFFFFFFFFu);
+                        const uint64_t bm = __ballot(take);
+                        const uint32_t pos = m + __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
+                        if (take && pos < (uint32_t)RF_MAX) sel[pos] = c.y;
+                        m += (uint32_t)__popcll(bm);
+                    }
+                } else
                 for (int p = 0; p < parts; p++) {
                     const uint2 *lp = lst + p * cap;
                     const unsigned cp = cnts[p];
