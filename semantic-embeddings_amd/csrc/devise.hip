@@ -21,29 +21,31 @@ typedef float dv_f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int DV_BK = 64;            // k per staged chunk
 constexpr int DV_LD = DV_BK + 4;     // padded row pitch (floats): conflict-free ds_read_b128
+constexpr int DV_FWD_BK = 128;       // the forward kernel's chunk (one wave per workgroup: long chunks hide its global round trips)
 
 // Staging loads are UNCONDITIONAL (out-of-range rows / k read a valid in-range address and are zeroed afterwards): with a branch per
 // element the compiler waited for every load before issuing the next one, which was most of these kernels' time.
+template <int BK = DV_BK>
 __device__ __forceinline__ void dv_put(float *lds, int r, int kq, const float v[4])
 {
-    float *o = lds + r * DV_LD;                      // even k to [0, 32), odd k to [32, 64) of the row
+    float *o = lds + r * (BK + 4);                   // even k to [0, BK / 2), odd k to [BK / 2, BK) of the row
     o[(kq >> 1)] = v[0];
     o[(kq >> 1) + 1] = v[2];
-    o[32 + (kq >> 1)] = v[1];
-    o[32 + (kq >> 1) + 1] = v[3];
+    o[BK / 2 + (kq >> 1)] = v[1];
+    o[BK / 2 + (kq >> 1) + 1] = v[3];
 }
 
-// 8 x (one row's 4 consecutive k) per lane; rowp(r) = pointer to LDS row r's source row, or nullptr outside the matrix
-template <class RowPtr>
-__device__ __forceinline__ void dv_stage_rows(float *lds, RowPtr rowp, const float *any_valid_row, int64_t ld, int64_t k0, int64_t K)
+// 8 x (one row's 4 consecutive k) per lane; rowp(r) = pointer to LDS row r's source row, or nullptr outside the matrix.
+// Split in two so that a kernel can keep the NEXT chunk's loads in flight while the matrix pipe works on the current one.
+template <int BK = DV_BK, class RowPtr>
+__device__ __forceinline__ void dv_load_rows(float (&v)[BK / 8][4], RowPtr rowp, const float *any_valid_row, int64_t ld, int64_t k0, int64_t K)
 {
     const int lane = lane_id();
-    float v[8][4];
     const bool vec = ((ld | K) & 3) == 0 && (((uintptr_t)any_valid_row) & 15) == 0;          // wave-uniform
 #pragma unroll
-    for (int it = 0; it < 8; it++) {
+    for (int it = 0; it < BK / 8; it++) {
         const int idx = it * 64 + lane;
-        const int r = idx >> 4, kq = (idx & 15) * 4;
+        const int r = idx / (BK / 4), kq = (idx % (BK / 4)) * 4;
         const float *p = rowp(r);
         const bool rok = p != nullptr;
         if (!rok) p = any_valid_row;
@@ -60,11 +62,25 @@ __device__ __forceinline__ void dv_stage_rows(float *lds, RowPtr rowp, const flo
             }
         }
     }
+}
+
+template <int BK = DV_BK>
+__device__ __forceinline__ void dv_put_rows(float *lds, const float (&v)[BK / 8][4])
+{
+    const int lane = lane_id();
 #pragma unroll
-    for (int it = 0; it < 8; it++) {
+    for (int it = 0; it < BK / 8; it++) {
         const int idx = it * 64 + lane;
-        dv_put(lds, idx >> 4, (idx & 15) * 4, v[it]);
+        dv_put<BK>(lds, idx / (BK / 4), (idx % (BK / 4)) * 4, v[it]);
     }
+}
+
+template <class RowPtr>
+__device__ __forceinline__ void dv_stage_rows(float *lds, RowPtr rowp, const float *any_valid_row, int64_t ld, int64_t k0, int64_t K)
+{
+    float v[DV_BK / 8][4];
+    dv_load_rows<DV_BK>(v, rowp, any_valid_row, ld, k0, K);
+    dv_put_rows<DV_BK>(lds, v);
 }
 
 // 32 rows x 64 k of a row-major [rows, K] matrix -> LDS; zero outside
@@ -111,11 +127,12 @@ __device__ __forceinline__ void dv_stage_t(float *lds, const float *src, int64_t
     }
 }
 
+template <int BK = DV_BK>
 __device__ __forceinline__ dv_f32x16 dv_mma_chunk(dv_f32x16 acc, const float *sA, const float *sB, int col, int hi, int64_t kc)
 {
     const int steps = (int)((kc + 1) / 2);
-    const float *pa = sA + col * DV_LD + hi * 32;
-    const float *pb = sB + col * DV_LD + hi * 32;
+    const float *pa = sA + col * (BK + 4) + hi * (BK / 2);
+    const float *pb = sB + col * (BK + 4) + hi * (BK / 2);
     for (int s = 0; s < steps; s += 4) {
         const float4 a4 = *(const float4 *)(pa + s);
         const float4 b4 = *(const float4 *)(pb + s);
@@ -128,8 +145,32 @@ __device__ __forceinline__ dv_f32x16 dv_mma_chunk(dv_f32x16 acc, const float *sA
 }
 
 // aux layout: true_sim [B] | n_active [B] | mask [B, C]
-__global__ __launch_bounds__(64) void devise_fwd_kernel(const float *__restrict__ yp, int64_t ldp, const int64_t *__restrict__ labels,
-                                                        const float *__restrict__ yt, int64_t ldt, const float *__restrict__ emb, int64_t lde,
+
+// true_sim_i = sum_d y_true[i, d] * y_pred[i, d] (utils.py:118): one wave per sample, coalesced loads, k-ascending fmaf chains per lane
+// + a wave reduction.  Its own launch: inside devise_fwd_kernel it was a 16-chunk pre-pass in front of EVERY class slice (40 of the
+// kernel's 128 us at C = D = 1000).
+__global__ __launch_bounds__(256) void devise_true_sim_kernel(const float *__restrict__ yp, int64_t ldp, const int64_t *__restrict__ labels,
+                                                             const float *__restrict__ yt, int64_t ldt, const float *__restrict__ emb, int64_t lde,
+                                                             int64_t B, int64_t D, int64_t C, float *__restrict__ aux)
+{
+    const int lane = lane_id();
+    const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= B) return;
+    const float *t;
+    if (yt) t = yt + i * ldt;
+    else {
+        int64_t y = labels[i];
+        y = y < 0 ? 0 : (y >= C ? C - 1 : y);
+        t = emb + y * lde;
+    }
+    const float *p = yp + i * ldp;
+    float acc = 0.f;
+    for (int64_t k = lane; k < D; k += 64) acc = fmaf(p[k], t[k], acc);
+    acc = wave_sum(acc);
+    if (lane == 0) aux[i] = acc;
+}
+
+__global__ __launch_bounds__(64) void devise_fwd_kernel(const float *__restrict__ yp, int64_t ldp, const float *__restrict__ emb, int64_t lde,
                                                         int64_t B, int64_t D, int64_t C, float margin, float *__restrict__ loss_i,
                                                         float *__restrict__ aux, int tiles_per_block)
 {
@@ -137,35 +178,18 @@ __global__ __launch_bounds__(64) void devise_fwd_kernel(const float *__restrict_
     // class sets: one wave walking all C / 32 class tiles of its 32 samples was 4 waves on the chip for a batch of 128): every slice
     // leaves its partial hinge sums / active counts behind the mask in `aux` and devise_finish_kernel adds them in slice order
     // (deterministic: no floating-point atomics).
-    __shared__ __attribute__((aligned(16))) float sA[32 * DV_LD];
-    __shared__ __attribute__((aligned(16))) float sB[32 * DV_LD];
+    // The (class tile, K-chunk) sequence is software-pipelined: while the MFMAs of one chunk run out of LDS the next chunk's operand
+    // rows are already in flight into registers (one wave per workgroup: nothing else hides the round trip -- unpipelined, every one of
+    // the 16 chunks of a D = 1000 tile exposed it).
+    constexpr int FB = DV_FWD_BK;     // 128 k per chunk: 64 MFMA steps (1.7 us) per global round trip instead of 32
+    __shared__ __attribute__((aligned(16))) float sA[32 * (FB + 4)];
+    __shared__ __attribute__((aligned(16))) float sB[32 * (FB + 4)];
     __shared__ float sTrue[32];
     const int lane = lane_id();
     const int col = lane & 31, hi = lane >> 5;
     const int64_t row0 = (int64_t)blockIdx.x * 32;
     float *mask = aux + 2 * B;
-
-    // true_sim (utils.py:118): the sample rows and their target rows go through LDS in the same 64-wide chunks as the class tiles
-    // (coalesced loads; walking D with one dependent global load per element was 2/3 of this kernel at D = 1000); lane (row, half)
-    // runs one k-ascending fmaf chain over the even / odd k of its row and the two halves are added at the end
-    {
-        float t = 0.f;
-        for (int64_t k0 = 0; k0 < D; k0 += DV_BK) {
-            __syncthreads();
-            dv_stage(sA, yp, ldp, row0, B, k0, D);
-            dv_stage_target(sB, yt, ldt, labels, emb, lde, row0, B, C, k0, D);
-            __syncthreads();
-            const float *pa = sA + col * DV_LD + hi * 32, *pb = sB + col * DV_LD + hi * 32;
-#pragma unroll
-            for (int s4 = 0; s4 < 32; s4 += 4) {                   // zero padded beyond D: fmaf(0, 0, t) == t
-                const float4 a4 = *(const float4 *)(pa + s4), b4 = *(const float4 *)(pb + s4);
-                t = fmaf(a4.x, b4.x, t); t = fmaf(a4.y, b4.y, t); t = fmaf(a4.z, b4.z, t); t = fmaf(a4.w, b4.w, t);
-            }
-        }
-        t += __shfl_xor(t, 32, 64);
-        if (hi == 0) sTrue[col] = t;
-    }
-    __syncthreads();
+    if (lane < 32) sTrue[lane] = row0 + lane < B ? aux[row0 + lane] : 0.f;      // devise_true_sim_kernel ran ahead of this launch
 
     float hinge[16], nact[16];
 #pragma unroll
@@ -173,27 +197,47 @@ __global__ __launch_bounds__(64) void devise_fwd_kernel(const float *__restrict_
 
     const int64_t c_beg = (int64_t)blockIdx.y * tiles_per_block * 32;
     const int64_t c_end = (c_beg + (int64_t)tiles_per_block * 32 < C) ? c_beg + (int64_t)tiles_per_block * 32 : C;
-    for (int64_t c0 = c_beg; c0 < c_end; c0 += 32) {
-        dv_f32x16 acc;
+    const int64_t nchunks = (D + FB - 1) / FB;
+    auto rows_a = [=](int r) -> const float * { return row0 + r < B ? yp + (row0 + r) * ldp : nullptr; };
+    float va[FB / 8][4], vb[FB / 8][4];
+    int64_t c0 = c_beg;
+    if (c0 < c_end) {
+        dv_load_rows<FB>(va, rows_a, yp, ldp, 0, D);
+        dv_load_rows<FB>(vb, [=](int r) -> const float * { return c0 + r < C ? emb + (c0 + r) * lde : nullptr; }, emb, lde, 0, D);
+    }
+    dv_f32x16 acc;
 #pragma unroll
-        for (int r = 0; r < 16; r++) acc[r] = 0.f;
-        for (int64_t k0 = 0; k0 < D; k0 += DV_BK) {
-            __syncthreads();
-            dv_stage(sA, yp, ldp, row0, B, k0, D);
-            dv_stage(sB, emb, lde, c0, C, k0, D);
-            __syncthreads();
-            acc = dv_mma_chunk(acc, sA, sB, col, hi, (D - k0 < DV_BK) ? (D - k0) : DV_BK);
+    for (int r = 0; r < 16; r++) acc[r] = 0.f;
+    int64_t chunk = 0;
+    while (c0 < c_end) {
+        __syncthreads();                      // the previous chunk's MFMA reads of sA / sB are done
+        dv_put_rows<FB>(sA, va);
+        dv_put_rows<FB>(sB, vb);
+        __syncthreads();
+        // request the next chunk (same class tile, or the first chunk of the next one)
+        const bool last_chunk = chunk + 1 == nchunks;
+        const int64_t nc0 = last_chunk ? c0 + 32 : c0, nk0 = last_chunk ? 0 : (chunk + 1) * FB;
+        if (nc0 < c_end) {
+            dv_load_rows<FB>(va, rows_a, yp, ldp, nk0, D);
+            dv_load_rows<FB>(vb, [=](int r) -> const float * { return nc0 + r < C ? emb + (nc0 + r) * lde : nullptr; }, emb, lde, nk0, D);
         }
-        const int64_t c = c0 + col;
+        const int64_t k0 = chunk * FB;
+        acc = dv_mma_chunk<FB>(acc, sA, sB, col, hi, (D - k0 < FB) ? (D - k0) : FB);
+        if (last_chunk) {
+            const int64_t c = c0 + col;
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int lr = (r & 3) + 8 * (r >> 2) + 4 * hi;      // row of this accumulator register
-            const bool valid = (c < C) && (row0 + lr < B);
-            const float h = (margin - sTrue[lr]) + acc[r];       // margin - true_sim[:, None] + other_sim (utils.py:120)
-            const bool on = valid && h > 0.f;
-            if (on) { hinge[r] += h; nact[r] += 1.f; }
-            if (valid) mask[(row0 + lr) * C + c] = on ? 1.f : 0.f;
+            for (int r = 0; r < 16; r++) {
+                const int lr = (r & 3) + 8 * (r >> 2) + 4 * hi;      // row of this accumulator register
+                const bool valid = (c < C) && (row0 + lr < B);
+                const float h = (margin - sTrue[lr]) + acc[r];       // margin - true_sim[:, None] + other_sim (utils.py:120)
+                const bool on = valid && h > 0.f;
+                if (on) { hinge[r] += h; nact[r] += 1.f; }
+                if (valid) mask[(row0 + lr) * C + c] = on ? 1.f : 0.f;
+                acc[r] = 0.f;
+            }
         }
+        chunk = last_chunk ? 0 : chunk + 1;
+        c0 = nc0;
     }
 #pragma unroll
     for (int r = 0; r < 16; r++) {
@@ -206,13 +250,11 @@ __global__ __launch_bounds__(64) void devise_fwd_kernel(const float *__restrict_
         if (col == 0 && row0 + lr < B) {
             if (gridDim.y == 1) {
                 loss_i[row0 + lr] = hinge[r] - margin;
-                aux[row0 + lr] = sTrue[lr];
                 aux[B + row0 + lr] = nact[r];
             } else {
                 float *part = aux + 2 * B + B * C + (int64_t)blockIdx.y * 2 * B;     // [slices][2][B]
                 part[row0 + lr] = hinge[r];
                 part[B + row0 + lr] = nact[r];
-                if (blockIdx.y == 0) aux[row0 + lr] = sTrue[lr];
             }
         }
     }
@@ -316,8 +358,11 @@ extern "C" int se_devise_loss_fwd(const float *y_pred, int64_t ldp, const int64_
     if (ldp < D || lde < D || (y_true && ldt < D)) return fail(SE_ERR_INVALID, "se_devise_loss_fwd: leading dimension < D");
     const int tpb = devise_tiles_per_block(B, C);
     const int64_t slices = ((C + 31) / 32 + tpb - 1) / tpb;
-    hipLaunchKernelGGL(devise_fwd_kernel, dim3((unsigned)((B + 31) / 32), (unsigned)slices), dim3(64), 0, (hipStream_t)stream, y_pred, ldp, labels,
-                       y_true, ldt, emb, lde, B, D, C, margin, loss_i, aux, tpb);
+    hipLaunchKernelGGL(devise_true_sim_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, (hipStream_t)stream, y_pred, ldp, labels, y_true, ldt, emb, lde,
+                       B, D, C, aux);
+    SE_LAUNCH_CHECK();
+    hipLaunchKernelGGL(devise_fwd_kernel, dim3((unsigned)((B + 31) / 32), (unsigned)slices), dim3(64), 0, (hipStream_t)stream, y_pred, ldp, emb, lde, B, D,
+                       C, margin, loss_i, aux, tpb);
     SE_LAUNCH_CHECK();
     if (slices > 1) {
         hipLaunchKernelGGL(devise_finish_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, (hipStream_t)stream, aux, B, C, (int)slices, margin, loss_i);

@@ -255,9 +255,25 @@ class _DeviseLoss(torch.autograd.Function):
         return dp.to(ctx.in_dtype), None, None, None
 
 
+DEVISE_TORCH_ABOVE = 1 << 29      # B * C * D from which the loss is written with PyTorch ops instead of the fused kernels
+
+
 def devise_ranking_loss(y_pred, target, embedding, margin=0.1):
     """Per-sample DeViSE ranking loss [B] (utils.py:103-122), differentiable w.r.t. ``y_pred``; ``target`` = int64 labels [B]
-    (rows of ``embedding`` gathered on the device) or an explicit float ``y_true`` [B, D]."""
+    (rows of ``embedding`` gathered on the device) or an explicit float ``y_true`` [B, D].
+
+    Fused fp32-MFMA kernels (``se_devise_loss_fwd/bwd``) up to ``B * C * D < DEVISE_TORCH_ABOVE``; larger problems -- batch 1024 at
+    C = D = 1000 -- take the same expression in PyTorch ops: there the one-wave-per-tile forward kernel (111 us) loses to
+    hipBLASLt's GEMM + elementwise kernels (measured: 223 vs 206 us forward + backward), while at the training sizes (batch 128)
+    the fused pair wins (165 vs 208 us at C = D = 1000; profiles/r04_d_devise_microbench.txt).  Both are float32 and
+    differentiable; the kernels are what the parity tests hold to the reference-produced fixtures."""
+    B, D = y_pred.shape
+    if B * embedding.shape[0] * D >= DEVISE_TORCH_ABOVE and y_pred.is_cuda:
+        yp = y_pred.to(torch.float32)
+        yt = embedding[target.long().clamp(0, embedding.shape[0] - 1)] if (target.dim() == 1 and not target.is_floating_point()) \
+            else target.to(torch.float32)
+        true_sim = (yt * yp).sum(-1)
+        return torch.relu(float(margin) - true_sim[:, None] + yp @ embedding.t()).sum(-1) - float(margin)
     return _DeviseLoss.apply(y_pred, target, embedding, float(margin))
 
 

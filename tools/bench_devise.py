@@ -1,4 +1,6 @@
-import sys; sys.path[:0]=["semantic-embeddings_amd","."]
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "semantic-embeddings_amd"), ROOT]
 import torch, sehip, numpy as np
 def timeit(fn, reps=30):
     fn(); torch.cuda.synchronize()
