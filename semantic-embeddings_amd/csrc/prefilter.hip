@@ -41,14 +41,20 @@ typedef float pf_f32x16 __attribute__((ext_vector_type(16)));
 #ifndef SE_PF_BM
 #define SE_PF_BM 128      // 256: 512-thread workgroups, one per CU (measured: 28.8 vs 26.6 ms on the D = 1000 shard -- with one workgroup per CU
 #endif                    // every wave is in the same phase at the same time and nothing overlaps the load bursts)
-constexpr int PF_BM = SE_PF_BM, PF_BN = 128, PF_BK = 128;   // tile (gallery rows x queries), K-chunk (fp16 elements)
+#ifndef SE_PF_BK
+#define SE_PF_BK 128
+#endif
+constexpr int PF_BM = SE_PF_BM, PF_BN = 128, PF_BK = SE_PF_BK;   // tile (gallery rows x queries), K-chunk (fp16 elements)
 constexpr int PF_THREADS = PF_BM * 2;                       // (PF_BM / 64) x 2 waves of 64 x 64 outputs
 constexpr int PF_ROWB = PF_BK * 2;                          // bytes of one operand row of a chunk (256)
 constexpr int PF_PITCH = PF_ROWB + 16;                      // LDS row pitch in bytes: 68 dwords -> conflict-free ds_read_b128 over 16 rows
 constexpr int PF_PPR = PF_ROWB / 16;                        // 16-byte pieces per row (16)
 constexpr int PF_NLOAD_A = PF_BM * PF_PPR / PF_THREADS;     // pieces per thread: gallery operand (8)
 constexpr int PF_NLOAD_B = PF_BN * PF_PPR / PF_THREADS;     // query operand (4)
-constexpr int PF_WGS_PER_CU = 256 / PF_BM;                  // 8 waves per CU, <= 256 registers each
+#ifndef SE_PF_WGS
+#define SE_PF_WGS (256 / SE_PF_BM)
+#endif
+constexpr int PF_WGS_PER_CU = SE_PF_WGS;                    // default: 8 waves per CU, <= 256 registers each
 
 constexpr int PF_GROUPMIN = PF_EPI_GROUPMIN, PF_FILTER = PF_EPI_FILTER, PF_STORE = PF_EPI_STORE;
 
@@ -562,6 +568,7 @@ PfGeom pf_geometry(int64_t n_a, int64_t n_q, int want_parts)
     const int per_xcd = (int)(pf_grid() / 8);
     PfGeom g;
     g.gi = 8;
+    if (const char *e = tuning_env("SE_PF_GI")) g.gi = atoi(e) > 0 ? atoi(e) : 8;   // -DSE_TUNING build: shape of the per-XCD workgroup grid
     while (g.gi > 1 && (g.gi > tiles_n || per_xcd % g.gi)) g.gi >>= 1;          // few queries: fewer query tiles side by side, more gallery sequences
     g.gj = per_xcd / g.gi;
     if (g.gj > tiles_m) g.gj = (int)tiles_m;

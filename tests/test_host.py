@@ -307,6 +307,9 @@ def test_bench_gpus_flag_spawns_that_many_ranks():
     assert len(lines) == 1, out.stdout
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["dry"] is True and rec["sharded_topk_matches_unsharded"] is True
+    # the communicator's identity travels with the line: backend, world size, one (rank, device, pid) triple per rank, collected THROUGH it
+    assert rec["rccl"]["backend"] == "gloo" and rec["rccl"]["world"] == 2 and sorted(r["rank"] for r in rec["rccl"]["ranks_seen"]) == [0, 1]
+    assert rec["multi_gpu"]["n_gpus"] == 2
 
 
 def test_bench_dry_run_with_8_ranks_completes_every_leg():
