@@ -210,10 +210,10 @@ __global__ __launch_bounds__(64) void devise_fwd_kernel(const float *__restrict_
     for (int r = 0; r < 16; r++) acc[r] = 0.f;
     int64_t chunk = 0;
     while (c0 < c_end) {
-        __syncthreads();                      // the previous chunk's MFMA reads of sA / sB are done
+        wg_barrier();                      // the previous chunk's MFMA reads of sA / sB are done
         dv_put_rows<FB>(sA, va);
         dv_put_rows<FB>(sB, vb);
-        __syncthreads();
+        wg_barrier();
         // request the next chunk (same class tile, or the first chunk of the next one)
         const bool last_chunk = chunk + 1 == nchunks;
         const int64_t nc0 = last_chunk ? c0 + 32 : c0, nk0 = last_chunk ? 0 : (chunk + 1) * FB;
@@ -312,7 +312,7 @@ __global__ __launch_bounds__(64 * DV_BW) void devise_bwd_kernel(const int64_t *_
 #pragma unroll
         for (int r = 0; r < 16; r++) sRed[wave - 1][r][lane] = acc[r];
     }
-    __syncthreads();
+    wg_barrier();
     if (wave > 0) return;
 #pragma unroll
     for (int w = 0; w < DV_BW - 1; w++)

@@ -134,19 +134,19 @@ __global__ __launch_bounds__(HP_ORDER_THREADS) void hprec_order_kernel(const int
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int c = tid; c < C; c += HP_ORDER_THREADS) hp_hist[c] = 0;
     if (tid < HP_WS_HEAD) ws[tid] = 0;
-    __syncthreads();
+    wg_barrier();
     for (int64_t i = tid; i < Q; i += HP_ORDER_THREADS) atomicAdd(&hp_hist[qcls[i]], 1);
-    __syncthreads();
+    wg_barrier();
     const int per = (C + HP_ORDER_THREADS - 1) / HP_ORDER_THREADS, lo = tid * per, hi = (lo + per < C) ? lo + per : C;
     int mine = 0;
     for (int c = lo; c < hi; c++) mine += hp_hist[c];
     const int incl = wave_incl_scan_i32(mine);
     if (lane == 63) s_wt[wave] = incl;
-    __syncthreads();
+    wg_barrier();
     int run = incl - mine;
     for (int w = 0; w < wave; w++) run += s_wt[w];
     for (int c = lo; c < hi; c++) { const int t = hp_hist[c]; hp_hist[c] = run; run += t; }
-    __syncthreads();
+    wg_barrier();
     int4 *ent = reinterpret_cast<int4 *>(ws + HP_WS_HEAD);      // everything a workgroup needs to start a query, in one 16-byte load
     for (int64_t i = tid; i < Q; i += HP_ORDER_THREADS) {
         const int c = qcls[i];
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(HP_THREADS, SE_HP_WAVES_PER_SIMD) void hprec_kernel
             w[i >> 1] = ((unsigned)cls[i] & 0xFFFFu) | ((i + 1 < gallery ? (unsigned)cls[i + 1] & 0xFFFFu : 0u) << 16);
     }
     for (int s = tid; s < nk; s += HP_THREADS) s_perm[s] = ks[s];       // raw cut-offs (LDS copy), ranked below
-    __syncthreads();
+    wg_barrier();
     int my_k[(HP_MAX_KS + HP_THREADS - 1) / HP_THREADS], my_r[(HP_MAX_KS + HP_THREADS - 1) / HP_THREADS];
 #pragma unroll
     for (int v = 0; v < (HP_MAX_KS + HP_THREADS - 1) / HP_THREADS; v++) {
@@ -217,13 +217,13 @@ __global__ __launch_bounds__(HP_THREADS, SE_HP_WAVES_PER_SIMD) void hprec_kernel
             for (int u = 0; u < nk; u++) { const int ku = s_perm[u]; r += (ku < my_k[v] || (ku == my_k[v] && u < s)) ? 1 : 0; }
         my_r[v] = r;
     }
-    __syncthreads();
+    wg_barrier();
 #pragma unroll
     for (int v = 0; v < (HP_MAX_KS + HP_THREADS - 1) / HP_THREADS; v++) {
         const int s = tid + v * HP_THREADS;
         if (s < nk) { s_ks[my_r[v]] = my_k[v]; s_perm[my_r[v]] = s; }
     }
-    __syncthreads();
+    wg_barrier();
     const int kmax = nk > 0 ? s_ks[nk - 1] : 0;                    // cut-offs live at original positions <= kmax
     // the cut-offs the CLI asks for are 1, 2, ..., K in that order (evaluate_retrieval.py: range(1, plot_max + 1)): rank j then IS
     // slot j -- no look-up at all.  One vote per workgroup.
@@ -261,7 +261,7 @@ __global__ __launch_bounds__(HP_THREADS, SE_HP_WAVES_PER_SIMD) void hprec_kernel
                 }
                 *s_next = got;
             }
-            __syncthreads();
+            wg_barrier();
             q = *s_next;
             if (q < 0) break;
             if (tid == 0 && seg < 8) ticket = atomicAdd(&order_ws[(xcd + seg) & 7], 1);   // the next draw: in flight during this query
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(HP_THREADS, SE_HP_WAVES_PER_SIMD) void hprec_kernel
         for (int c = tid; c < C; c += HP_THREADS) s_sim[c] = make_double2(wup[(int64_t)qc * C + c], lcs[(int64_t)qc * C + c]);
         if (tid == 0) *s_qpos = (self >= 0 && first == self) ? 0 : 0x7FFFFFFF;
         if (tid < 4) s_ends[tid] = 0.0;
-        __syncthreads();
+        wg_barrier();
         // ---- position of the query in its own ranking (first hit; L if absent): normally it is its own nearest neighbour (rank 0) ----
         if (self >= 0 && first != self) {   // otherwise chunk by chunk with a uniform early exit
             for (int64_t b0 = 0; b0 < L; b0 += 4 * HP_THREADS) {
@@ -305,9 +305,9 @@ __global__ __launch_bounds__(HP_THREADS, SE_HP_WAVES_PER_SIMD) void hprec_kernel
                     const int64_t i = b0 + e * HP_THREADS + tid;
                     if (i < L && rrow[i] == self) atomicMin(s_qpos, (int)i);
                 }
-                __syncthreads();
+                wg_barrier();
                 const int found = *s_qpos;      // read into a register BEFORE the second barrier: a fast wave must not start the next
-                __syncthreads();                // chunk's atomicMin while a slow wave has yet to read the flag (the waves would take
+                wg_barrier();                // chunk's atomicMin while a slow wave has yet to read the flag (the waves would take
                 if (found != 0x7FFFFFFF) break; // different exits and pair their barriers out of order)
             }
         }
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(HP_THREADS, SE_HP_WAVES_PER_SIMD) void hprec_kernel
                 if (FAST) HP_T(3)
                 double *part = s_part + par * (HP_WAVES * 3);
                 if (lane == 63) { part[wave * 3 + 0] = iw; part[wave * 3 + 1] = il; part[wave * 3 + 2] = (double)ir; }
-                __syncthreads();   // the only barrier of a chunk: the other half of s_part is written next time
+                wg_barrier();   // the only barrier of a chunk: the other half of s_part is written next time
                 if (FAST) HP_T(4)
                 load_ranks(rr, i0 + HP_PF * HP_CHUNK, last_pos);
                 double cw = car_w + (iw - tw), cl = car_l + (il - tl);     // sums BEFORE this thread's first element
@@ -459,7 +459,7 @@ __global__ __launch_bounds__(HP_THREADS, SE_HP_WAVES_PER_SIMD) void hprec_kernel
         {
             const double f0 = wave_incl_scan_f64(acc_w), f1 = wave_incl_scan_f64(acc_l), f2 = wave_incl_scan_f64(acc_ap);   // lane 63: the wave's sums
             if (lane == 63) { s_fin[wave * 3 + 0] = f0; s_fin[wave * 3 + 1] = f1; s_fin[wave * 3 + 2] = f2; }
-            __syncthreads();
+            wg_barrier();
             if (tid == 0) {
                 double g0 = 0.0, g1 = 0.0, g2 = 0.0;
                 for (int w = 0; w < HP_WAVES; w++) { g0 += s_fin[w * 3 + 0]; g1 += s_fin[w * 3 + 1]; g2 += s_fin[w * 3 + 2]; }

@@ -116,10 +116,10 @@ __global__ __launch_bounds__(256) void labelembed_finish_kernel(const float *__r
     float s = 0.f;
     for (int64_t i = threadIdx.x; i < B; i += 256) s += aux[i * LE_AUX + 4];
     part[threadIdx.x] = s;
-    __syncthreads();
+    wg_barrier();
     for (int off = 128; off > 0; off >>= 1) {
         if ((int)threadIdx.x < off) part[threadIdx.x] += part[threadIdx.x + off];
-        __syncthreads();
+        wg_barrier();
     }
     const float scale = (float)B / (part[0] + 1e-8f);
     if (threadIdx.x == 0) scale_out[0] = scale;

@@ -118,10 +118,10 @@ __global__ __launch_bounds__(256) void mean_kernel(const float *__restrict__ v, 
     float s = 0.f;
     for (int64_t i = threadIdx.x; i < n; i += 256) s += v[i];
     part[threadIdx.x] = s;
-    __syncthreads();
+    wg_barrier();
     for (int off = 128; off > 0; off >>= 1) {
         if ((int)threadIdx.x < off) part[threadIdx.x] += part[threadIdx.x + off];
-        __syncthreads();
+        wg_barrier();
     }
     if (threadIdx.x == 0) out[0] = part[0] / (float)n;
 }
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(64) void nn_accuracy_kernel(
             sTrue[col] = dot_prod_sim ? t : ((pn + other) - 2.0f * t);
         }
     }
-    __syncthreads();
+    wg_barrier();
 
     int n_better[16], n_within[16];
     float best_v[16];
@@ -319,10 +319,10 @@ __global__ __launch_bounds__(64) void nn_accuracy_kernel(
         for (int r = 0; r < 16; r++) acc[r] = 0.f;
         float cn = 0.f;  // |emb_c|^2 for this lane's class (Euclidean variant), half of D per lane
         for (int64_t k0 = 0; k0 < D; k0 += ACC_BK) {
-            __syncthreads();
+            wg_barrier();
             stage_tile32(sA, yp, ldp, row0, B, k0, D);
             stage_tile32(sB, emb, lde, c0, C, k0, D);
-            __syncthreads();
+            wg_barrier();
             const int64_t kc = (D - k0 < ACC_BK) ? (D - k0) : ACC_BK;
             const int steps = (int)((kc + 1) / 2);           // MFMA steps (2 k each), zero padded
             const float *pa = sA + col * ACC_LD + hi * 32;
@@ -344,9 +344,9 @@ __global__ __launch_bounds__(64) void nn_accuracy_kernel(
         }
         if (!dot_prod_sim) {
             cn += __shfl_xor(cn, 32, 64);
-            __syncthreads();
+            wg_barrier();
             if (hi == 0) sCn[col] = cn;
-            __syncthreads();
+            wg_barrier();
         }
         const int64_t c = c0 + col;
 #pragma unroll

@@ -302,7 +302,7 @@ __global__ __launch_bounds__(PD_THREADS, (PD_WAVES / 4) * PD_WGS_PER_CU) void pd
     bool cur_closes = closes_kb;
     pd_store(sA, ra, (int)((Q - cur_m0 < PD_BM) ? (Q - cur_m0) : PD_BM), kc);
     pd_store(sB, rb, (int)((N - cur_n0 < PD_BN) ? (N - cur_n0) : PD_BN), kc);
-    __syncthreads();
+    wg_barrier();
 #pragma unroll 1
     for (int64_t it = 0; it < total; it++) {
         PD_T(2)
@@ -510,13 +510,13 @@ __global__ __launch_bounds__(PD_THREADS, (PD_WAVES / 4) * PD_WGS_PER_CU) void pd
                         // FMA chain with commuted factors: bit-identical).  The tile goes through the idle operand LDS so that a lane again
                         // owns ONE query (a tile row) and reads 16 of its gallery values as 4 x 16 bytes.
                         static_assert(PD_SR == PD_BM || EPI != EPI_FILTER || !SYM, "the mirrored filter stages a whole tile");
-                        __syncthreads();   // every wave has finished this chunk's MFMA reads of the operand LDS
+                        wg_barrier();   // every wave has finished this chunk's MFMA reads of the operand LDS
 #pragma unroll
                         for (int j = 0; j < 2; j++)
 #pragma unroll
                             for (int r = 0; r < 16; r++)
                                 smem[(lr0 + (r & 3) + 8 * (r >> 2)) * PD_SP + wn * 64 + j * 32 + col] = MULTI_KB ? tot[j][r] : acc[j][r];
-                        __syncthreads();
+                        wg_barrier();
 #pragma unroll
                         for (int j = 0; j < 2; j++) {
                             const int ql = wn * 64 + j * 32 + col;                    // this lane's query = tile row ql
@@ -598,7 +598,7 @@ __global__ __launch_bounds__(PD_THREADS, (PD_WAVES / 4) * PD_WGS_PER_CU) void pd
                 }
 #pragma unroll
                 for (int h = 0; h < PD_BM / PD_SR; h++) {
-                    __syncthreads();   // operands of the last chunk / the previous stage contents are no longer needed
+                    wg_barrier();   // operands of the last chunk / the previous stage contents are no longer needed
                     PD_T(6)
                     // tile rows [h SR, (h+1) SR) -> stage[row][col]: per instruction lanes 0-31 fill 32 consecutive floats of one row
 #pragma unroll
@@ -611,7 +611,7 @@ __global__ __launch_bounds__(PD_THREADS, (PD_WAVES / 4) * PD_WGS_PER_CU) void pd
                                     smem[(lr0 + mi * 32 - h * PD_SR + (r & 3) + 8 * (r >> 2)) * PD_SP + wn * 64 + j * 32 + col] = PD_VAL(mi, j, r);
                         }
                     PD_T(7)
-                    __syncthreads();
+                    wg_barrier();
                     PD_T(8)
                     pd_stream_rows(smem, out + ((cur_m0 + h * PD_SR) * (int64_t)ldo + cur_n0), ldo, rows_here - h * PD_SR, cols_here, fast, nt,
                                    flags & PDF_NO_GSTORE);
@@ -622,7 +622,7 @@ __global__ __launch_bounds__(PD_THREADS, (PD_WAVES / 4) * PD_WGS_PER_CU) void pd
                     for (int h = 0; h < PD_BN / PD_SR; h++) {
                         // transposed tile rows (= tile columns) [h SR, (h+1) SR) -> stage[col][row]: a lane owns 4 consecutive
                         // rows of its column = 16 bytes
-                        __syncthreads();
+                        wg_barrier();
                         PD_T(6)
                         if ((wn * 64) / PD_SR == h) {
 #pragma unroll
@@ -635,7 +635,7 @@ __global__ __launch_bounds__(PD_THREADS, (PD_WAVES / 4) * PD_WGS_PER_CU) void pd
                                             make_float4(PD_VAL(mi, j, 4 * g), PD_VAL(mi, j, 4 * g + 1), PD_VAL(mi, j, 4 * g + 2), PD_VAL(mi, j, 4 * g + 3));
                         }
                         PD_T(7)
-                        __syncthreads();
+                        wg_barrier();
                         PD_T(8)
                         pd_stream_rows(smem, out + ((cur_n0 + h * PD_SR) * (int64_t)ldo + cur_m0), ldo, cols_here - h * PD_SR, rows_here, fast, nt,
                                        flags & PDF_NO_GSTORE);
@@ -652,7 +652,7 @@ __global__ __launch_bounds__(PD_THREADS, (PD_WAVES / 4) * PD_WGS_PER_CU) void pd
             first_kb = true;
             PD_T(5)
         }
-        __syncthreads();   // every wave has finished reading this chunk (and, EPI_STORE, the epilogue stage) out of LDS
+        wg_barrier();   // every wave has finished reading this chunk (and, EPI_STORE, the epilogue stage) out of LDS
         PD_T(0)
         if (have_next) {
             cur_m0 = m0; cur_n0 = n0;
@@ -662,7 +662,7 @@ __global__ __launch_bounds__(PD_THREADS, (PD_WAVES / 4) * PD_WGS_PER_CU) void pd
             pd_store(sB, rb, (int)((N - cur_n0 < PD_BN) ? (N - cur_n0) : PD_BN), kc);
         }
         PD_T(1)
-        __syncthreads();
+        wg_barrier();
         c = last_chunk ? 0 : c + 1;
         tile_i += last_chunk ? 1u : 0u;
     }

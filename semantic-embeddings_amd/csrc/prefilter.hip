@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void pf_maxabs_kernel(const float *__restrict_
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { const float o = __shfl_xor(m, off, 64); m = o > m ? o : m; }
     if (lane == 0) wmax[wave] = m;
-    __syncthreads();
+    wg_barrier();
     if (threadIdx.x == 0) {
         m = wmax[0];
         for (int i = 1; i < 4; i++) m = wmax[i] > m ? wmax[i] : m;
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void pf_convert_kernel(const float *__restrict
     }
     // one set of atomics per workgroup (per wave they serialised on three addresses: 0.75 ms for 50,000 short rows)
     if (lane == 0) { wm_n[wave] = wmax_n; wm_r[wave] = wmax_r; wm_b[wave] = wbad; }
-    __syncthreads();
+    wg_barrier();
     if (threadIdx.x == 0) {
         float a = wm_n[0], b = wm_r[0];
         unsigned c = wm_b[0];
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(PF_THREADS, PF_WGS_PER_CU) void pf_tile_kernel(
     pf_stage<PF_NLOAD_B>(sB, rb);
     PF_JOB_SIDE(cur.tn)
     PF_TILE_SIDE(cur.t)
-    __syncthreads();
+    wg_barrier();
     bool more = true;
 #pragma unroll 1
     while (more) {
@@ -476,7 +476,7 @@ __global__ __launch_bounds__(PF_THREADS, PF_WGS_PER_CU) void pf_tile_kernel(
                     if (mask[j]) slotj[j] = atomicAdd(&jobCnt[wn * 64 + j * 32 + col], (unsigned)__popc(mask[j]));
                 }
                 PF_T(4)
-                __syncthreads();       // every wave is done with the operands of the last chunk: their LDS becomes the dump
+                wg_barrier();       // every wave is done with the operands of the last chunk: their LDS becomes the dump
                 float *mine = (float *)pf_smem + threadIdx.x * 36;          // lane-private row of 32 + 4 dwords, one query's values at a time
                 PF_T(5)
 #pragma unroll
@@ -513,7 +513,7 @@ __global__ __launch_bounds__(PF_THREADS, PF_WGS_PER_CU) void pf_tile_kernel(
 #pragma unroll
                     for (int r = 0; r < 16; r++) acc[mi][j][r] = 0.f;
         }
-        __syncthreads();   // every wave has finished reading this chunk out of LDS (and, at a tile's end, its epilogue)
+        wg_barrier();   // every wave has finished reading this chunk out of LDS (and, at a tile's end, its epilogue)
         PF_T(10)
         if (last_chunk && job_ends && EPI == PF_FILTER && threadIdx.x < PF_BN) {
             // the job is complete: its slot counters -> rowcnt[query][sub-list] (counts above the capacity mark an overflow: the query is redone)
@@ -529,7 +529,7 @@ __global__ __launch_bounds__(PF_THREADS, PF_WGS_PER_CU) void pf_tile_kernel(
                 cur = nx;
             }
         }
-        __syncthreads();
+        wg_barrier();
         c = last_chunk ? 0 : c + 1;
         more = have_next;
         PF_T(11)

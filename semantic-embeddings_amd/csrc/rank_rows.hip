@@ -74,9 +74,9 @@ __global__ __launch_bounds__(RK_THREADS) void rank_rows_kernel(const float *__re
         const float *drow = pdist + row * ldp;
 
         // ---------------- H: histograms of all four digits, one read of the row ----------------
-        __syncthreads();
+        wg_barrier();
         for (int i = tid; i < 4 * RK_NB; i += RK_THREADS) (&L.gbase[0][0])[i] = 0;
-        __syncthreads();
+        wg_barrier();
         for (int i = tid; i < N; i += RK_THREADS) {
             const uint32_t key = canon_key(drow[i]);
             atomicAdd(&L.gbase[0][key & 0xFF], 1u);
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(RK_THREADS) void rank_rows_kernel(const float *__re
             atomicAdd(&L.gbase[2][(key >> 16) & 0xFF], 1u);
             atomicAdd(&L.gbase[3][key >> 24], 1u);
         }
-        __syncthreads();
+        wg_barrier();
         if (wave < 4) {  // wave p scans histogram p (4 digits per lane)
             uint32_t c[4], s = 0;
 #pragma unroll
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(RK_THREADS) void rank_rows_kernel(const float *__re
 #pragma unroll
             for (int j = 0; j < 4; j++) { L.gbase[wave][lane * 4 + j] = run; run += c[j]; }
         }
-        __syncthreads();
+        wg_barrier();
 
         // ---------------- P: four stable counting passes ----------------
 #pragma unroll 1
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(RK_THREADS) void rank_rows_kernel(const float *__re
                     const int li = wbeg + s * WAVE + lane;
                     if (li < tcount) atomicAdd(&L.wcnt[wave][(key[s] >> shift) & 0xFF], 1u);
                 }
-                __syncthreads();
+                wg_barrier();
                 // 1c. digit-major / wave-minor exclusive scan (threads 0..255 own one digit each)
                 uint32_t my_total = 0;
                 if (tid < RK_NB) {
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(RK_THREADS) void rank_rows_kernel(const float *__re
                     if (lane == 63) L.wave_tot[wave] = wtot;
                     L.tile_start[tid] = ex;  // still missing the totals of the lower waves
                 }
-                __syncthreads();
+                wg_barrier();
                 if (tid < RK_NB) {
                     uint32_t add = 0;
                     for (int w = 0; w < wave; w++) add += L.wave_tot[w];
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(RK_THREADS) void rank_rows_kernel(const float *__re
 #pragma unroll
                     for (int w = 0; w < RK_WAVES; w++) L.wcnt[w][tid] += st;
                 }
-                __syncthreads();
+                wg_barrier();
 
                 // 2. stable rank inside the tile, place into LDS in tile-sorted order
                 volatile uint32_t *cur = L.wcnt[wave];
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(RK_THREADS) void rank_rows_kernel(const float *__re
                         L.tidx[base + rnk] = idx[s];
                     }
                 }
-                __syncthreads();
+                wg_barrier();
 
                 // 3. coalesced write-out of the tile-sorted keys
 #pragma unroll
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(RK_THREADS) void rank_rows_kernel(const float *__re
                         }
                     }
                 }
-                __syncthreads();
+                wg_barrier();
                 if (tid < RK_NB) L.gbase[p][tid] += my_total;
                 // (next tile's first barrier orders this update before its use)
             }
@@ -550,7 +550,7 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
     };
     // tuning aid (SE_RR_PROFILE=1): shader-clock cycles per phase, summed over every workgroup's wave 0
     uint64_t t_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_pp[24] = {}, t_last = PROF ? __builtin_amdgcn_s_memtime() : 0;
-#define RR_T(i) if constexpr (PROF) { lds_wait(); __syncthreads(); /* phase times are workgroup-wide: include the skew between the waves */ const uint64_t now = __builtin_amdgcn_s_memtime(); t_acc[i] += now - t_last; if (rr_pass >= 0) t_pp[(i) * 3 + rr_pass] += now - t_last; t_last = now; } else { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
+#define RR_T(i) if constexpr (PROF) { lds_wait(); wg_barrier(); /* phase times are workgroup-wide: include the skew between the waves */ const uint64_t now = __builtin_amdgcn_s_memtime(); t_acc[i] += now - t_last; if (rr_pass >= 0) t_pp[(i) * 3 + rr_pass] += now - t_last; t_last = now; } else { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
 
     // The row loop is software-pipelined over HBM: the NEXT row is prefetched into L2 during the last pass (one dword per 128-byte
     // line), loaded into the key registers right after it -- BEFORE this row's rank stores are issued, so the memory pipeline serves
@@ -630,7 +630,7 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
             for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, off, 64));
             if (lane == 0) stat[wave] = mx;
             if (tid == 0) stat[2 * RR_WAVES] = 0;                        // cursor of the list
-            __syncthreads();
+            wg_barrier();
 #pragma unroll
             for (int w = 0; w < RR_WAVES; w++) mx = max(mx, stat[w]);
             const uint32_t kmax = mx ? mx - 1u : 0u;
@@ -640,7 +640,7 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
 #pragma unroll
             for (int s = 0; s < ITEMS; s++) below_w += (uint32_t)__popcll(__ballot(key[s] < lo));
             if (lane == 0) stat[RR_WAVES + wave] = below_w;
-            __syncthreads();
+            wg_barrier();
             uint32_t below = 0;
 #pragma unroll
             for (int w = 0; w < RR_WAVES; w++) below += stat[RR_WAVES + w];
@@ -681,7 +681,7 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
             uint32_t *pcnt = wcnt;              // [RR_WAVES][pcw]
             int pcw = CNT_WORDS;
             if (wide) {
-                __syncthreads();                // every wave has finished reading the exchange buffer (previous pass's key exchange)
+                wg_barrier();                // every wave has finished reading the exchange buffer (previous pass's key exchange)
                 pcnt = reinterpret_cast<uint32_t *>(xbuf);
                 pcw = RR_WIDE_WORDS;
             }
@@ -704,7 +704,7 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
             else RRRank<ITEMS>::run(ir, key, shift, lane, cb);
             lds_wait();
             RR_T(1)
-            __syncthreads();
+            wg_barrier();
             if (SE_RR_PF == 3) { RR_PREFETCH_NEXT_ROW() }
             // ---- S: counters -> first destination of every (wave, digit) ----
             if constexpr (!HWORD) {
@@ -717,7 +717,7 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
                 ex = wave_excl_scan(run, wtot);
                 if (lane == 63) wave_tot[wave] = wtot;
             }
-            __syncthreads();
+            wg_barrier();
             if (tid < RK_NB) {   // (the per-wave counts are re-read rather than kept in 8 registers across the barrier)
                 for (int w = 0; w < wave; w++) ex += wave_tot[w];
 #pragma unroll
@@ -752,7 +752,7 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
                 uint32_t ex = wave_excl_scan(T0 + T1, wtot);   // both halves scanned at once
                 if (wide) ex2 = wave_excl_scan(U0 + U1, wtot2);
                 if (scanner && lane == 63) { wave_tot[wave] = wtot; wave_tot[RR_SCAN_WAVES + wave] = wtot2; }
-                __syncthreads();
+                wg_barrier();
                 uint32_t all = 0, all2 = 0;
 #pragma unroll
                 for (int w = 0; w < RR_SCAN_WAVES; w++) {
@@ -787,7 +787,7 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
                 }
                 }
             }
-            __syncthreads();
+            wg_barrier();
             RR_T(2)
             // L2 prefetch of this workgroup's NEXT row (one workgroup per CU: nothing else hides its 200 KB of HBM latency): one dword
             // per 128-byte line, all into one sink register that stays reserved until the loads after the pass loop have been waited for.
@@ -814,26 +814,26 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
             }
             }
             if (SE_RR_PF == 2) { RR_PREFETCH_NEXT_ROW() }
-            if (wide) __syncthreads();   // the scatter below overwrites the (aliased) counters other waves may still be looking up
+            if (wide) wg_barrier();   // the scatter below overwrites the (aliased) counters other waves may still be looking up
             RR_T(3)
             if (wave_live) {
 #pragma unroll
                 for (int s = 0; s < ITEMS; s++) { opaque(ir[s]); lds_st16_hi(RR_DST(ir[s]), ir[s]); }       // index
             }
             lds_wait();
-            __syncthreads();
+            wg_barrier();
             RR_T(4)
             const bool last = end >= 32;
             if (last) {
                 if constexpr (!SEG) break;   // last pass: the index buffer is the ranking
                 else {                       // run planes: the indices leave now, the two key halves follow through the same buffer
                     RR_STREAM_PLANE(0, row)
-                    __syncthreads();
+                    wg_barrier();
                 }
             } else {
                 if (wave_live) RRRead<ITEMS, true>::run(ir, ring, rb);
                 lds_wait();
-                __syncthreads();
+                wg_barrier();
             }
             RR_T(5)
             if (wave_live) {
@@ -841,7 +841,7 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
                 for (int s = 0; s < ITEMS; s++) { opaque(ir[s]); lds_st16_hi(RR_DST(ir[s]), key[s]); }      // key bits 16-31  (opaque: no cached addresses)
             }
             lds_wait();
-            __syncthreads();
+            wg_barrier();
             if (SEG && last) {
                 RR_STREAM_PLANE(1, row)
             } else {
@@ -849,13 +849,13 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
                 lds_wait();
             }
             if (end < 16 || SEG) {                                                       // key bits 0-15: still needed by a later pass (SEG: by the run, so they travel through every pass)
-                __syncthreads();
+                wg_barrier();
                 if (wave_live) {
 #pragma unroll
                     for (int s = 0; s < ITEMS; s++) { opaque(ir[s]); lds_st16_lo(RR_DST(ir[s]), key[s]); }  // (low half is still the old key's)
                 }
                 lds_wait();
-                __syncthreads();
+                wg_barrier();
                 if (SEG && last) break;      // the key registers are free: the next row is loaded before the last plane is streamed out
                 if (wave_live) RRRead<ITEMS, false>::run(key, ring, rb);
                 lds_wait();
@@ -877,7 +877,7 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
                     }
                     xbuf[r] = (uint16_t)me.y;
                 }
-                __syncthreads();
+                wg_barrier();
             }
         }
         // ---- the exchange buffer now holds the ranking: canonicalise the next row's keys (waits for its loads), then stream the ranks out ----
@@ -988,7 +988,7 @@ __global__ __launch_bounds__(256) void rank_skew_detect_kernel(const float *__re
     for (int i = threadIdx.x; i < NBIN; i += 256) hist[i] = 0;
     if (threadIdx.x == 0) best = 0;
     if (threadIdx.x < 3) { row_max[threadIdx.x] = 0; row_below[threadIdx.x] = 0; }
-    __syncthreads();
+    wg_barrier();
     const int cols = N < 1024 ? N : 1024;
     for (int r = 0; r < 3; r++) {
         const int64_t row = (r == 0) ? 0 : (r == 1 ? Q / 2 : Q - 1);
@@ -999,7 +999,7 @@ __global__ __launch_bounds__(256) void rank_skew_detect_kernel(const float *__re
             if (k != 0xFFFFFFFFu) atomicMax(&row_max[r], k);
         }
     }
-    __syncthreads();
+    wg_barrier();
     // two-pass candidates: (nearly) every sampled key of every sampled row within RR_TWO_SPAN codes of the row's largest one --
     // one sampled key below the window stands for ~N / 1024 in the row; each row checks itself again inside the kernel
     for (int r = 0; r < 3; r++) {
@@ -1012,7 +1012,7 @@ __global__ __launch_bounds__(256) void rank_skew_detect_kernel(const float *__re
     uint32_t mine = 0;
     for (int i = threadIdx.x; i < NBIN; i += 256) mine = hist[i] > mine ? hist[i] : mine;
     atomicMax(&best, mine);
-    __syncthreads();
+    wg_barrier();
     // peeling pays from roughly a 30 % share of one digit (two-valued Euclidean rows: ~50 %; mixed-sign cosine rows: ~10 %)
     if (threadIdx.x == 0) {
         const bool two = two_ok && row_below[0] <= 4 && row_below[1] <= 4 && row_below[2] <= 4;   // ~N / 1024 keys of the row per sampled key
@@ -1205,7 +1205,7 @@ __global__ __launch_bounds__(MG_THREADS) void rank_merge_kernel(const MergeLevel
     // ---- both parts of the tile -> LDS: [0, na) from run A, [na, tot) from run B ----
     merge_stage<PLANES>(L, r, 2 * p, a0, na, sK, sI, 0, tid);
     merge_stage<PLANES>(L, r, 2 * p + 1, b0, nb, sK, sI, na, tid);
-    __syncthreads();
+    wg_barrier();
     // ---- this thread's VT outputs start at diagonal d of the tile: merge path through LDS ----
     const int d = tid * VT < tot ? tid * VT : tot;
     int lo = d > nb ? d - nb : 0, hi = d < na ? d : na;
@@ -1229,12 +1229,12 @@ __global__ __launch_bounds__(MG_THREADS) void rank_merge_kernel(const MergeLevel
         if (take_a) { a++; ka = sK[a < na ? a : 0]; }
         else { b++; kb = sK[na + (b < nb ? b : 0)]; }
     }
-    __syncthreads();
+    wg_barrier();
     if constexpr (OUT_RANKS) {
         // ---- transpose through LDS: 16-byte stores of consecutive ranks ----
 #pragma unroll
         for (int i = 0; i < VT; i++) sK[tid * VT + i] = out[i];
-        __syncthreads();
+        wg_barrier();
         if constexpr (IDX64) {
             int64_t *o = (int64_t *)rank + r * ldr + o0;
             for (int j = tid * 2; j < tot; j += MG_THREADS * 2) {
@@ -1254,12 +1254,12 @@ __global__ __launch_bounds__(MG_THREADS) void rank_merge_kernel(const MergeLevel
         const int64_t ob = r * L.ld + (int64_t)(2 * p) * L.run_n + o0;
 #pragma unroll
         for (int i = 0; i < VT; i++) sK[tid * VT + i] = outk[i];
-        __syncthreads();
+        wg_barrier();
         for (int j = tid; j < tot; j += MG_THREADS) out_key[ob + j] = sK[j];
-        __syncthreads();
+        wg_barrier();
 #pragma unroll
         for (int i = 0; i < VT; i++) sK[tid * VT + i] = out[i];
-        __syncthreads();
+        wg_barrier();
         for (int j = tid; j < tot; j += MG_THREADS) out_idx[ob + j] = sK[j];
     }
 }
@@ -1410,7 +1410,7 @@ __global__ __launch_bounds__(RR_THREADS) void rank_order_probe_kernel(uint32_t *
     __shared__ uint32_t cnt[RR_WAVES][RK_NB], ref[RR_WAVES][RK_NB];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int i = lane; i < RK_NB; i += WAVE) { cnt[wave][i] = 0; ref[wave][i] = 0; }
-    __syncthreads();
+    wg_barrier();
     const uint32_t cb = lds_off(&cnt[wave][0]);
     uint32_t bad = 0, seed = (blockIdx.x * RR_THREADS + threadIdx.x) * 2654435761u + 12345u;
     const int mode = blockIdx.x & 3;
@@ -1430,9 +1430,9 @@ __global__ __launch_bounds__(RR_THREADS) void rank_order_probe_kernel(uint32_t *
     }
     // ---- the same property under PRODUCTION conditions: packed 16-bit counter halves (increment 1 or 1 << 16 on the shared word),
     // eight returning adds in flight per lane before the first result is looked at, all eight waves hammering their tables ----
-    __syncthreads();
+    wg_barrier();
     for (int i = lane; i < RK_NB; i += WAVE) { cnt[wave][i] = 0; ref[wave][i] = 0; }   // ref: low half = expected count of (word, half 0), high half = of half 1
-    __syncthreads();
+    wg_barrier();
     for (int batch = 0; batch < 6; batch++) {
         uint32_t got[8], dw[8], dh[8];
 #pragma unroll
@@ -1458,9 +1458,9 @@ __global__ __launch_bounds__(RR_THREADS) void rank_order_probe_kernel(uint32_t *
             const uint32_t want = (dh[j] ? (packed >> 16) : (packed & 0xFFFFu)) + rnk;
             const uint32_t mine = dh[j] ? (got[j] >> 16) : (got[j] & 0xFFFFu);
             bad += (mine != want);
-            __builtin_amdgcn_s_barrier();   // (every lane has read ref before the group leaders update it; whole workgroup in lockstep)
+            wg_barrier();   // (every lane has read ref before the group leaders update it; whole workgroup in lockstep)
             if (rnk == 0) atomicAdd(&ref[wave][dw[j]], (64u - (uint32_t)(__popc(dlo) + __popc(dhi))) << (dh[j] ? 16 : 0));
-            __builtin_amdgcn_s_barrier();
+            wg_barrier();
         }
     }
     for (int off = 32; off > 0; off >>= 1) bad += __shfl_xor(bad, off, 64);
@@ -1487,7 +1487,7 @@ __global__ __launch_bounds__(RC_THREADS) void rank_check_kernel(const float *__r
     for (int64_t row = (int64_t)blockIdx.x * row_stride; row < Q; row += (int64_t)gridDim.x * row_stride) {
         const float *drow = pdist + row * ldp;
         if (threadIdx.x == 0) wg_bad = 0;
-        __syncthreads();
+        wg_barrier();
         uint32_t mine = 0;
         for (int r0 = threadIdx.x * RC_PER; r0 < N; r0 += RC_THREADS * RC_PER) {
             uint32_t pk = 0, pi = 0;
@@ -1505,12 +1505,12 @@ __global__ __launch_bounds__(RC_THREADS) void rank_check_kernel(const float *__r
             }
         }
         if (mine) atomicOr(&wg_bad, 1u);
-        __syncthreads();
+        wg_barrier();
         if (threadIdx.x == 0 && wg_bad) {
             const uint32_t slot = atomicAdd(&bad[0], 1u);
             if ((int)slot < cap) bad[1 + slot] = (uint32_t)row;
         }
-        __syncthreads();
+        wg_barrier();
     }
 }
 

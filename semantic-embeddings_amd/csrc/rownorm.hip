@@ -67,12 +67,12 @@ __device__ float np_row_sqsum_staged(const float *__restrict__ x, int64_t ldx, i
         if (f.stage == 0) {
             if (f.n <= RN_CHUNK) {
                 // stage columns [off, off+n) of the 64 rows
-                __syncthreads();
+                wg_barrier();
                 for (int idx = tid; idx < RN_ROWS * f.n; idx += RN_ROWS) {
                     const int r = idx / f.n, c = idx - r * f.n;
                     lds[r * RN_LD + c] = (row0 + r < nrows) ? x[(row0 + r) * ldx + f.off + c] : 0.f;
                 }
-                __syncthreads();
+                wg_barrier();
                 ret = np_leaf_sqsum(lds + tid * RN_LD, f.n);
                 sp--;
             } else {
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(RN_ROWS) void rownorm_kernel(float *__restrict__ x,
         return;
     }
     snorm[threadIdx.x] = sqrtf(ss);
-    __syncthreads();
+    wg_barrier();
     const int64_t rows = (n - row0 < RN_ROWS) ? (n - row0) : RN_ROWS;
     for (int64_t r = 0; r < rows; r++) {
         const float nrm = snorm[r];

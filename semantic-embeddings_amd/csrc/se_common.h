@@ -44,6 +44,18 @@ inline const char *tuning_env(const char *) { return nullptr; }
 constexpr bool kTuning = false;
 #endif
 
+// Work-group barrier of every kernel in this library: drain this wave's LDS queue, THEN barrier.
+// __syncthreads() alone is not enough on gfx950 with this compiler: for a barrier at a loop header the waitcnt pass can leave
+// the back edge without an s_waitcnt lgkmcnt(0) between the previous stage's ds_write and the s_barrier (seen in the ISA of the
+// LDS bitonic sort of topk_rows_kernel).  The stores are then still queued when the wave signals the barrier; the next stage's
+// reader on another SIMD normally loses that race, but not when a second kernel's waves share the SIMD's LDS queue --
+// se_topk_rows returned the right k entries in the wrong order in ~1 of 5 calls with another stream busy.
+__device__ __forceinline__ void wg_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
 // Order-preserving float32 -> uint32 key of the canonical ranking order:
 // ascending value, -0.0 == +0.0, every NaN maps to 0xFFFFFFFF (sorted last).
 __device__ __forceinline__ uint32_t canon_key(float f)

@@ -34,7 +34,7 @@ __device__ __forceinline__ void bitonic_sort_u64(uint64_t *v, int P, int nthread
 {
     for (int k = 2; k <= P; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
-            __syncthreads();
+            wg_barrier();
             for (int t = threadIdx.x; t < P / 2; t += nthreads) {
                 const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));  // index with bit j clear
                 const int l = i | j;
@@ -44,7 +44,7 @@ __device__ __forceinline__ void bitonic_sort_u64(uint64_t *v, int P, int nthread
             }
         }
     }
-    __syncthreads();
+    wg_barrier();
 }
 
 // One row: exact radix SELECT of the k-th smallest canonical key, tie-aware collection, sort, output (whole workgroup).
@@ -69,14 +69,14 @@ __device__ __forceinline__ void topk_select_row(const float *__restrict__ drow, 
             const int shift = (pass == 0) ? 21 : (pass == 1 ? 10 : 0);
             const int nb = (pass == 2) ? 10 : 11;
             const uint32_t dmask = (1u << nb) - 1u;
-            __syncthreads();
+            wg_barrier();
             for (int i = tid; i < TK_NB; i += TK_THREADS) hist[i] = 0;
-            __syncthreads();
+            wg_barrier();
             for (int i = tid; i < N; i += TK_THREADS) {
                 const uint32_t key = canon_key(drow[i]);
                 if ((key & prefix_mask) == prefix) atomicAdd(&hist[(key >> shift) & dmask], 1u);
             }
-            __syncthreads();
+            wg_barrier();
             // wave 0 scans the histogram to find the digit holding the `remaining`-th key
             if (wave == 0) {
                 constexpr int PER = TK_NB / WAVE;  // 32 bins per lane
@@ -102,7 +102,7 @@ __device__ __forceinline__ void topk_select_row(const float *__restrict__ drow, 
                     }
                 }
             }
-            __syncthreads();
+            wg_barrier();
             prefix |= ctl[0] << shift;
             prefix_mask |= dmask << shift;
             remaining = ctl[1];
@@ -112,7 +112,7 @@ __device__ __forceinline__ void topk_select_row(const float *__restrict__ drow, 
         const uint32_t n_lt = (uint32_t)k - need_ties;
 
         // ---------- collect: keys < kth (any order) + the `need_ties` lowest-index ties ----------
-        __syncthreads();
+        wg_barrier();
         if (tid == 0) ctl[2] = 0;
         // per-wave tie counts (index order matters for ties)
         uint32_t myties = 0;
@@ -121,7 +121,7 @@ __device__ __forceinline__ void topk_select_row(const float *__restrict__ drow, 
         for (int off = 32; off > 0; off >>= 1) myties += __shfl_xor(myties, off, 64);
         if (lane == 0) wcnt[wave] = myties;
         for (int i = tid; i < P; i += TK_THREADS) cand[i] = ~0ull;
-        __syncthreads();
+        wg_barrier();
         uint32_t tie_base = 0;
         for (int w = 0; w < wave; w++) tie_base += wcnt[w];
         const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -142,7 +142,7 @@ __device__ __forceinline__ void topk_select_row(const float *__restrict__ drow, 
             }
             tie_base += (uint32_t)__popcll(tie_ballot);
         }
-        __syncthreads();
+        wg_barrier();
 
         // ---------- sort the k survivors on (key, index) and emit ----------
         bitonic_sort_u64(cand, P, TK_THREADS);
@@ -197,10 +197,10 @@ __device__ __forceinline__ void blocked_bitonic_sort(T (&v)[PER], T *lds)
         int j = k >> 1;
 #pragma unroll 1
         for (; j >= 64 * PER; j >>= 1) {               // partner in another wave: through LDS
-            __syncthreads();
+            wg_barrier();
 #pragma unroll
             for (int r = 0; r < PER; r++) lds[tid * PER + r] = v[r];
-            __syncthreads();
+            wg_barrier();
 #pragma unroll
             for (int r = 0; r < PER; r++) {
                 const T o = lds[(tid * PER + r) ^ j];
@@ -253,7 +253,7 @@ __device__ __forceinline__ void bitonic_sort_u32(uint32_t *v, int P, int nthread
 {
     for (int k = 2; k <= P; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
-            __syncthreads();
+            wg_barrier();
             for (int t = threadIdx.x; t < P / 2; t += nthreads) {
                 const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
                 const int l = i | j;
@@ -263,7 +263,7 @@ __device__ __forceinline__ void bitonic_sort_u32(uint32_t *v, int P, int nthread
             }
         }
     }
-    __syncthreads();
+    wg_barrier();
 }
 
 __global__ __launch_bounds__(TK_THREADS, 4) void topk_sample_kernel(const float *__restrict__ pdist, int64_t ldp, int64_t Q, int N,
@@ -277,18 +277,18 @@ __global__ __launch_bounds__(TK_THREADS, 4) void topk_sample_kernel(const float 
     const int tid = threadIdx.x;
     for (int64_t row = blockIdx.x; row < Q; row += gridDim.x) {
         const float *drow = pdist + row * ldp;
-        __syncthreads();
+        wg_barrier();
         {   // 2048 evenly spaced sample keys, 4 per thread, sorted in registers (+ 2 LDS stages); rank r is the pivot
             uint32_t sv[TK_SAMPLES / TK_THREADS];
 #pragma unroll
             for (int r = 0; r < TK_SAMPLES / TK_THREADS; r++)
                 sv[r] = canon_key(drow[(int64_t)(tid * (TK_SAMPLES / TK_THREADS) + r) * N / TK_SAMPLES]);
             blocked_bitonic_sort<uint32_t, TK_SAMPLES / TK_THREADS>(sv, smp);
-            __syncthreads();
+            wg_barrier();
 #pragma unroll
             for (int r = 0; r < TK_SAMPLES / TK_THREADS; r++) smp[tid * (TK_SAMPLES / TK_THREADS) + r] = sv[r];
             if (tid == 0) ctl[0] = 0;
-            __syncthreads();
+            wg_barrier();
         }
         const uint32_t pivot = smp[pivot_rank];
         // ---- one pass: collect (key, index) with key <= pivot ----
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(TK_THREADS, 4) void topk_sample_kernel(const float 
                 }
             }
         }
-        __syncthreads();
+        wg_barrier();
         const uint32_t total = ctl[0];
         if (total < (uint32_t)k || total > (uint32_t)TK_CAP) {      // uniform: hand the row to the exact kernel
             if (tid == 0) out_i[row * k] = TK_REDO;
@@ -325,9 +325,9 @@ __global__ __launch_bounds__(TK_THREADS, 4) void topk_sample_kernel(const float 
             cv[r] = (e < (int)total) ? cand[e] : ~0ull;                                       \
         }                                                                                     \
         blocked_bitonic_sort<uint64_t, PER>(cv, cand);                                        \
-        __syncthreads();                                                                      \
+        wg_barrier();                                                                      \
         _Pragma("unroll") for (int r = 0; r < PER; r++) cand[tid * PER + r] = cv[r];          \
-        __syncthreads();                                                                      \
+        wg_barrier();                                                                      \
     }
         if (total <= TK_THREADS) TK_SORT_CAND(1)
         else if (total <= 2 * TK_THREADS) TK_SORT_CAND(2)
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(256) void topk_merge_kernel(const float *__restrict
     extern __shared__ __attribute__((aligned(16))) uint64_t mg_lds[];
     const int m = parts * k;
     for (int64_t row = blockIdx.x; row < Q; row += gridDim.x) {
-        __syncthreads();
+        wg_barrier();
         for (int t = threadIdx.x; t < P; t += 256) {
             uint64_t v = ~0ull;
             if (t < m) {
@@ -755,7 +755,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_lists_kernel(const uint2 *__r
             continue;
         }
         const uint2 *lst = lists + row * cap;
-        __syncthreads();     // the previous row's output reads of cand are done
+        wg_barrier();     // the previous row's output reads of cand are done
 #define TK_SORT_LIST(PER)                                                                     \
     {                                                                                         \
         uint64_t cv[PER];                                                                     \
@@ -765,9 +765,9 @@ __global__ __launch_bounds__(TK_THREADS) void topk_lists_kernel(const uint2 *__r
             if (e < (int)total) { const uint2 c = lst[e]; cv[r] = ((uint64_t)canon_key(__uint_as_float(c.x)) << 32) | c.y; } \
         }                                                                                     \
         blocked_bitonic_sort<uint64_t, PER>(cv, cand);                                        \
-        __syncthreads();                                                                      \
+        wg_barrier();                                                                      \
         _Pragma("unroll") for (int r = 0; r < PER; r++) if (tid * PER + r < k) cand[tid * PER + r] = cv[r]; \
-        __syncthreads();                                                                      \
+        wg_barrier();                                                                      \
     }
         if (total <= TK_THREADS) TK_SORT_LIST(1)
         else if (total <= 2 * TK_THREADS) TK_SORT_LIST(2)
@@ -815,9 +815,9 @@ __global__ __launch_bounds__(TK_THREADS) void topk_fallback_kernel(const float *
             else v = (sqg[c] + sq_q) - 2.0f * tot;
             drow[c] = v;
         }
-        __syncthreads();     // (global writes of this workgroup are visible to it after the barrier)
+        wg_barrier();     // (global writes of this workgroup are visible to it after the barrier)
         topk_select_row(drow, N, col_offset, k, P, out_d + row * k, out_i + row * k, tk_lds64);
-        __syncthreads();
+        wg_barrier();
     }
 }
 

@@ -114,3 +114,21 @@ def test_no_unsynchronised_function_local_state_in_the_library():
             if m and "std::mutex" not in line and "guarded by mu" not in line and "(" not in line.split("=")[0]:
                 bad.append("%s:%d: %s" % (f, ln, line.strip()))
     assert not bad, bad
+
+
+def test_every_work_group_barrier_drains_the_lds_queue_first():
+    """Round 4 bug: one barrier of the LDS bitonic sort was compiled without `s_waitcnt lgkmcnt(0)` on its loop back edge and
+    se_topk_rows returned unsorted rows under two-stream contention.  Every kernel now goes through wg_barrier() (se_common.h);
+    the audit reads the SHIPPED code objects, and the sources may not go back to a bare barrier."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import isa_barrier_audit
+    import sehip
+    kernels, barriers, bare = isa_barrier_audit.audit(sehip.LIB_PATH)
+    assert barriers > 500 and len(kernels) > 100, (barriers, len(kernels))        # the audit did see the kernels
+    assert not bare, bare[:5]
+    csrc = os.path.join(ROOT, "semantic-embeddings_amd", "csrc")
+    for name in sorted(os.listdir(csrc)):
+        if name.endswith(".hip"):
+            src = re.sub(r"//.*", "", open(os.path.join(csrc, name)).read())
+            assert not re.search(r"__syncthreads\s*\(\s*\)|__builtin_amdgcn_s_barrier", src), name

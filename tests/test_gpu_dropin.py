@@ -516,10 +516,15 @@ def _sharded_topk_worker(rank, world, port, out, d=200, kblocks=None):
     sehip.normalize_rows_(g)
     sehip.normalize_rows_(q)
     dd, i = sr.sharded_topk(q, g, 251, lo_, metric=sehip.METRIC_COSINE, kblocks=kblocks)      # the real kernels: se_retrieve_topk + se_topk_merge
+    # this rank's own shard once more, checked against the oracle here (if the merged result is ever wrong, this says which stage was)
+    ld_, li_ = sehip.retrieve_topk(q, g, 251, metric=sehip.METRIC_COSINE, col_offset=lo_, kblocks=kblocks)
+    wd_, wi_ = ro.canon_topk_rows(ro.canon_pdist(q.cpu().numpy(), g.cpu().numpy(), ro.METRIC_COSINE, kblocks=kblocks), 251, col_offset=lo_)
+    local_ok = bool(np.array_equal(li_.cpu().numpy(), wi_) and np.array_equal(ld_.cpu().numpy(), wd_))
     both = [None] * world
-    dist.all_gather_object(both, i.cpu().numpy().tobytes())
+    dist.all_gather_object(both, (i.cpu().numpy().tobytes(), local_ok))
     if rank == 0:
-        np.savez(out, d=dd.cpu().numpy(), i=i.cpu().numpy(), gallery=gallery, queries=queries, same=both[0] == both[1])
+        np.savez(out, d=dd.cpu().numpy(), i=i.cpu().numpy(), gallery=gallery, queries=queries, same=both[0][0] == both[1][0],
+                 local_ok=np.array([b[1] for b in both]))
     dist.destroy_process_group()
 
 
@@ -537,7 +542,13 @@ def test_sharded_gallery_topk_two_processes_real_kernels(tmp_path, d, kblocks, p
     gal = ro.canon_normalize_rows(g["gallery"])
     qs = ro.canon_normalize_rows(g["queries"])
     wd, wi = ro.canon_topk_rows(ro.canon_pdist(qs, gal, ro.METRIC_COSINE, kblocks=kblocks), 251)
-    assert np.array_equal(g["i"], wi) and np.array_equal(g["d"], wd)
+    bad = np.nonzero((g["i"] != wi).any(axis=1) | (g["d"] != wd).any(axis=1))[0]
+    detail = ""
+    if len(bad):
+        r = int(bad[0]); c = int(np.nonzero((g["i"][r] != wi[r]) | (g["d"][r] != wd[r]))[0][0])
+        detail = "%d rows differ; first: row %d col %d got (%r, %d) want (%r, %d); per-rank shard results ok: %s" % (
+            len(bad), r, c, g["d"][r, c], g["i"][r, c], wd[r, c], wi[r, c], g["local_ok"].tolist())
+    assert not len(bad), detail
 
 
 @pytest.mark.parametrize("arch,loss", [("resnet-32", "inv_corr"), ("resnet-110-fc", "softmax_corr")])

@@ -372,3 +372,31 @@ def test_prefilter_statistics_at_full_size():
     print(line)
     redo = int(line.split("redo=")[1].split()[0])
     assert redo <= 50, line
+
+
+@pytest.mark.parametrize("side_work", ["pdist", "topk"])
+def test_topk_rows_stays_sorted_while_a_second_stream_is_busy(sehip, side_work):
+    """Regression (round 4): with another stream's kernels sharing the CUs, se_topk_rows (k = 251 -> a 256-entry LDS bitonic
+    sort over two waves) returned the right entries in the wrong order in ~1 of 5 calls: one s_barrier of the sort loop was
+    compiled without the LDS wait in front of it.  tools/stress_one_proc.py is the long version of this test."""
+    rng = np.random.default_rng(0)
+    gallery = rng.standard_normal((1501, 200)).astype(np.float32)
+    gh = ro.canon_normalize_rows(gallery)
+    pd = ro.canon_pdist(gh[:300], gh, 0)
+    k = 251
+    wd, wi = ro.canon_topk_rows(pd, k)
+    pdg = dev(pd)
+    big = dev(rng.standard_normal((6000, 200)).astype(np.float32))
+    side = torch.cuda.Stream()
+    wrong = 0
+    for it in range(120):
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                if side_work == "pdist":
+                    sehip.pairwise_dist(big, big, metric=0)
+                else:
+                    sehip.topk_rows(pdg, k)
+        d, i = sehip.topk_rows(pdg, k)
+        wrong += not (np.array_equal(i.cpu().numpy(), wi) and np.array_equal(d.cpu().numpy(), wd))
+    torch.cuda.synchronize()
+    assert wrong == 0, "%d of 120 calls differ from the canonical ranking" % wrong

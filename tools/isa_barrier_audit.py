@@ -1,0 +1,87 @@
+"""Every s_barrier of every kernel in libsehip.so must have an `s_waitcnt ... lgkmcnt(0)` in front of it (only ALU work in between).
+
+Why: a work-group barrier orders LDS traffic only for stores that have LEFT the wave's LDS queue.  The compiler's waitcnt pass
+left one barrier of the LDS bitonic sort (loop header, reached over the back edge) without that wait and se_topk_rows returned
+unsorted rows whenever a second stream kept the CU's LDS pipe busy.  `wg_barrier()` (se_common.h) now
+issues the wait itself; this audit reads the shipped code objects, so a kernel that goes back to a bare __syncthreads() -- or
+a compiler that moves the wait -- is caught on the CPU, without a GPU.
+
+    python tools/isa_barrier_audit.py [path/to/libsehip.so]      # exit 1 and the offending kernels when a barrier is bare
+"""
+import os, re, struct, subprocess, sys, tempfile
+
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
+
+
+def code_objects(path):
+    """The gfx950 ELF images of the uncompressed clang offload bundles embedded in a host shared object."""
+    blob = open(path, "rb").read()
+    out = []
+    for m in re.finditer(MAGIC, blob):
+        base = m.start()
+        (n,) = struct.unpack_from("<Q", blob, base + len(MAGIC))
+        pos = base + len(MAGIC) + 8
+        for _ in range(n):
+            off, size, tlen = struct.unpack_from("<QQQ", blob, pos)
+            triple = blob[pos + 24:pos + 24 + tlen].decode()
+            pos += 24 + tlen
+            if "amdgcn" in triple and size:
+                out.append((triple, blob[base + off:base + off + size]))
+    return out
+
+
+def audit(path):
+    """-> (kernels, barriers, bare) with bare = [(kernel, address, reason)].
+
+    A barrier passes when, walking back from it, an `s_waitcnt` with lgkmcnt(0) is met before any LDS instruction, any
+    branch and any branch target (the scheduler may slide ALU work between the wait and the barrier; nothing else)."""
+    kernels, barriers, bare = set(), 0, []
+    for triple, image in code_objects(path):
+        with tempfile.NamedTemporaryFile(suffix=".co") as f:
+            f.write(image); f.flush()
+            text = subprocess.run([OBJDUMP, "-d", "--no-show-raw-insn", f.name], check=True, capture_output=True, text=True).stdout
+        funcs, cur = [], None                          # [(name, start address, [(address, instruction)])]
+        for ln in text.split("\n"):
+            m = re.match(r"^([0-9a-f]+) <([^>]+)>:", ln)
+            if m:
+                cur = (m.group(2), int(m.group(1), 16), [])
+                funcs.append(cur)
+                continue
+            m = re.match(r"^\s+(\S.*?)\s+// ([0-9A-F]+): ", ln)
+            if m and cur is not None:
+                cur[2].append((int(m.group(2), 16), m.group(1), ln))
+        for name, start, body in funcs:
+            targets = set()
+            for addr, ins, ln in body:
+                if ins.startswith("s_branch") or ins.startswith("s_cbranch"):
+                    m = re.search(r"<[^>]+\+0x([0-9a-f]+)>\s*$", ln)
+                    targets.add(start + int(m.group(1), 16) if m else -1)
+            for i, (addr, ins, ln) in enumerate(body):
+                if not ins.startswith("s_barrier"):
+                    continue
+                barriers += 1
+                kernels.add(name)
+                reason, j = "start of kernel", i
+                while j > 0:
+                    if body[j][0] in targets:
+                        reason = "branch target at %x before a wait" % body[j][0]; break
+                    j -= 1
+                    p = body[j][1]
+                    if p.startswith("s_waitcnt") and "lgkmcnt(0)" in p:
+                        reason = None; break
+                    if p.startswith("ds_") or p.startswith("s_branch") or p.startswith("s_cbranch") or p.startswith("s_barrier"):
+                        reason = "reaches `%s` first" % p; break
+                if reason:
+                    bare.append((name, "%x" % addr, reason))
+    return kernels, barriers, bare
+
+
+if __name__ == "__main__":
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = sys.argv[1] if len(sys.argv) > 1 else os.path.join(here, "semantic-embeddings_amd", "sehip", "libsehip.so")
+    k, b, bare = audit(lib)
+    print("%s: %d barriers in %d kernels, %d without the LDS wait" % (os.path.basename(lib), b, len(k), len(bare)))
+    for kern, addr, why in bare[:40]:
+        print("  bare barrier in %s at %s: %s" % (kern[:90], addr, why))
+    sys.exit(1 if bare else 0)
