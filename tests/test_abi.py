@@ -127,6 +127,7 @@ def test_every_work_group_barrier_drains_the_lds_queue_first():
     kernels, barriers, bare = isa_barrier_audit.audit(sehip.LIB_PATH)
     assert barriers > 500 and len(kernels) > 100, (barriers, len(kernels))        # the audit did see the kernels
     assert not bare, bare[:5]
+    assert isa_barrier_audit.hazards(sehip.LIB_PATH) == []                         # the path-sensitive form of the same question
     csrc = os.path.join(ROOT, "semantic-embeddings_amd", "csrc")
     for name in sorted(os.listdir(csrc)):
         if name.endswith(".hip"):
