@@ -922,6 +922,13 @@ __device__ __forceinline__ float rf_chain(const float *__restrict__ g, const flo
     return tot;
 }
 
+#ifdef SE_TUNING
+__device__ unsigned long long rf_prof[8];      // tuning build, SE_TOPK_VERBOSE: cycles per phase of pf_refine_kernel, summed over every wave
+#define RF_T(i) if (stats) { const uint64_t now = __builtin_amdgcn_s_memtime(); t_acc[i] += now - t_last; t_last = now; }
+#else
+#define RF_T(i)
+#endif
+
 template <int METRIC, bool VEC>
 __global__ __launch_bounds__(RF_WAVES * 64) void pf_refine_kernel(const uint2 *__restrict__ lists, const unsigned *__restrict__ rowcnt, int64_t cap, int parts, int64_t Q,
                                                                   const float *__restrict__ thr, const float *__restrict__ eps,
@@ -936,8 +943,12 @@ __global__ __launch_bounds__(RF_WAVES * 64) void pf_refine_kernel(const uint2 *_
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t *hist = hist_all[wave], *sel = sel_all[wave];
     uint64_t *comp = comp_all[wave];
+#ifdef SE_TUNING
+    uint64_t t_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_last = stats ? __builtin_amdgcn_s_memtime() : 0;
+#endif
     for (int64_t row = (int64_t)blockIdx.x * RF_WAVES + wave; row < Q; row += (int64_t)gridDim.x * RF_WAVES) {
         const int64_t urow = __builtin_amdgcn_readfirstlane((int)row);          // (Q < 2^31: the launcher checks)
+        RF_T(7)
         // the query's candidates: `parts` sub-lists (one per gallery range of the filter pass) of up to `cap` entries each
         const uint2 *lst = lists + urow * parts * cap;
         const unsigned *cnts = rowcnt + urow * parts;
@@ -949,6 +960,7 @@ __global__ __launch_bounds__(RF_WAVES * 64) void pf_refine_kernel(const uint2 *_
             total += c;
         }
         ok = ok && total >= (unsigned)k;
+        RF_T(0)
         // ---- lists of up to RF_MAX entries are STAGED in LDS first, every load of the query in flight at once: the five passes below
         //      otherwise each walk the sub-lists with dependent global loads (~80 serialised round trips per query: 0.8 of the kernel's
         //      1.4 ms at 50k x 50k x 100).  Entry e of the concatenated list lives in sub-list p = the last one with pre[p] <= e. ----
@@ -992,6 +1004,7 @@ __global__ __launch_bounds__(RF_WAVES * 64) void pf_refine_kernel(const uint2 *_
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
+        RF_T(1)
         uint32_t m = 0;
         float B = 0.f;
         const float e_q = eps[urow], thr_q = thr[urow];
@@ -1044,6 +1057,7 @@ __global__ __launch_bounds__(RF_WAVES * 64) void pf_refine_kernel(const uint2 *_
                 pmask |= 255u << shift;
             }
             const uint32_t kth = prefix;
+            RF_T(2)
             ok = kth != 0xFFFFFFFFu && e_q == e_q;                                  // fewer than k finite d~, or an irregular query
             if (ok) {
                 const float b1 = key_to_float(kth) + 2.05f * e_q;
@@ -1081,6 +1095,7 @@ __global__ __launch_bounds__(RF_WAVES * 64) void pf_refine_kernel(const uint2 *_
                 ok = m <= (uint32_t)RF_MAX;
             }
         }
+        RF_T(3)
         if (ok) {
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             // ---- exact distances of R: one lane per candidate, the canonical fmaf chain over its gallery row ----
@@ -1096,6 +1111,7 @@ __global__ __launch_bounds__(RF_WAVES * 64) void pf_refine_kernel(const uint2 *_
                 if (e < m) comp[e] = ((uint64_t)canon_key(v) << 32) | gi;
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            RF_T(4)
             // ---- sort R on (key, index); accept iff the k-th exact distance is <= B - eps ----
             uint32_t kkey = 0;
 #define RF_SORT_OUT(P2)                                                                        \
@@ -1120,6 +1136,7 @@ __global__ __launch_bounds__(RF_WAVES * 64) void pf_refine_kernel(const uint2 *_
             else RF_SORT_OUT(16)
 #undef RF_SORT_OUT
             kkey = (uint32_t)(comp[k - 1] >> 32);
+            RF_T(5)
             const float dk = kkey == 0xFFFFFFFFu ? __builtin_nanf("") : key_to_float(kkey);
             ok = dk <= B - 1.01f * e_q;                     // false for NaN
             if (ok) {
@@ -1133,7 +1150,12 @@ __global__ __launch_bounds__(RF_WAVES * 64) void pf_refine_kernel(const uint2 *_
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         }
         if (!ok && lane == 0) { out_i[urow * k] = TK_REDO; atomicAdd(&nflag[1], 1u); }
+        RF_T(6)
     }
+#ifdef SE_TUNING
+    if (stats && lane == 0)
+        for (int i = 0; i < 8; i++) atomicAdd(&rf_prof[i], (unsigned long long)t_acc[i]);
+#endif
 }
 
 }  // namespace se
@@ -1263,6 +1285,7 @@ static int retrieve_topk_prefilter(const float *queries, int64_t ldq, const floa
         rc = pf_pass(PF_EPI_FILTER, &L.geom, metric, gimg, kp, qi, kp, sqg, sq, n, rows, kp, ctl, qc, pa, s);
         if (rc != SE_OK) return rc;
         const bool verbose = kTuning && tuning_env("SE_TOPK_VERBOSE");
+
         const int64_t rgrid = (rows + RF_WAVES - 1) / RF_WAVES < 8192 ? (rows + RF_WAVES - 1) / RF_WAVES : 8192;
 #define SE_RF_LAUNCH(M, V) hipLaunchKernelGGL((pf_refine_kernel<M, V>), dim3((unsigned)rgrid), dim3(RF_WAVES * 64), 0, s, lists, rowcnt, L.cap, L.parts, rows, thr, eps, qs, ldq, \
                                               gallery, ldg, sq, sqg, kbs, col_offset, k, out_d + q0 * k, out_i + q0 * k, nflag, verbose ? nflag + 2 : nullptr)
@@ -1272,6 +1295,19 @@ static int retrieve_topk_prefilter(const float *queries, int64_t ldq, const floa
         SE_LAUNCH_CHECK();
         if (verbose) {   // -DSE_TUNING build only: synchronises and reports how the lists came out
             SE_HIP_CHECK(hipStreamSynchronize(s));
+#ifdef SE_TUNING
+            {
+                unsigned long long hp[8], zero[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                SE_HIP_CHECK(hipMemcpyFromSymbol(hp, HIP_SYMBOL(rf_prof), sizeof(hp)));
+                SE_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(rf_prof), zero, sizeof(zero)));
+                static const char *names[8] = {"counts", "stage-lists", "select-kth", "compact", "chains", "sort", "accept+write", "loop"};
+                double tot = 0;
+                for (int i = 0; i < 8; i++) tot += (double)hp[i];
+                fprintf(stderr, "[pf_refine_kernel profile]");
+                for (int i = 0; i < 8; i++) fprintf(stderr, " %s %.1f%%", names[i], 100.0 * (double)hp[i] / (tot > 0 ? tot : 1));
+                fprintf(stderr, "  (%.0f cycles per query and wave)\n", tot / (double)rows);
+            }
+#endif
             unsigned h[4], hc[8];
             SE_HIP_CHECK(hipMemcpy(h, nflag, sizeof(h), hipMemcpyDeviceToHost));
             SE_HIP_CHECK(hipMemcpy(hc, ctl, sizeof(hc), hipMemcpyDeviceToHost));
