@@ -671,3 +671,14 @@ def test_cifar_pipeline_on_the_device_matches_reference_and_augmentation_statist
     got = gen.apply_transform(gen.compose_batch(np.arange(n), train=True, augment=False).contiguous(), torch.from_numpy(p[:, 0]).float().cuda(),
                               torch.from_numpy(p[:, 1]).float().cuda(), torch.from_numpy(p[:, 2] != 0).cuda())
     assert np.abs(got.permute(0, 2, 3, 1).cpu().numpy() - g["aug_X"]).max() < 2e-4
+
+
+def test_entry_points_under_two_stream_contention():
+    """tools/stress_streams.py (short form): every retrieval / loss entry point, called while a second stream keeps the CUs busy,
+    returns what it returns alone, bit for bit (round 4: se_topk_rows did not -- DESIGN.md section 5.6)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "stress_streams.py"), "4"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "stress_streams: 0 differing calls" in r.stdout
