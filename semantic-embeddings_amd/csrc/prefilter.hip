@@ -32,6 +32,7 @@
 //                                      transposition, no barrier
 //                         PF_STORE     (tuning build only) d~ matrix out, for the hardware-assumption test of the error bound
 #include "se_common.h"
+#include <type_traits>
 
 namespace se {
 
@@ -543,6 +544,293 @@ __global__ __launch_bounds__(PF_THREADS, PF_WGS_PER_CU) void pf_tile_kernel(
 #undef PF_TILE_SIDE
 }
 
+// ---- big-tile filter kernel (long rows: kp >= 256) -------------------------------------------------------------------------------
+// The 128 x 128 kernel above needs three pipes of a CU at 100 % at the same moment to keep the matrix core busy: with 64 x 64 outputs
+// per wave every v_mfma_f32_32x32x16_f16 (32 cycles) reads 1 KB of fragments out of LDS (128 B / clk = the LDS peak) and every
+// 128 x 128 x 128 chunk step (1024 matrix cycles per SIMD) brings 64 KB through the L1 (64 B / clk = its fill peak) -- measured: 17 % of
+// the fp16 peak on the D = 1000 shard, `prefetch-issue` (vector-memory issue stalls) the largest phase.  This kernel halves both ratios:
+// 256 x 256 tiles, FOUR waves of 128 x 128 outputs (4 x 4 MFMA blocks, 256 accumulators in the AGPR half of a lone wave's 512
+// registers -- one workgroup per CU).  With one wave per SIMD nothing else hides a wave's own memory phases, so the operands do not
+// pass through registers at all: global_load_lds_dwordx4 writes K-chunks of 64 straight into a double-buffered LDS image (2 x 64 KB,
+// rows of 128 bytes, the 16-byte pieces XOR-swizzled on the SOURCE side so that fragment reads are conflict-free without padding),
+// requested one chunk ahead and in flight under the 64 MFMAs of the current chunk; ONE barrier per chunk.  Filter epilogue only (the
+// sample pass is small and keeps the kernel above); job / super-job order, slot counters and list format are the same.
+constexpr int PB_BM = 256, PB_BN = 256, PB_BK = 64, PB_THREADS = 256;
+constexpr int PB_ROWB = PB_BK * 2;                          // bytes of one operand row of a chunk (128) = its LDS pitch
+constexpr int PB_STAGE = (PB_BM + PB_BN) * PB_ROWB;         // bytes of one LDS stage (65,536)
+constexpr int PB_NISSUE = PB_BM * PB_ROWB / (PB_THREADS * 16);   // load instructions per wave, chunk and operand (8; 8 rows each)
+static_assert(PB_BM == PB_BN, "one loader for both operands");
+
+typedef __attribute__((address_space(1))) const void pb_gptr_t;
+typedef __attribute__((address_space(3))) void pb_lptr_t;
+
+// byte offsets (from the tile's first row) of the 16-byte pieces this lane fetches: instruction i covers tile rows wave * 64 + i * 8 + [0, 8),
+// lane l row + (l >> 3), LDS slot l & 7 <- source piece (l & 7) ^ ((row >> 1) & 7).  Rows beyond the matrix: clamped (masked by the epilogue).
+__device__ __forceinline__ void pb_offsets(uint32_t (&off)[PB_NISSUE], uint32_t ld, int64_t row0, int64_t nrows, int wave, int lane)
+{
+    const int rows_here = (int)((nrows - row0 < PB_BM) ? (nrows - row0) : PB_BM);
+#pragma unroll
+    for (int i = 0; i < PB_NISSUE; i++) {
+        const int r = wave * 64 + i * 8 + (lane >> 3);
+        const int rc = r < rows_here ? r : rows_here - 1;
+        off[i] = (uint32_t)rc * ld * 2u + (uint32_t)(((lane & 7) ^ ((r >> 1) & 7)) * 16);
+    }
+}
+
+// chunk [k0, k0 + 64) of one operand tile -> LDS image `dst` (wave-uniform; this wave's 64 rows)
+__device__ __forceinline__ void pb_issue(const char *base, const uint32_t (&off)[PB_NISSUE], int k0, char *dst, int wave)
+{
+#pragma unroll
+    for (int i = 0; i < PB_NISSUE; i++)
+        __builtin_amdgcn_global_load_lds((pb_gptr_t *)(base + (off[i] + (uint32_t)k0 * 2u)), (pb_lptr_t *)(dst + (wave * 64 + i * 8) * PB_ROWB), 16, 0, 0);
+}
+
+template <int METRIC>
+__global__ __launch_bounds__(PB_THREADS, 1) void pf_big_kernel(
+    const uint16_t *__restrict__ A, uint32_t lda, const uint16_t *__restrict__ B, uint32_t ldb, const float *__restrict__ sqa,
+    const float *__restrict__ sqb, int64_t NA, int64_t NB, int nchunks, int tiles_m, int tiles_n, int parts, int tpp, int gi, int gj,
+    const unsigned *__restrict__ ctl_a, const unsigned *__restrict__ ctl_b, PfArgs fa)
+{
+    extern __shared__ __attribute__((aligned(16))) char pf_smem[];
+    // two stages of [A rows | B rows]; side arrays behind them (see pf_tile_kernel)
+    float *tCmpCol = (float *)(pf_smem + 2 * PB_STAGE), *tSqCol = tCmpCol + PB_BN, *tSqRow = tSqCol + PB_BN, *tCmpRow = tSqRow + PB_BM;
+    unsigned *jobCnt = (unsigned *)(tCmpRow + PB_BM);
+    static_assert(PB_THREADS * 36 * 4 <= PB_STAGE, "the epilogue's half dump must fit one stage");
+    static_assert(PB_BN <= PB_THREADS && PB_BM <= PB_THREADS, "side arrays are filled by one thread per entry");
+
+    const int xcd = blockIdx.x & 7, slot_in_xcd = blockIdx.x >> 3;
+    const int gi_i = slot_in_xcd / gj, gj_j = slot_in_xcd - gi_i * gj;
+    const int nsq = (tiles_n + gi - 1) / gi, nsuper = nsq * parts;
+    const int nsub = parts * gj;
+    PfJob cur = {xcd - 8, 0, 0, 0, 0};
+    if (gi_i >= gi || !pf_next_job(cur, 8, nsq, nsuper, gi, gj, gi_i, gj_j, tiles_m, tiles_n, tpp)) return;
+    PfJob nx = cur;
+
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wm = wave >> 1, wn = wave & 1;        // 2 x 2 waves, 128 x 128 outputs each
+    const int col = lane & 31, hi = lane >> 5;
+    const int esum = (int)ctl_a[4] + (int)ctl_b[4];
+    const float unscale = ldexpf(1.0f, -esum), rescale = ldexpf(1.0f, esum);
+
+    // fragment reads: operand row (wm | wn) * 128 + block * 32 + col (block: an immediate offset of 32 rows), k16 step s = pieces 2 s + hi,
+    // stored at slot piece ^ ((row >> 1) & 7) -- the same for all four blocks (32 rows apart)
+    const int swz = (col >> 1) & 7;
+    const int rowa = (wm * 128 + col) * PB_ROWB, rowb = PB_BM * PB_ROWB + (wn * 128 + col) * PB_ROWB;
+    int fo[PB_BK / 16];
+#pragma unroll
+    for (int s = 0; s < PB_BK / 16; s++) fo[s] = ((2 * s + hi) ^ swz) * 16;
+
+    uint32_t offa[PB_NISSUE], offb[PB_NISSUE];
+    pb_offsets(offa, lda, (int64_t)cur.t * PB_BM, NA, wave, lane);
+    pb_offsets(offb, ldb, (int64_t)cur.tn * PB_BN, NB, wave, lane);
+    const char *basea = (const char *)(A + (int64_t)cur.t * PB_BM * lda), *baseb = (const char *)(B + (int64_t)cur.tn * PB_BN * ldb);
+    pb_issue(basea, offa, 0, pf_smem, wave);
+    pb_issue(baseb, offb, 0, pf_smem + PB_BM * PB_ROWB, wave);
+
+#define PB_JOB_SIDE(TN_)                                                                                             \
+    {                                                                                                                \
+        const int64_t qc_ = (int64_t)(TN_) * PB_BN + threadIdx.x;                                                    \
+        const bool ok_ = qc_ < NB;                                                                                   \
+        const float sq_ = METRIC == SE_METRIC_EUCLID ? sqb[ok_ ? qc_ : NB - 1] : 0.f;                                \
+        const float th_ = ok_ ? fa.thr[qc_] : __builtin_nanf("");                                                    \
+        float c_ = METRIC == SE_METRIC_EUCLID ? (sq_ - th_) * (0.5f * rescale) : -th_ * rescale;                     \
+        tCmpCol[threadIdx.x] = c_ == c_ ? c_ : __builtin_inff();                                                     \
+        jobCnt[threadIdx.x] = 0;                                                                                     \
+        if (METRIC == SE_METRIC_EUCLID) tSqCol[threadIdx.x] = sq_;                                                   \
+    }
+#define PB_TILE_SIDE(T_)                                                                                             \
+    if (METRIC == SE_METRIC_EUCLID) {                                                                                \
+        const int64_t gr_ = (int64_t)(T_) * PB_BM + threadIdx.x;                                                     \
+        const float sg_ = sqa[(gr_ < NA ? gr_ : NA - 1) * fa.sqa_stride];                                            \
+        tSqRow[threadIdx.x] = sg_;                                                                                   \
+        tCmpRow[threadIdx.x] = sg_ * (0.5f * rescale);                                                               \
+    }
+#ifdef SE_TUNING
+    uint64_t t_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_last = fa.prof ? __builtin_amdgcn_s_memtime() : 0;
+#define PF_T(i) if (fa.prof) { const uint64_t now = __builtin_amdgcn_s_memtime(); t_acc[i] += now - t_last; t_last = now; }
+#else
+#define PF_T(i)
+#endif
+    int buf = 0;
+    PB_JOB_SIDE(cur.tn)
+    PB_TILE_SIDE(cur.t)
+    // One tile per iteration of the outer loop, its K-chunks in the inner one.  (The accumulators are cleared in front of the inner loop
+    // and read behind it: written as ONE flat loop over chunks with a conditional epilogue, the compiler carried all 256 of them through the
+    // loop in VGPRs, copied them into AGPRs around every MFMA and spilled 200-340 registers.)
+#pragma unroll 1
+    while (true) {
+        pf_f32x16 acc[4][4];
+#pragma unroll
+        for (int mi = 0; mi < 4; mi++)
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[mi][j][r] = 0.f;
+        bool have_next = true, job_ends = false;
+#pragma unroll 1
+        for (int c = 0; c < nchunks; c++) {
+            PF_T(0)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's pieces of the chunk have landed in stage `buf`
+            wg_barrier();                                       // ... everyone's have, and everyone is done reading the other stage
+            PF_T(10)
+            // ---- request the next chunk into the other stage: same tile, next tile of the job, or first tile of this workgroup's next job ----
+            const bool last_chunk = (c + 1 == nchunks);
+            int nc = c + 1;
+            if (last_chunk) {
+                nc = 0;
+                nx.t = cur.t + gj;
+                if (nx.t >= cur.t1) {
+                    job_ends = true;
+                    have_next = pf_next_job(nx, 8, nsq, nsuper, gi, gj, gi_i, gj_j, tiles_m, tiles_n, tpp);
+                }
+                if (have_next) {
+                    pb_offsets(offa, lda, (int64_t)nx.t * PB_BM, NA, wave, lane);
+                    basea = (const char *)(A + (int64_t)nx.t * PB_BM * lda);
+                    if (job_ends) {
+                        pb_offsets(offb, ldb, (int64_t)nx.tn * PB_BN, NB, wave, lane);
+                        baseb = (const char *)(B + (int64_t)nx.tn * PB_BN * ldb);
+                    }
+                }
+            }
+            // (nothing follows this workgroup's last chunk: the requests below then fetch chunk 0 of the current tile again -- valid
+            //  addresses, a stage nobody reads -- so that the loop body has no branch around its loads)
+            char *st = pf_smem + (buf ^ 1) * PB_STAGE;
+            const uint32_t kb2 = (uint32_t)nc * (PB_BK * 2u);
+            PF_T(1)
+            // ---- MFMA over the chunk in this stage: 4 steps of k = 16, 16 blocks each; step s + 1's fragments are requested in front of
+            //      step s's MFMAs (one wave per SIMD: nobody else hides the LDS latency), and the 16 load instructions of the next chunk
+            //      are dealt one per four MFMAs: issued in a burst they filled the memory pipe's queue and the wave sat in front of its
+            //      MFMAs until the queue drained (28 % of the kernel) ----
+            const char *sa = pf_smem + buf * PB_STAGE + rowa, *sb = pf_smem + buf * PB_STAGE + rowb;
+            f16x8 af[2][4], bf[2][4];
+#pragma unroll
+            for (int mi = 0; mi < 4; mi++) af[0][mi] = __builtin_bit_cast(f16x8, *(const uint4 *)(sa + mi * 32 * PB_ROWB + fo[0]));
+#pragma unroll
+            for (int j = 0; j < 4; j++) bf[0][j] = __builtin_bit_cast(f16x8, *(const uint4 *)(sb + j * 32 * PB_ROWB + fo[0]));
+#pragma unroll
+            for (int s = 0; s < PB_BK / 16; s++) {
+                if (s + 1 < PB_BK / 16) {
+#pragma unroll
+                    for (int mi = 0; mi < 4; mi++) af[(s + 1) & 1][mi] = __builtin_bit_cast(f16x8, *(const uint4 *)(sa + mi * 32 * PB_ROWB + fo[s + 1]));
+#pragma unroll
+                    for (int j = 0; j < 4; j++) bf[(s + 1) & 1][j] = __builtin_bit_cast(f16x8, *(const uint4 *)(sb + j * 32 * PB_ROWB + fo[s + 1]));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int mi = 0; mi < 4; mi++) {
+                    const int li = s * 4 + mi;                       // load instruction 0 .. 15: A rows, then B rows
+                    if (li < PB_NISSUE)
+                        __builtin_amdgcn_global_load_lds((pb_gptr_t *)(basea + (offa[li] + kb2)), (pb_lptr_t *)(st + (wave * 64 + li * 8) * PB_ROWB), 16, 0, 0);
+                    else
+                        __builtin_amdgcn_global_load_lds((pb_gptr_t *)(baseb + (offb[li - PB_NISSUE] + kb2)),
+                                                         (pb_lptr_t *)(st + PB_BM * PB_ROWB + (wave * 64 + (li - PB_NISSUE) * 8) * PB_ROWB), 16, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) acc[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[s & 1][mi], bf[s & 1][j], acc[mi][j], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            buf ^= 1;
+            PF_T(2)
+        }
+        {
+            // ---- tile finished (its last chunk sat in stage buf ^ 1; the next tile's first chunk is on its way into stage buf).
+            //      acc[mi][j][r]: gallery row  cur_m0 + wm*128 + mi*32 + (r&3) + 8*(r>>2) + 4*hi,  query  cur_n0 + wn*128 + j*32 + col.
+            //      Scan as in pf_tile_kernel: two instructions per value (+ the AGPR read) -> per (lane, query) a 64-bit pass mask
+            //      (two words: blocks 0-1, 2-3) ----
+            const int64_t cur_m0 = (int64_t)cur.t * PB_BM, cur_n0 = (int64_t)cur.tn * PB_BN;
+            const int rows_here = (int)((NA - cur_m0 < PB_BM) ? (NA - cur_m0) : PB_BM);
+            const int cols_here = (int)((NB - cur_n0 < PB_BN) ? (NB - cur_n0) : PB_BN);
+            const int lr0 = wm * 128 + 4 * hi;
+            uint32_t mask[4][2];
+            unsigned slotj[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int lc = wn * 128 + j * 32 + col;
+                const float cq = tCmpCol[lc];
+                mask[j][0] = mask[j][1] = 0u;
+#pragma unroll
+                for (int mi = 0; mi < 4; mi++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        float cmpv = cq;
+                        if (METRIC == SE_METRIC_EUCLID) cmpv = cq + tCmpRow[lr0 + mi * 32 + (r & 3) + 8 * (r >> 2)];
+                        float tmpv;             // the accumulators live in AGPRs ("a"): read one, compare, shift the verdict into the mask
+                        asm volatile("v_accvgpr_read_b32 %1, %2\n\ts_nop 0\n\tv_cmp_nlt_f32 vcc, %1, %3\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
+                                     : "+v"(mask[j][mi >> 1]), "=&v"(tmpv) : "a"(acc[mi][j][r]), "v"(cmpv) : "vcc");
+                    }
+                if (rows_here != PB_BM) {       // last gallery tile: rows beyond the gallery were clamped reads
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        uint32_t vm = 0u;
+#pragma unroll
+                        for (int i = 0; i < 32; i++) vm |= (lr0 + (2 * h + (i >> 4)) * 32 + (i & 3) + 8 * ((i >> 2) & 3) < rows_here) ? (0x80000000u >> i) : 0u;
+                        mask[j][h] &= vm;
+                    }
+                }
+                if (lc >= cols_here) mask[j][0] = mask[j][1] = 0u;
+                const unsigned cnt = (unsigned)(__popc(mask[j][0]) + __popc(mask[j][1]));
+                slotj[j] = 0;
+                if (cnt) slotj[j] = atomicAdd(&jobCnt[lc], cnt);
+            }
+            PF_T(4)
+            wg_barrier();       // every wave is done with the last chunk's stage: it becomes the dump
+            float *mine = (float *)(pf_smem + (buf ^ 1) * PB_STAGE) + threadIdx.x * 36;      // lane-private row of 32 + 4 dwords
+            PF_T(5)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int lc = wn * 128 + j * 32 + col;
+                uint2 *lst = fa.lists + ((cur_n0 + lc) * (int64_t)nsub + (cur.p * gj + gj_j)) * fa.cap;
+                const float sbq = METRIC == SE_METRIC_EUCLID ? tSqCol[lc] : 0.f;
+                unsigned slot = slotj[j];
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    uint32_t m = mask[j][h];
+                    if (__ballot(m != 0u) == 0ull) continue;                            // (wave-uniform) nothing passed in this half
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");               // the row is private: no barrier between rounds
+#pragma unroll
+                    for (int mm = 0; mm < 2; mm++)
+#pragma unroll
+                        for (int g = 0; g < 4; g++)
+                            *(float4 *)(mine + mm * 16 + g * 4) = make_float4(acc[2 * h + mm][j][4 * g], acc[2 * h + mm][j][4 * g + 1],
+                                                                              acc[2 * h + mm][j][4 * g + 2], acc[2 * h + mm][j][4 * g + 3]);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    while (m) {
+                        const int i = __builtin_clz(m);                                   // value index: block 2h + (i >> 4), r = i & 15
+                        m &= ~(0x80000000u >> i);
+                        const int lr = lr0 + (2 * h + (i >> 4)) * 32 + (i & 3) + 8 * ((i >> 2) & 3);
+                        const float a = mine[i];
+                        const float v = pf_finish<METRIC>(a * unscale, METRIC == SE_METRIC_EUCLID ? tSqRow[lr] : 0.f, sbq);
+                        if (slot < (unsigned)fa.cap) lst[slot] = make_uint2(__float_as_uint(v), (uint32_t)(cur_m0 + lr));
+                        slot++;
+                    }
+                }
+            }
+            PF_T(6)
+            wg_barrier();       // every wave is past its reads of the side arrays and its slot reservations
+            if (job_ends) {
+                // the job is complete: its slot counters -> rowcnt[query][sub-list] (counts above the capacity mark an overflow: the query is redone)
+                const int64_t qc = (int64_t)cur.tn * PB_BN + threadIdx.x;
+                if (qc < NB) fa.rowcnt[qc * nsub + (cur.p * gj + gj_j)] = jobCnt[threadIdx.x];
+            }
+            if (!have_next) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the last (unused) requests must have landed before this workgroup's LDS is handed on
+                break;
+            }
+            if (job_ends) PB_JOB_SIDE(nx.tn)          // (thread t read jobCnt[t] above and resets it here: its own entry)
+            PB_TILE_SIDE(nx.t)
+            cur = nx;
+            PF_T(11)
+        }
+    }
+#ifdef SE_TUNING
+    if (fa.prof && threadIdx.x == 0)
+        for (int i = 0; i < 12; i++) atomicAdd(&fa.prof[i], (unsigned long long)t_acc[i]);
+#endif
+#undef PF_T
+#undef PB_JOB_SIDE
+#undef PB_TILE_SIDE
+}
+
 static int pf_num_cus()
 {
     static const int cus = [] {
@@ -562,11 +850,15 @@ static int64_t pf_grid()
 
 // geometry of a pass over n_a gallery rows x n_q queries: the gi x gj grid of workgroups per XCD (gi query tiles x gj interleaved
 // gallery tile sequences per super-job) and the number of contiguous gallery ranges `parts` (>= ~4 super-job rounds per XCD)
-PfGeom pf_geometry(int64_t n_a, int64_t n_q, int want_parts)
+// kp > 0: the FILTER pass of a problem with kp padded columns -- long rows take the 256 x 256 kernel (g.big), one workgroup per CU.
+PfGeom pf_geometry(int64_t n_a, int64_t n_q, int want_parts, int kp)
 {
-    const int64_t tiles_m = (n_a + PF_BM - 1) / PF_BM, tiles_n = (n_q + PF_BN - 1) / PF_BN;
-    const int per_xcd = (int)(pf_grid() / 8);
     PfGeom g;
+    g.big = (kp >= 256 && n_a >= 4096 && n_q >= 256) ? 1 : 0;
+    if (const char *e = tuning_env("SE_PF_BIG")) g.big = (kp > 0 && atoi(e) != 0) ? 1 : 0;      // -DSE_TUNING build: pins the kernel
+    const int bm = g.big ? PB_BM : PF_BM, bn = g.big ? PB_BN : PF_BN;
+    const int64_t tiles_m = (n_a + bm - 1) / bm, tiles_n = (n_q + bn - 1) / bn;
+    const int per_xcd = (int)((g.big ? (int64_t)pf_num_cus() / 8 * 8 : pf_grid()) / 8);
     g.gi = 8;
     if (const char *e = tuning_env("SE_PF_GI")) g.gi = atoi(e) > 0 ? atoi(e) : 8;   // -DSE_TUNING build: shape of the per-XCD workgroup grid
     while (g.gi > 1 && (g.gi > tiles_n || per_xcd % g.gi)) g.gi >>= 1;          // few queries: fewer query tiles side by side, more gallery sequences
@@ -584,6 +876,48 @@ PfGeom pf_geometry(int64_t n_a, int64_t n_q, int want_parts)
     g.tpp = (int)((tiles_m + parts - 1) / parts);
     g.parts = (int)((tiles_m + g.tpp - 1) / g.tpp);
     return g;
+}
+
+template <int METRIC>
+static int pf_launch_big(const uint16_t *a, int64_t lda, const uint16_t *b, int64_t ldb, const float *sqa, const float *sqb, int64_t na, int64_t nb,
+                         int kp, const PfGeom &g, const unsigned *ctl_a, const unsigned *ctl_b, const PfArgs &fa, hipStream_t s)
+{
+    const int64_t tiles_m = (na + PB_BM - 1) / PB_BM, tiles_n = (nb + PB_BN - 1) / PB_BN;
+    if (g.gi < 1 || g.gj < 1 || g.parts < 1 || (int64_t)g.tpp * g.parts < tiles_m || g.gj > g.tpp || kp % PB_BK)
+        return fail(SE_ERR_INVALID, "pre-filter pass: geometry %d x %d, %d parts of %d tiles does not cover %lld gallery tiles", g.gi, g.gj, g.parts, g.tpp, (long long)tiles_m);
+    if (tiles_m * tiles_n >= ((int64_t)1 << 31))
+        return fail(SE_ERR_UNSUPPORTED, "se_retrieve_topk: %lld pre-filter tiles exceed the 32-bit tile counter", (long long)(tiles_m * tiles_n));
+    if (lda * 2 * PB_BM >= ((int64_t)1 << 32) || ldb * 2 * PB_BN >= ((int64_t)1 << 32))
+        return fail(SE_ERR_UNSUPPORTED, "se_retrieve_topk: pre-filter row pitch too large for 32-bit tile offsets");
+    const size_t lds = (size_t)2 * PB_STAGE + (size_t)(2 * PB_BM + 3 * PB_BN) * sizeof(float);
+    const int64_t grid = (int64_t)8 * g.gi * g.gj;
+    auto kern = pf_big_kernel<METRIC>;
+    SE_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    PfArgs fb = fa;
+    fb.prof = nullptr;
+    static const bool profile = tuning_env("SE_PF_PROFILE") != nullptr;   // -DSE_TUNING build only: allocates, synchronises, prints
+    if (profile) {
+        SE_HIP_CHECK(hipMalloc((void **)&fb.prof, 12 * sizeof(unsigned long long)));
+        SE_HIP_CHECK(hipMemsetAsync(fb.prof, 0, 12 * sizeof(unsigned long long), s));
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(PB_THREADS), lds, s, a, (uint32_t)lda, b, (uint32_t)ldb, sqa, sqb, na, nb, kp / PB_BK,
+                       (int)tiles_m, (int)tiles_n, g.parts, g.tpp, g.gi, g.gj, ctl_a, ctl_b, fb);
+    SE_LAUNCH_CHECK();
+    if (profile) {
+        unsigned long long h[12];
+        SE_HIP_CHECK(hipStreamSynchronize(s));
+        SE_HIP_CHECK(hipMemcpy(h, fb.prof, sizeof(h), hipMemcpyDeviceToHost));
+        SE_HIP_CHECK(hipFree(fb.prof));
+        static const char *names[12] = {"loop-top", "request-next", "mfma", "-", "scan+reserve", "barrier+dump", "candidates", "-", "-", "-", "wait+barrier",
+                                        "tile-end"};
+        double tot = 0;
+        for (int i = 0; i < 12; i++) tot += (double)h[i];
+        fprintf(stderr, "[pf_big_kernel profile] metric=%d grid=%lld (8 x %d x %d) tiles=%lld x %lld chunks=%d parts=%d:", METRIC, (long long)grid,
+                g.gi, g.gj, (long long)tiles_m, (long long)tiles_n, kp / PB_BK, g.parts);
+        for (int i = 0; i < 12; i++) if (names[i][0] != '-') fprintf(stderr, " %s %.1f%%", names[i], 100.0 * (double)h[i] / tot);
+        fprintf(stderr, "  (%.0f cycles per tile per workgroup)\n", tot / (double)(tiles_m * tiles_n));
+    }
+    return SE_OK;
 }
 
 template <int METRIC, int EPI>
@@ -661,7 +995,13 @@ int pf_pass(int epi, const PfGeom *geom, int metric, const uint16_t *gallery, in
     PfArgs fa;
     fa.gm = pa.gm; fa.gm_ld = pa.gm_ld; fa.thr = pa.thr; fa.rowcnt = pa.rowcnt; fa.lists = pa.lists; fa.cap = pa.cap;
     fa.sqa_stride = pa.sqa_stride; fa.out = pa.out; fa.ldo = pa.ldo; fa.prof = nullptr;
-    const PfGeom g = geom ? *geom : pf_geometry(n_a, n_q, 1);
+    const PfGeom g = geom ? *geom : pf_geometry(n_a, n_q, 1, 0);
+    if (g.big) {
+        if (epi != PF_FILTER) return fail(SE_ERR_INVALID, "pre-filter pass: the 256 x 256 kernel only filters");
+        if (metric == SE_METRIC_COSINE) return pf_launch_big<SE_METRIC_COSINE>(gallery, lda, queries, ldq, sqg, sqq, n_a, n_q, kp, g, ctl_g, ctl_q, fa, s);
+        if (metric == SE_METRIC_EUCLID) return pf_launch_big<SE_METRIC_EUCLID>(gallery, lda, queries, ldq, sqg, sqq, n_a, n_q, kp, g, ctl_g, ctl_q, fa, s);
+        return fail(SE_ERR_UNSUPPORTED, "pre-filter pass: metric %d", metric);
+    }
     if (metric == SE_METRIC_COSINE) return pf_launch2<SE_METRIC_COSINE>(epi, gallery, lda, queries, ldq, sqg, sqq, n_a, n_q, kp, g, ctl_g, ctl_q, fa, s);
     if (metric == SE_METRIC_EUCLID) return pf_launch2<SE_METRIC_EUCLID>(epi, gallery, lda, queries, ldq, sqg, sqq, n_a, n_q, kp, g, ctl_g, ctl_q, fa, s);
     return fail(SE_ERR_UNSUPPORTED, "pre-filter pass: metric %d", metric);

@@ -135,8 +135,8 @@ int pf_convert(const float *x, int64_t ldx, int64_t n, int64_t d, uint16_t *out,
 // contiguous gallery ranges of `tpp` tiles) at a time, workgroup (i, j) walking the range's tiles j, j + gj, ...  A query's candidates of
 // (range p, sequence j) go to sub-list p * gj + j:  lists[(query * nsub + sub) * cap ...], their number to rowcnt[query * nsub + sub],
 // nsub = parts * gj.  want_parts = 0: as many ranges as keep every XCD busy for >= ~4 rounds.
-struct PfGeom { int gi, gj, parts, tpp; };
-PfGeom pf_geometry(int64_t n_a, int64_t n_q, int want_parts);
+struct PfGeom { int gi, gj, parts, tpp, big; };      // big: the 256 x 256 filter kernel (long rows) instead of the 128 x 128 one
+PfGeom pf_geometry(int64_t n_a, int64_t n_q, int want_parts, int kp);    // kp: padded columns of the FILTER pass this is for; 0: sample pass
 int pf_pass(int epi, const PfGeom *geom, int metric, const uint16_t *gallery, int64_t lda, const uint16_t *queries, int64_t ldq, const float *sqg,
             const float *sqq, int64_t n_a, int64_t n_q, int kp, const unsigned *ctl_g, const unsigned *ctl_q, const PfPassArgs &pa, hipStream_t s);
 

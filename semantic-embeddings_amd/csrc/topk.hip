@@ -1198,7 +1198,7 @@ static FusedLayout fused_layout(int64_t q, int64_t n, int64_t d, const FusedPlan
     if (pf) {
         // the half-precision thresholds admit a window of 4 eps more than the exact ones the plan was made for: 1.5x the planned total,
         // cut into the filter pass's gallery parts (+ room for the relative fluctuation of a small share)
-        L.geom = pf_geometry(n, q, 0);
+        L.geom = pf_geometry(n, q, 0, pf_padded_dim(d));
         L.parts = L.geom.parts * L.geom.gj;
         const int64_t total_cap = align256((int64_t)p.cap * 3 / 2);
         L.cap = (total_cap / L.parts + 32 + 15) / 16 * 16;

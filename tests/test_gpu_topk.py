@@ -116,6 +116,18 @@ def test_fused_topk_equals_head_of_canonical_ranking():
     run_with_tuning_lib(FUSED_CASES + "os.environ['SE_TOPK_FUSED'] = '1'\nrun_cases('fused')\n")
 
 
+def test_fused_topk_big_tile_filter_kernel_on_ragged_shapes():
+    """The 256 x 256 filter kernel (product default for padded widths >= 256 on large problems) pinned on SMALL ragged ones
+    (SE_PF_BIG=1): partial tiles in both directions, one-tile galleries, several K-chunks, K-blocks, both metrics, and the same
+    cases with capacities forced small (its overflow marking).  Its product-size run is test_product_library_d1000_kblocks_large_gallery."""
+    cases = ("CASES = [(300, 3000, 100, 25, 0, None, 0), (77, 20000, 300, 251, 0, None, 1000), (130, 2999, 64, 40, 1, None, 7),\n"
+             "         (513, 4097, 260, 10, 0, None, 0), (65, 2500, 555, 100, 1, [278, 277], 0), (129, 2048, 1000, 251, 0, [448, 276, 276], 5),\n"
+             "         (257, 700, 130, 1, 1, None, 0), (40, 9000, 200, 500, 0, None, 0)]\n")
+    body = FUSED_CASES[FUSED_CASES.index("def run_cases"):]
+    run_with_tuning_lib(cases + body + "os.environ['SE_TOPK_FUSED'] = '1'\nos.environ['SE_PF_BIG'] = '1'\nrun_cases('big tiles')\n"
+                        "os.environ['SE_TOPK_CAP'] = '256'\nCASES = [c for c in CASES if c[3] <= 128]\nrun_cases('big tiles, overflow')\n")
+
+
 def test_fused_topk_exact_fallback_paths():
     """Thresholds forced too low (j = 1: lists shorter than k) and capacities forced too small (overflow): every query is
     flagged and redone by the exact kernel (VALU FMA chain + radix select) -- same bits."""
