@@ -718,15 +718,22 @@ __global__ __launch_bounds__(PB_THREADS, 1) void pf_big_kernel(
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int mi = 0; mi < 4; mi++) {
-                    const int li = s * 4 + mi;                       // load instruction 0 .. 15: A rows, then B rows
-                    if (li < PB_NISSUE)
-                        __builtin_amdgcn_global_load_lds((pb_gptr_t *)(basea + (offa[li] + kb2)), (pb_lptr_t *)(st + (wave * 64 + li * 8) * PB_ROWB), 16, 0, 0);
-                    else
-                        __builtin_amdgcn_global_load_lds((pb_gptr_t *)(baseb + (offb[li - PB_NISSUE] + kb2)),
-                                                         (pb_lptr_t *)(st + PB_BM * PB_ROWB + (wave * 64 + (li - PB_NISSUE) * 8) * PB_ROWB), 16, 0, 0);
 #pragma unroll
-                    for (int j = 0; j < 4; j++) acc[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[s & 1][mi], bf[s & 1][j], acc[mi][j], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
+                    for (int jh = 0; jh < 2; jh++) {
+                        // the next chunk's 16 load instructions: one per two MFMAs of the first two steps (issued in a burst they filled the
+                        // memory pipe's queue and the wave sat in front of its MFMAs: 28 % of the kernel; spread over all four steps the
+                        // last of them landed after the chunk's MFMAs were done)
+                        const int li = (s * 4 + mi) * 2 + jh;
+                        if (li < PB_NISSUE)
+                            __builtin_amdgcn_global_load_lds((pb_gptr_t *)(basea + (offa[li] + kb2)), (pb_lptr_t *)(st + (wave * 64 + li * 8) * PB_ROWB), 16, 0, 0);
+                        else if (li < 2 * PB_NISSUE)
+                            __builtin_amdgcn_global_load_lds((pb_gptr_t *)(baseb + (offb[li - PB_NISSUE] + kb2)),
+                                                             (pb_lptr_t *)(st + PB_BM * PB_ROWB + (wave * 64 + (li - PB_NISSUE) * 8) * PB_ROWB), 16, 0, 0);
+#pragma unroll
+                        for (int j = 2 * jh; j < 2 * jh + 2; j++)
+                            acc[mi][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[s & 1][mi], bf[s & 1][j], acc[mi][j], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
             }
             buf ^= 1;

@@ -839,6 +839,16 @@ __global__ __launch_bounds__(TK_THREADS) void topk_fallback_kernel(const float *
 constexpr int RF_MAX = 1024;            // exact recomputations per query the refinement takes
 constexpr int RF_WAVES = 4;
 constexpr int PF_K_MAX = RF_MAX / 2;
+#ifndef SE_RF_LPC
+#define SE_RF_LPC 4
+#endif
+constexpr int RF_STAGE_M = 384, RF_STAGE_D = 256;      // lists of up to RF_STAGE_M candidates with rows of RF_STAGE_D columns and more are staged through LDS:
+constexpr int RF_LPC = SE_RF_LPC;                       //   lanes per candidate row and load instruction (each 16 bytes)
+constexpr int RF_KC = RF_LPC * 4;                       //   columns per chunk
+constexpr int RF_CPR = 1024 / RF_KC;                    //   candidates per round (a 4 KB block of rows per chunk)
+constexpr int RF_NI = RF_CPR * RF_LPC / 64;             //   load instructions per chunk
+constexpr int RF_PITCH = RF_KC + 4;                     //   LDS row pitch in words: conflict-free 16-byte reads by one lane per row
+static_assert(RF_NI >= 1 && RF_CPR <= 64 && (RF_MAX - RF_STAGE_M) * 8 >= RF_CPR * RF_PITCH * 4, "the row buffer lives in comp above the results");
 
 // thr / eps per query from the group minima of the sample pass.  hq, rq: norm of the query's bf16 image / of its rounding residual
 // (upper bounds, NaN for irregular rows); gctl[0..1]: float bits of the maxima of the same two norms over the gallery.
@@ -1101,6 +1111,88 @@ __global__ __launch_bounds__(RF_WAVES * 64) void pf_refine_kernel(const uint2 *_
             // ---- exact distances of R: one lane per candidate, the canonical fmaf chain over its gallery row ----
             const float *qv = queries + urow * ldq;
             const float sq_q = METRIC == SE_METRIC_EUCLID ? sqq[urow] : 0.f;
+            // Long rows (D >= RF_STAGE_D) reach the chains through LDS when the list fits beside the results (m <= RF_STAGE_M, 16-byte rows,
+            // K-block boundaries on multiples of 4): RF_LPC lanes fetch RF_KC * 4 contiguous bytes of ONE candidate row per instruction
+            // instead of every lane fetching 16 bytes of its own row -- a quarter of the cache lines per load instruction, and DRAM sees
+            // 256-byte bursts of a row instead of 64-byte ones.  RF_CPR candidates per round (one chain lane each), two chunks in flight.
+            // D = 1000 shard: 12.5 -> 10.7 ms with 4 lanes x 64 bytes (16 lanes x 256 bytes: 10.9 -- not a matter of burst length); short rows (D = 100: the 20 MB gallery sits in Infinity Cache) lose
+            // 0.1 ms to it and keep the direct form.
+            int dtot = 0;
+            for (int kb = 0; kb < kbs.n; kb++) dtot += kbs.len[kb];
+            bool rows_staged = VEC && m <= (uint32_t)RF_STAGE_M && dtot >= RF_STAGE_D;
+            for (int kb = 0; kb + 1 < kbs.n; kb++) rows_staged = rows_staged && (kbs.len[kb] & 3) == 0;
+            if (rows_staged) {
+                float *rowbuf = reinterpret_cast<float *>(comp + RF_STAGE_M);          // [RF_CPR][RF_PITCH]: the part of comp above the results
+                float *wr = rowbuf + (lane / RF_LPC) * RF_PITCH + 4 * (lane % RF_LPC);
+                const float *rd = rowbuf + (lane < RF_CPR ? lane : 0) * RF_PITCH;
+                for (uint32_t e0 = 0; e0 < m; e0 += RF_CPR) {
+                    const uint32_t e = e0 + lane;
+                    const bool chain_lane = lane < RF_CPR && e < m;
+                    const uint32_t gi = sel[chain_lane ? e : m - 1];
+                    const float *g = gallery + (int64_t)gi * ldg;
+                    const float *src[RF_NI];
+#pragma unroll
+                    for (int i = 0; i < RF_NI; i++) {
+                        const uint32_t ec = e0 + (uint32_t)(i * (64 / RF_LPC) + lane / RF_LPC);
+                        src[i] = gallery + (int64_t)sel[ec < m ? ec : m - 1] * ldg + 4 * (lane % RF_LPC);
+                    }
+                    float tot = 0.f;
+                    int beg = 0;
+                    for (int kb = 0; kb < kbs.n; kb++) {
+                        const int end = beg + kbs.len[kb], end4 = beg + ((end - beg) & ~3);
+                        float acc = 0.f;
+                        float4 x0[RF_NI], x1[RF_NI];
+                        auto issue = [&](float4 (&x)[RF_NI], int kk) {
+                            const bool mine = kk + 4 * (lane % RF_LPC) < end4;
+#pragma unroll
+                            for (int i = 0; i < RF_NI; i++) x[i] = mine ? *reinterpret_cast<const float4 *>(src[i] + kk) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        };
+                        auto consume = [&](float4 (&x)[RF_NI], int kk) {
+#pragma unroll
+                            for (int i = 0; i < RF_NI; i++) *reinterpret_cast<float4 *>(wr + (64 / RF_LPC) * i * RF_PITCH) = x[i];
+                            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                            if (kk + RF_KC <= end4) {
+#pragma unroll
+                                for (int j = 0; j < RF_KC; j += 4) {
+                                    const float4 v4 = *reinterpret_cast<const float4 *>(rd + j);
+                                    acc = __builtin_fmaf(v4.x, qv[kk + j], acc);
+                                    acc = __builtin_fmaf(v4.y, qv[kk + j + 1], acc);
+                                    acc = __builtin_fmaf(v4.z, qv[kk + j + 2], acc);
+                                    acc = __builtin_fmaf(v4.w, qv[kk + j + 3], acc);
+                                }
+                            } else {
+                                for (int j = 0; kk + j < end4; j += 4) {
+                                    const float4 v4 = *reinterpret_cast<const float4 *>(rd + j);
+                                    acc = __builtin_fmaf(v4.x, qv[kk + j], acc);
+                                    acc = __builtin_fmaf(v4.y, qv[kk + j + 1], acc);
+                                    acc = __builtin_fmaf(v4.z, qv[kk + j + 2], acc);
+                                    acc = __builtin_fmaf(v4.w, qv[kk + j + 3], acc);
+                                }
+                            }
+                            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                        };
+                        int kk = beg;
+                        if (kk < end4) issue(x0, kk);
+                        if (kk + RF_KC < end4) issue(x1, kk + RF_KC);
+                        while (kk < end4) {
+                            consume(x0, kk);
+                            if (kk + 2 * RF_KC < end4) issue(x0, kk + 2 * RF_KC);
+                            kk += RF_KC;
+                            if (kk >= end4) break;
+                            consume(x1, kk);
+                            if (kk + 2 * RF_KC < end4) issue(x1, kk + 2 * RF_KC);
+                            kk += RF_KC;
+                        }
+                        for (kk = end4; kk < end; kk++) acc = __builtin_fmaf(g[kk], qv[kk], acc);     // (last block only: D % 4 columns)
+                        tot = kb == 0 ? acc : tot + acc;
+                        beg = end;
+                    }
+                    float v;
+                    if (METRIC == SE_METRIC_COSINE) v = -tot;
+                    else v = (sqg[gi] + sq_q) - 2.0f * tot;
+                    if (chain_lane) comp[e] = ((uint64_t)canon_key(v) << 32) | gi;
+                }
+            } else
             for (uint32_t e0 = 0; e0 < m; e0 += 64) {
                 const uint32_t e = e0 + lane;
                 const uint32_t gi = sel[e < m ? e : m - 1];

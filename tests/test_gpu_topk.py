@@ -126,6 +126,22 @@ def test_fused_topk_big_tile_filter_kernel_on_ragged_shapes():
     body = FUSED_CASES[FUSED_CASES.index("def run_cases"):]
     run_with_tuning_lib(cases + body + "os.environ['SE_TOPK_FUSED'] = '1'\nos.environ['SE_PF_BIG'] = '1'\nrun_cases('big tiles')\n"
                         "os.environ['SE_TOPK_CAP'] = '256'\nCASES = [c for c in CASES if c[3] <= 128]\nrun_cases('big tiles, overflow')\n")
+    # irregular rows (NaN / inf / huge / zero / denormal) in gallery and queries through the same kernel: NaN accumulators pass its compare
+    run_with_tuning_lib(
+        "os.environ['SE_TOPK_FUSED'] = '1'\nos.environ['SE_PF_BIG'] = '1'\n"
+        "rng = np.random.default_rng(34)\n"
+        "n, d, k = 5000, 260, 60\n"
+        "g = rng.standard_normal((n, d)).astype(np.float32)\n"
+        "g[17, 3] = np.inf; g[18, 5] = -np.inf; g[19, 0] = np.nan; g[20] = 0.0; g[21, 7] = 3e30; g[22, 1] = -2e19; g[23] *= 1e-41\n"
+        "g[24, 3] = np.inf; g[24, 4] = -np.inf; g[4100, 259] = np.nan\n"
+        "qs = np.concatenate([g[[0, 1, 17, 18, 19, 20, 21, 22, 23, 24, 4999]], g[300:600]]).copy()\n"
+        "qs[0, 2] = 1e-42\n"
+        "for metric in (0, 1):\n"
+        "    with np.errstate(all='ignore'):\n"
+        "        wd, wi = T.want_topk(qs, g, k, metric)\n"
+        "    dd, ii = sehip.retrieve_topk(torch.from_numpy(qs).cuda(), torch.from_numpy(g).cuda(), k, metric=metric)\n"
+        "    assert np.array_equal(ii.cpu().numpy(), wi), metric\n"
+        "    assert np.array_equal(dd.cpu().numpy(), wd, equal_nan=True), metric\n")
 
 
 def test_fused_topk_exact_fallback_paths():
