@@ -750,21 +750,35 @@ __global__ __launch_bounds__(PB_THREADS, 1) void pf_big_kernel(
             const int lr0 = wm * 128 + 4 * hi;
             uint32_t mask[4][2];
             unsigned slotj[4];
+            // (the matrix core's last results are not interlocked against a plain vector read of their registers)
+            asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const int lc = wn * 128 + j * 32 + col;
                 const float cq = tCmpCol[lc];
-                mask[j][0] = mask[j][1] = 0u;
+                // Four independent chains (one per 32-row block) advance together: AGPR read -> compare into an SGPR pair -> shift the verdict
+                // into the block's 16-bit mask.  (One wave per SIMD: a single dependent chain of read / compare / add-with-carry ran at the
+                // pipeline's latency, ~24 cycles per value, 11 % of the kernel.)
+                uint32_t pm0 = 0u, pm1 = 0u, pm2 = 0u, pm3 = 0u;
 #pragma unroll
-                for (int mi = 0; mi < 4; mi++)
-#pragma unroll
-                    for (int r = 0; r < 16; r++) {
-                        float cmpv = cq;
-                        if (METRIC == SE_METRIC_EUCLID) cmpv = cq + tCmpRow[lr0 + mi * 32 + (r & 3) + 8 * (r >> 2)];
-                        float tmpv;             // the accumulators live in AGPRs ("a"): read one, compare, shift the verdict into the mask
-                        asm volatile("v_accvgpr_read_b32 %1, %2\n\ts_nop 0\n\tv_cmp_nlt_f32 vcc, %1, %3\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc"
-                                     : "+v"(mask[j][mi >> 1]), "=&v"(tmpv) : "a"(acc[mi][j][r]), "v"(cmpv) : "vcc");
+                for (int r = 0; r < 16; r++) {
+                    float c0 = cq, c1 = cq, c2 = cq, c3 = cq;
+                    if (METRIC == SE_METRIC_EUCLID) {
+                        const int lrr = lr0 + (r & 3) + 8 * (r >> 2);
+                        c0 = cq + tCmpRow[lrr]; c1 = cq + tCmpRow[lrr + 32]; c2 = cq + tCmpRow[lrr + 64]; c3 = cq + tCmpRow[lrr + 96];
                     }
+                    float t0, t1, t2, t3;
+                    uint64_t s0, s1, s2, s3;
+                    asm volatile("v_accvgpr_read_b32 %4, %12\n\tv_accvgpr_read_b32 %5, %13\n\tv_accvgpr_read_b32 %6, %14\n\tv_accvgpr_read_b32 %7, %15\n\t"
+                                 "v_cmp_nlt_f32_e64 %8, %4, %16\n\tv_cmp_nlt_f32_e64 %9, %5, %17\n\tv_cmp_nlt_f32_e64 %10, %6, %18\n\tv_cmp_nlt_f32_e64 %11, %7, %19\n\t"
+                                 "v_addc_co_u32_e64 %0, %8, %0, %0, %8\n\tv_addc_co_u32_e64 %1, %9, %1, %1, %9\n\t"
+                                 "v_addc_co_u32_e64 %2, %10, %2, %2, %10\n\tv_addc_co_u32_e64 %3, %11, %3, %3, %11"
+                                 : "+v"(pm0), "+v"(pm1), "+v"(pm2), "+v"(pm3), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3),
+                                   "=&s"(s0), "=&s"(s1), "=&s"(s2), "=&s"(s3)
+                                 : "a"(acc[0][j][r]), "a"(acc[1][j][r]), "a"(acc[2][j][r]), "a"(acc[3][j][r]), "v"(c0), "v"(c1), "v"(c2), "v"(c3));
+                }
+                mask[j][0] = (pm0 << 16) | pm1;             // value i = (block & 1) * 16 + r of half h = block >> 1 at bit 31 - i
+                mask[j][1] = (pm2 << 16) | pm3;
                 if (rows_here != PB_BM) {       // last gallery tile: rows beyond the gallery were clamped reads
 #pragma unroll
                     for (int h = 0; h < 2; h++) {
@@ -861,6 +875,7 @@ static int64_t pf_grid()
 PfGeom pf_geometry(int64_t n_a, int64_t n_q, int want_parts, int kp)
 {
     PfGeom g;
+    // (padded width 128: the two kernels are level -- cosine 3.0 vs 3.1 ms, Euclidean 3.7 vs 3.6 ms at 50k x 50k x 100 -- and the small one stays)
     g.big = (kp >= 256 && n_a >= 4096 && n_q >= 256) ? 1 : 0;
     if (const char *e = tuning_env("SE_PF_BIG")) g.big = (kp > 0 && atoi(e) != 0) ? 1 : 0;      // -DSE_TUNING build: pins the kernel
     const int bm = g.big ? PB_BM : PF_BM, bn = g.big ? PB_BN : PF_BN;
