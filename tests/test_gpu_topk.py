@@ -264,6 +264,37 @@ def test_topk_merge_packed_equals_separate_lists(sehip):
     assert np.array_equal(pd_.cpu().numpy(), wd) and np.array_equal(pi_.cpu().numpy(), wi)
 
 
+@pytest.mark.parametrize("parts,k", [(1, 251), (2, 1), (8, 251), (3, 64), (5, 65), (4, 128), (7, 300), (8, 512), (3, 1024), (2, 1500)])
+def test_topk_merge_wave_kernel_shapes(sehip, parts, k):
+    """The wave-per-query merge (k <= 1024: running best list in registers, one bitonic merge per part) and the LDS sort it replaced
+    (k > 1024) against the oracle: every register count (k = 1 ... 1024), ties across parts, +inf padding of short shards, NaN last."""
+    rng = np.random.default_rng(parts * 10007 + k)
+    q = 257
+    d = np.sort(rng.standard_normal((parts, q, k)).astype(np.float32), axis=-1)
+    i = (np.arange(parts)[:, None, None] * 1000000 + np.sort(rng.integers(0, 1000000, size=(parts, q, k)), axis=-1)).astype(np.int32)
+    if parts > 1:
+        d[1, :, :k // 3] = d[0, :, :k // 3]                       # exact ties across parts: the global index decides
+        d[-1, ::3, k - k // 4:] = np.inf                          # a short shard's padding
+        i[-1, ::3, k - k // 4:] = 2 ** 31 - 1
+    d[0, 5, k - 1] = np.nan                                       # NaN sorts last
+    md, mi = sehip.topk_merge(dev(d), dev(i))
+    wd, wi = ro.canon_topk_merge(d, i)
+    assert np.array_equal(mi.cpu().numpy(), wi)
+    assert np.array_equal(md.cpu().numpy(), wd, equal_nan=True)
+
+
+def test_topk_merge_accepts_unsorted_parts(sehip):
+    """The C ABI does not promise sorted parts to se_topk_merge: a part that is not ascending is sorted inside the wave first."""
+    rng = np.random.default_rng(77)
+    parts, q, k = 4, 130, 251
+    d = rng.standard_normal((parts, q, k)).astype(np.float32)                       # unsorted
+    d[2] = np.sort(d[2], axis=-1)                                                   # one part sorted, the others not
+    i = rng.permutation(parts * q * k).reshape(parts, q, k).astype(np.int32)
+    md, mi = sehip.topk_merge(dev(d), dev(i))
+    wd, wi = ro.canon_topk_merge(d, i)
+    assert np.array_equal(mi.cpu().numpy(), wi) and np.array_equal(md.cpu().numpy(), wd)
+
+
 # ---------------------------------------------------------------- bf16 pre-filter (prefilter.hip + pf_refine_kernel)
 
 def test_fp32_fused_passes_stay_covered():

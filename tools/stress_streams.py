@@ -24,6 +24,7 @@ f32 = lambda *s: rng.standard_normal(s).astype(np.float32)
 # ---- inputs ----
 g20 = dev(f32(20000, 100)); sehip.normalize_rows_(g20)
 g3 = dev(f32(3001, 200)); sehip.normalize_rows_(g3)
+gw = dev(f32(20000, 320)); sehip.normalize_rows_(gw)              # padded width 384: the 256 x 256 LDS-DMA filter kernel
 raw = dev(f32(8192, 1000))
 sq20 = sehip.row_sqnorm(g20)
 pd_short = sehip.pairwise_dist(g3[:512], g3)                       # 3001 columns: short-row instantiations
@@ -63,6 +64,7 @@ OPS = {
     "topk_merge packed 8 parts": lambda: sehip.topk_merge(parts),
     "retrieve_topk fused cosine": lambda: sehip.retrieve_topk(g20[:4096], g20, 251),
     "retrieve_topk fused Euclid": lambda: sehip.retrieve_topk(g20[:4096], g20, 100, metric=sehip.METRIC_EUCLID, sqq=sq20[:4096], sqg=sq20),
+    "retrieve_topk fused, long rows (LDS-DMA)": lambda: sehip.retrieve_topk(gw[:4096], gw, 251),
     "retrieve_topk slab (3,001 rows)": lambda: sehip.retrieve_topk(g3[:512], g3, 64),
     "hierarchical_precision": lambda: sehip.hierarchical_precision(rk_mid, cls, cls[:1024].contiguous(), qidx, tab_d, tab_d, best_d, best_d, ks,
                                                                      ahp_len=0, want_ap=True, curves=curves),
