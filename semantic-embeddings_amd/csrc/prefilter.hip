@@ -31,6 +31,8 @@
 //                                      the second one (queries = tile rows) straight from the accumulators with wave ballots: no LDS
 //                                      transposition, no barrier
 //                         PF_STORE     (tuning build only) d~ matrix out, for the hardware-assumption test of the error bound
+//   pf_big_kernel       the filter pass for long rows (padded width >= 256): 256 x 256 tiles, four waves of 128 x 128 outputs with their
+//                       accumulators in AGPRs, operands by LDS-DMA one K-chunk ahead -- see its own header further down
 #include "se_common.h"
 #include <type_traits>
 
