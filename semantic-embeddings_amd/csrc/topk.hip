@@ -836,45 +836,6 @@ __global__ __launch_bounds__(TK_THREADS) void topk_lists_kernel(const uint2 *__r
     }
 }
 
-// Exact path for flagged queries: the query's whole distance row, recomputed with the canonical FMA chain on the vector
-// ALU (fmaf over k ascending, restarted per K-block, block sums added in order: what the MFMA tiles compute), into this
-// workgroup's scratch row; then the radix select of topk_rows_kernel on it.
-template <int METRIC>
-__global__ __launch_bounds__(TK_THREADS) void topk_fallback_kernel(const float *__restrict__ queries, int64_t ldq, const float *__restrict__ gallery,
-                                                                   int64_t ldg, const float *__restrict__ sqq, const float *__restrict__ sqg,
-                                                                   int64_t Q, int N, int D, KBlocks kbs, int64_t col_offset, int k, int P,
-                                                                   float *__restrict__ scratch, float *__restrict__ out_d,
-                                                                   int32_t *__restrict__ out_i, const unsigned *__restrict__ nflag)
-{
-    extern __shared__ __attribute__((aligned(16))) uint64_t tk_lds64[];
-    if (nflag[1] == 0) return;                                     // no query was flagged: the usual case
-    float *drow = scratch + (int64_t)blockIdx.x * N;
-    for (int64_t row = blockIdx.x; row < Q; row += gridDim.x) {
-        if (out_i[row * k] != TK_REDO) continue;       // uniform per workgroup
-        const float *qv = queries + row * ldq;
-        const float sq_q = METRIC == SE_METRIC_EUCLID ? sqq[row] : 0.f;
-        for (int c = threadIdx.x; c < N; c += TK_THREADS) {
-            const float *g = gallery + (int64_t)c * ldg;
-            float tot = 0.f;
-            int beg = 0;
-            for (int kb = 0; kb < kbs.n; kb++) {
-                float acc = 0.f;
-                for (int kk = beg; kk < beg + kbs.len[kb]; kk++) acc = __builtin_fmaf(g[kk], qv[kk], acc);
-                tot = kb == 0 ? acc : tot + acc;
-                beg += kbs.len[kb];
-            }
-            float v;
-            if (METRIC == SE_METRIC_COSINE) v = -tot;
-            else v = (sqg[c] + sq_q) - 2.0f * tot;
-            drow[c] = v;
-        }
-        wg_barrier();     // (global writes of this workgroup are visible to it after the barrier)
-        topk_select_row(drow, N, col_offset, k, P, out_d + row * k, out_i + row * k, tk_lds64);
-        wg_barrier();
-    }
-}
-
-
 // ------------------------------------------------------------------------------------------------
 // bf16 pre-filter path of se_retrieve_topk (prefilter.hip holds the tile kernel).  Notation: d = the canonical fp32 distance (what
 // the caller gets), d~ = the distance the bf16 matrix-core pass computes, eps(q) >= |d~ - d| for every gallery item (pf_thr_kernel).
@@ -902,6 +863,7 @@ constexpr int RF_CPR = 1024 / RF_KC;                    //   candidates per roun
 constexpr int RF_NI = RF_CPR * RF_LPC / 64;             //   load instructions per chunk
 constexpr int RF_PITCH = RF_KC + 4;                     //   LDS row pitch in words: conflict-free 16-byte reads by one lane per row
 static_assert(RF_NI >= 1 && RF_CPR <= 64 && (RF_MAX - RF_STAGE_M) * 8 >= RF_CPR * RF_PITCH * 4, "the row buffer lives in comp above the results");
+constexpr size_t FB_ROWBUF_BYTES = (size_t)TK_WAVES * RF_CPR * RF_PITCH * 4;      // topk_fallback_kernel: one such buffer per wave, behind the select's LDS
 
 // thr / eps per query from the group minima of the sample pass.  hq, rq: norm of the query's bf16 image / of its rounding residual
 // (upper bounds, NaN for irregular rows); gctl[0..1]: float bits of the maxima of the same two norms over the gallery.
@@ -984,6 +946,139 @@ __device__ __forceinline__ float rf_chain(const float *__restrict__ g, const flo
     }
     return tot;
 }
+
+// The same chains for RF_CPR gallery rows at once, the rows passing through LDS: RF_LPC lanes fetch RF_KC * 4 contiguous bytes of ONE row
+// per load instruction (src[i]: this lane's piece of the row that instruction i serves -- row i * 64 / RF_LPC + lane / RF_LPC of the round,
+// columns 4 (lane % RF_LPC) ...), two chunks in flight, then lane r < RF_CPR runs row r's chain out of `rowbuf` ([RF_CPR][RF_PITCH] floats,
+// private to the wave).  g: the chain lane's own row (the D % 4 last columns).  Needs 16-byte aligned rows and K-block boundaries on
+// multiples of 4 (the callers check).  Returns the chain lane's sum.
+__device__ __forceinline__ float rf_chain_staged(const float *const (&src)[RF_NI], const float *__restrict__ g, const float *__restrict__ qv,
+                                                 const KBlocks &kbs, float *rowbuf, int lane)
+{
+    float *wr = rowbuf + (lane / RF_LPC) * RF_PITCH + 4 * (lane % RF_LPC);
+    const float *rd = rowbuf + (lane < RF_CPR ? lane : 0) * RF_PITCH;
+    float tot = 0.f;
+    int beg = 0;
+    for (int kb = 0; kb < kbs.n; kb++) {
+        const int end = beg + kbs.len[kb], end4 = beg + ((end - beg) & ~3);
+        float acc = 0.f;
+        float4 x0[RF_NI], x1[RF_NI];
+        auto issue = [&](float4 (&x)[RF_NI], int kk) {
+            const bool mine = kk + 4 * (lane % RF_LPC) < end4;
+#pragma unroll
+            for (int i = 0; i < RF_NI; i++) x[i] = mine ? *reinterpret_cast<const float4 *>(src[i] + kk) : make_float4(0.f, 0.f, 0.f, 0.f);
+        };
+        auto consume = [&](float4 (&x)[RF_NI], int kk) {
+#pragma unroll
+            for (int i = 0; i < RF_NI; i++) *reinterpret_cast<float4 *>(wr + (64 / RF_LPC) * i * RF_PITCH) = x[i];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (kk + RF_KC <= end4) {
+#pragma unroll
+                for (int j = 0; j < RF_KC; j += 4) {
+                    const float4 v4 = *reinterpret_cast<const float4 *>(rd + j);
+                    acc = __builtin_fmaf(v4.x, qv[kk + j], acc);
+                    acc = __builtin_fmaf(v4.y, qv[kk + j + 1], acc);
+                    acc = __builtin_fmaf(v4.z, qv[kk + j + 2], acc);
+                    acc = __builtin_fmaf(v4.w, qv[kk + j + 3], acc);
+                }
+            } else {
+                for (int j = 0; kk + j < end4; j += 4) {
+                    const float4 v4 = *reinterpret_cast<const float4 *>(rd + j);
+                    acc = __builtin_fmaf(v4.x, qv[kk + j], acc);
+                    acc = __builtin_fmaf(v4.y, qv[kk + j + 1], acc);
+                    acc = __builtin_fmaf(v4.z, qv[kk + j + 2], acc);
+                    acc = __builtin_fmaf(v4.w, qv[kk + j + 3], acc);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        };
+        int kk = beg;
+        if (kk < end4) issue(x0, kk);
+        if (kk + RF_KC < end4) issue(x1, kk + RF_KC);
+        while (kk < end4) {
+            consume(x0, kk);
+            if (kk + 2 * RF_KC < end4) issue(x0, kk + 2 * RF_KC);
+            kk += RF_KC;
+            if (kk >= end4) break;
+            consume(x1, kk);
+            if (kk + 2 * RF_KC < end4) issue(x1, kk + 2 * RF_KC);
+            kk += RF_KC;
+        }
+        for (kk = end4; kk < end; kk++) acc = __builtin_fmaf(g[kk], qv[kk], acc);     // (last block only: D % 4 columns)
+        tot = kb == 0 ? acc : tot + acc;
+        beg = end;
+    }
+    return tot;
+}
+
+// Exact path for flagged queries: the query's whole distance row, recomputed with the canonical FMA chain on the vector
+// ALU (fmaf over k ascending, restarted per K-block, block sums added in order: what the MFMA tiles compute), into this
+// workgroup's scratch row; then the radix select of topk_rows_kernel on it.
+template <int METRIC>
+__global__ __launch_bounds__(TK_THREADS) void topk_fallback_kernel(const float *__restrict__ queries, int64_t ldq, const float *__restrict__ gallery,
+                                                                   int64_t ldg, const float *__restrict__ sqq, const float *__restrict__ sqg,
+                                                                   int64_t Q, int N, int D, KBlocks kbs, int64_t col_offset, int k, int P, int sel_bytes,
+                                                                   float *__restrict__ scratch, float *__restrict__ out_d,
+                                                                   int32_t *__restrict__ out_i, const unsigned *__restrict__ nflag)
+{
+    extern __shared__ __attribute__((aligned(16))) uint64_t tk_lds64[];
+    if (nflag[1] == 0) return;                                     // no query was flagged: the usual case
+    float *drow = scratch + (int64_t)blockIdx.x * N;
+    bool staged = (reinterpret_cast<uintptr_t>(gallery) & 15) == 0 && (ldg & 3) == 0;       // 16-byte rows, K-block boundaries on multiples of 4
+    for (int kb = 0; kb + 1 < kbs.n; kb++) staged = staged && (kbs.len[kb] & 3) == 0;
+    // this workgroup's rows blockIdx.x, blockIdx.x + gridDim.x, ...: the flags of 64 of them are read at once (every wave reads the same
+    // 64 words: one round trip per 64 rows instead of one per row) and the flagged ones are redone one after the other
+    for (int64_t r0 = blockIdx.x; r0 < Q; r0 += (int64_t)gridDim.x * 64) {
+      const int64_t myrow = r0 + (int64_t)(threadIdx.x & 63) * gridDim.x;
+      uint64_t todo = __ballot(myrow < Q && out_i[myrow * k] == TK_REDO);           // the same mask in every wave
+      while (todo) {
+        const int64_t row = r0 + (int64_t)(__ffsll((long long)todo) - 1) * gridDim.x;
+        todo &= todo - 1;
+        const float *qv = queries + row * ldq;
+        const float sq_q = METRIC == SE_METRIC_EUCLID ? sqq[row] : 0.f;
+        if (staged) {
+            // the whole gallery against one query: 64 consecutive rows per wave and round through the wave's LDS buffer (one lane per
+            // row fetching its own row 4 bytes at a time kept the CU's address path busy for 2 ms per query at 50,000 x 100)
+            const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+            float *rowbuf = reinterpret_cast<float *>(reinterpret_cast<char *>(tk_lds64) + sel_bytes) + wave * (RF_CPR * RF_PITCH);
+            for (int c0 = wave * RF_CPR; c0 < N; c0 += TK_WAVES * RF_CPR) {
+                const int c = c0 + lane;
+                const int cc = (lane < RF_CPR && c < N) ? c : N - 1;
+                const float *src[RF_NI];
+#pragma unroll
+                for (int i = 0; i < RF_NI; i++) {
+                    const int cr = c0 + i * (64 / RF_LPC) + lane / RF_LPC;
+                    src[i] = gallery + (int64_t)(cr < N ? cr : N - 1) * ldg + 4 * (lane % RF_LPC);
+                }
+                const float tot = rf_chain_staged(src, gallery + (int64_t)cc * ldg, qv, kbs, rowbuf, lane);
+                float v;
+                if (METRIC == SE_METRIC_COSINE) v = -tot;
+                else v = (sqg[cc] + sq_q) - 2.0f * tot;
+                if (lane < RF_CPR && c < N) drow[c] = v;
+            }
+        } else
+        for (int c = threadIdx.x; c < N; c += TK_THREADS) {
+            const float *g = gallery + (int64_t)c * ldg;
+            float tot = 0.f;
+            int beg = 0;
+            for (int kb = 0; kb < kbs.n; kb++) {
+                float acc = 0.f;
+                for (int kk = beg; kk < beg + kbs.len[kb]; kk++) acc = __builtin_fmaf(g[kk], qv[kk], acc);
+                tot = kb == 0 ? acc : tot + acc;
+                beg += kbs.len[kb];
+            }
+            float v;
+            if (METRIC == SE_METRIC_COSINE) v = -tot;
+            else v = (sqg[c] + sq_q) - 2.0f * tot;
+            drow[c] = v;
+        }
+        wg_barrier();     // (global writes of this workgroup are visible to it after the barrier)
+        topk_select_row(drow, N, col_offset, k, P, out_d + row * k, out_i + row * k, tk_lds64);
+        wg_barrier();
+      }
+    }
+}
+
 
 #ifdef SE_TUNING
 __device__ unsigned long long rf_prof[8];      // tuning build, SE_TOPK_VERBOSE: cycles per phase of pf_refine_kernel, summed over every wave
@@ -1176,70 +1271,17 @@ __global__ __launch_bounds__(RF_WAVES * 64) void pf_refine_kernel(const uint2 *_
             for (int kb = 0; kb + 1 < kbs.n; kb++) rows_staged = rows_staged && (kbs.len[kb] & 3) == 0;
             if (rows_staged) {
                 float *rowbuf = reinterpret_cast<float *>(comp + RF_STAGE_M);          // [RF_CPR][RF_PITCH]: the part of comp above the results
-                float *wr = rowbuf + (lane / RF_LPC) * RF_PITCH + 4 * (lane % RF_LPC);
-                const float *rd = rowbuf + (lane < RF_CPR ? lane : 0) * RF_PITCH;
                 for (uint32_t e0 = 0; e0 < m; e0 += RF_CPR) {
                     const uint32_t e = e0 + lane;
                     const bool chain_lane = lane < RF_CPR && e < m;
                     const uint32_t gi = sel[chain_lane ? e : m - 1];
-                    const float *g = gallery + (int64_t)gi * ldg;
                     const float *src[RF_NI];
 #pragma unroll
                     for (int i = 0; i < RF_NI; i++) {
                         const uint32_t ec = e0 + (uint32_t)(i * (64 / RF_LPC) + lane / RF_LPC);
                         src[i] = gallery + (int64_t)sel[ec < m ? ec : m - 1] * ldg + 4 * (lane % RF_LPC);
                     }
-                    float tot = 0.f;
-                    int beg = 0;
-                    for (int kb = 0; kb < kbs.n; kb++) {
-                        const int end = beg + kbs.len[kb], end4 = beg + ((end - beg) & ~3);
-                        float acc = 0.f;
-                        float4 x0[RF_NI], x1[RF_NI];
-                        auto issue = [&](float4 (&x)[RF_NI], int kk) {
-                            const bool mine = kk + 4 * (lane % RF_LPC) < end4;
-#pragma unroll
-                            for (int i = 0; i < RF_NI; i++) x[i] = mine ? *reinterpret_cast<const float4 *>(src[i] + kk) : make_float4(0.f, 0.f, 0.f, 0.f);
-                        };
-                        auto consume = [&](float4 (&x)[RF_NI], int kk) {
-#pragma unroll
-                            for (int i = 0; i < RF_NI; i++) *reinterpret_cast<float4 *>(wr + (64 / RF_LPC) * i * RF_PITCH) = x[i];
-                            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                            if (kk + RF_KC <= end4) {
-#pragma unroll
-                                for (int j = 0; j < RF_KC; j += 4) {
-                                    const float4 v4 = *reinterpret_cast<const float4 *>(rd + j);
-                                    acc = __builtin_fmaf(v4.x, qv[kk + j], acc);
-                                    acc = __builtin_fmaf(v4.y, qv[kk + j + 1], acc);
-                                    acc = __builtin_fmaf(v4.z, qv[kk + j + 2], acc);
-                                    acc = __builtin_fmaf(v4.w, qv[kk + j + 3], acc);
-                                }
-                            } else {
-                                for (int j = 0; kk + j < end4; j += 4) {
-                                    const float4 v4 = *reinterpret_cast<const float4 *>(rd + j);
-                                    acc = __builtin_fmaf(v4.x, qv[kk + j], acc);
-                                    acc = __builtin_fmaf(v4.y, qv[kk + j + 1], acc);
-                                    acc = __builtin_fmaf(v4.z, qv[kk + j + 2], acc);
-                                    acc = __builtin_fmaf(v4.w, qv[kk + j + 3], acc);
-                                }
-                            }
-                            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                        };
-                        int kk = beg;
-                        if (kk < end4) issue(x0, kk);
-                        if (kk + RF_KC < end4) issue(x1, kk + RF_KC);
-                        while (kk < end4) {
-                            consume(x0, kk);
-                            if (kk + 2 * RF_KC < end4) issue(x0, kk + 2 * RF_KC);
-                            kk += RF_KC;
-                            if (kk >= end4) break;
-                            consume(x1, kk);
-                            if (kk + 2 * RF_KC < end4) issue(x1, kk + 2 * RF_KC);
-                            kk += RF_KC;
-                        }
-                        for (kk = end4; kk < end; kk++) acc = __builtin_fmaf(g[kk], qv[kk], acc);     // (last block only: D % 4 columns)
-                        tot = kb == 0 ? acc : tot + acc;
-                        beg = end;
-                    }
+                    const float tot = rf_chain_staged(src, gallery + (int64_t)gi * ldg, qv, kbs, rowbuf, lane);
                     float v;
                     if (METRIC == SE_METRIC_COSINE) v = -tot;
                     else v = (sqg[gi] + sq_q) - 2.0f * tot;
@@ -1508,11 +1550,11 @@ static int retrieve_topk_prefilter(const float *queries, int64_t ldq, const floa
         }
         const int64_t fgrid = rows < FB_GRID ? rows : FB_GRID;
         if (metric == SE_METRIC_COSINE)
-            hipLaunchKernelGGL(topk_fallback_kernel<SE_METRIC_COSINE>, dim3((unsigned)fgrid), dim3(TK_THREADS), lds_sel, s, qs, ldq, gallery, ldg, sq, sqg,
-                               rows, (int)n, (int)d, kbs, col_offset, k, P, scratch, out_d + q0 * k, out_i + q0 * k, nflag);
+            hipLaunchKernelGGL(topk_fallback_kernel<SE_METRIC_COSINE>, dim3((unsigned)fgrid), dim3(TK_THREADS), ((lds_sel + 15) & ~(size_t)15) + FB_ROWBUF_BYTES, s, qs, ldq, gallery, ldg, sq, sqg,
+                               rows, (int)n, (int)d, kbs, col_offset, k, P, (int)((lds_sel + 15) & ~(size_t)15), scratch, out_d + q0 * k, out_i + q0 * k, nflag);
         else
-            hipLaunchKernelGGL(topk_fallback_kernel<SE_METRIC_EUCLID>, dim3((unsigned)fgrid), dim3(TK_THREADS), lds_sel, s, qs, ldq, gallery, ldg, sq, sqg,
-                               rows, (int)n, (int)d, kbs, col_offset, k, P, scratch, out_d + q0 * k, out_i + q0 * k, nflag);
+            hipLaunchKernelGGL(topk_fallback_kernel<SE_METRIC_EUCLID>, dim3((unsigned)fgrid), dim3(TK_THREADS), ((lds_sel + 15) & ~(size_t)15) + FB_ROWBUF_BYTES, s, qs, ldq, gallery, ldg, sq, sqg,
+                               rows, (int)n, (int)d, kbs, col_offset, k, P, (int)((lds_sel + 15) & ~(size_t)15), scratch, out_d + q0 * k, out_i + q0 * k, nflag);
         SE_LAUNCH_CHECK();
     }
     return SE_OK;
@@ -1608,11 +1650,11 @@ extern "C" int se_retrieve_topk(const float *queries, int64_t ldq, const float *
         }
         const int64_t fgrid = rows < FB_GRID ? rows : FB_GRID;
         if (metric == SE_METRIC_COSINE)
-            hipLaunchKernelGGL(topk_fallback_kernel<SE_METRIC_COSINE>, dim3((unsigned)fgrid), dim3(TK_THREADS), lds_sel, s, qs, ldq, gallery, ldg, sq, sqg,
-                               rows, (int)n, (int)d, kbs, col_offset, k, P, scratch, out_d + q0 * k, out_i + q0 * k, nflag);
+            hipLaunchKernelGGL(topk_fallback_kernel<SE_METRIC_COSINE>, dim3((unsigned)fgrid), dim3(TK_THREADS), ((lds_sel + 15) & ~(size_t)15) + FB_ROWBUF_BYTES, s, qs, ldq, gallery, ldg, sq, sqg,
+                               rows, (int)n, (int)d, kbs, col_offset, k, P, (int)((lds_sel + 15) & ~(size_t)15), scratch, out_d + q0 * k, out_i + q0 * k, nflag);
         else
-            hipLaunchKernelGGL(topk_fallback_kernel<SE_METRIC_EUCLID>, dim3((unsigned)fgrid), dim3(TK_THREADS), lds_sel, s, qs, ldq, gallery, ldg, sq, sqg,
-                               rows, (int)n, (int)d, kbs, col_offset, k, P, scratch, out_d + q0 * k, out_i + q0 * k, nflag);
+            hipLaunchKernelGGL(topk_fallback_kernel<SE_METRIC_EUCLID>, dim3((unsigned)fgrid), dim3(TK_THREADS), ((lds_sel + 15) & ~(size_t)15) + FB_ROWBUF_BYTES, s, qs, ldq, gallery, ldg, sq, sqg,
+                               rows, (int)n, (int)d, kbs, col_offset, k, P, (int)((lds_sel + 15) & ~(size_t)15), scratch, out_d + q0 * k, out_i + q0 * k, nflag);
         SE_LAUNCH_CHECK();
     }
     return SE_OK;
