@@ -453,17 +453,38 @@ __global__ __launch_bounds__(PF_THREADS, PF_WGS_PER_CU) void pf_tile_kernel(
                 //      and the next stage; 16 ds_write_b128 per lane, lane-private rows of 64 + 4 dwords) and read back by index.
                 //      (Before: a compare, an exec-mask block and a branch per VALUE, ~50 cycles each: 67 % of the kernel at D = 100.) ----
                 uint32_t mask[2] = {0u, 0u};
+                if (METRIC != SE_METRIC_EUCLID) {
 #pragma unroll
-                for (int j = 0; j < 2; j++) {
-                    const float cq = tCmpCol[wn * 64 + j * 32 + col];
+                    for (int j = 0; j < 2; j++) {
+                        const float cq = tCmpCol[wn * 64 + j * 32 + col];
 #pragma unroll
-                    for (int mi = 0; mi < 2; mi++)
+                        for (int mi = 0; mi < 2; mi++)
 #pragma unroll
-                        for (int r = 0; r < 16; r++) {
-                            float cmpv = cq;
-                            if (METRIC == SE_METRIC_EUCLID) cmpv = cq + tCmpRow[lr0 + mi * 32 + (r & 3) + 8 * (r >> 2)];
-                            asm volatile("v_cmp_nlt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mask[j]) : "v"(acc[mi][j][r]), "v"(cmpv) : "vcc");
+                            for (int r = 0; r < 16; r++)
+                                asm volatile("v_cmp_nlt_f32 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mask[j]) : "v"(acc[mi][j][r]), "v"(cq) : "vcc");
+                    }
+                } else {
+                    // Euclidean compare constants differ per value (query part + row part: an add in front of every compare); four independent
+                    // chains (2 queries x 2 row blocks) advance together, each compare into its own SGPR pair (3.68 -> 3.58 ms at 50k x 50k x 100;
+                    // the cosine form above measured 0.2 ms SLOWER this way and keeps its single chain through VCC)
+                    const float cq0 = tCmpCol[wn * 64 + col], cq1 = tCmpCol[wn * 64 + 32 + col];
+                    uint32_t pm00 = 0u, pm01 = 0u, pm10 = 0u, pm11 = 0u;      // pm[j][mi]: 16 verdicts each
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        float c00 = cq0, c01 = cq0, c10 = cq1, c11 = cq1;
+                        if (METRIC == SE_METRIC_EUCLID) {
+                            const float r0 = tCmpRow[lr0 + (r & 3) + 8 * (r >> 2)], r1 = tCmpRow[lr0 + 32 + (r & 3) + 8 * (r >> 2)];
+                            c00 = cq0 + r0; c01 = cq0 + r1; c10 = cq1 + r0; c11 = cq1 + r1;
                         }
+                        uint64_t s0, s1, s2, s3;
+                        asm volatile("v_cmp_nlt_f32_e64 %4, %8, %12\n\tv_cmp_nlt_f32_e64 %5, %9, %13\n\tv_cmp_nlt_f32_e64 %6, %10, %14\n\tv_cmp_nlt_f32_e64 %7, %11, %15\n\t"
+                                     "v_addc_co_u32_e64 %0, %4, %0, %0, %4\n\tv_addc_co_u32_e64 %1, %5, %1, %1, %5\n\t"
+                                     "v_addc_co_u32_e64 %2, %6, %2, %2, %6\n\tv_addc_co_u32_e64 %3, %7, %3, %3, %7"
+                                     : "+v"(pm00), "+v"(pm01), "+v"(pm10), "+v"(pm11), "=&s"(s0), "=&s"(s1), "=&s"(s2), "=&s"(s3)
+                                     : "v"(acc[0][0][r]), "v"(acc[1][0][r]), "v"(acc[0][1][r]), "v"(acc[1][1][r]), "v"(c00), "v"(c01), "v"(c10), "v"(c11));
+                    }
+                    mask[0] = (pm00 << 16) | pm01;           // value i = mi * 16 + r at bit 31 - i
+                    mask[1] = (pm10 << 16) | pm11;
                 }
                 if (!full_rows) {       // last gallery tile: rows beyond the gallery were clamped reads
                     uint32_t vm = 0u;
