@@ -261,6 +261,8 @@ int se_topk_rows(const float *pdist, int64_t ldp, int64_t q, int64_t n, int64_t 
  * Merge per-shard top-k lists (e.g. the RCCL all-gather of every rank's se_topk_rows output)
  * into the global top-k; the result is independent of how the gallery was sharded.
  *   d, idx: [parts, q, k];  out_d, out_i: [q, k].  parts * k <= SE_TOPK_MAX * 4.
+ *   Lists as se_retrieve_topk / se_topk_rows write them (ascending under the canonical (distance, index) order) merge fastest
+ *   (k <= 1024: one wave per query, the running best list in registers); a list that is not ascending is sorted first -- same result.
  */
 int se_topk_merge(const float *d, const int32_t *idx, int parts, int64_t q, int k, float *out_d,
                   int32_t *out_i, se_stream_t stream);
