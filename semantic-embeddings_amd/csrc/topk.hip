@@ -1088,7 +1088,7 @@ __device__ unsigned long long rf_prof[8];      // tuning build, SE_TOPK_VERBOSE:
 #endif
 
 template <int METRIC, bool VEC>
-__global__ __launch_bounds__(RF_WAVES * 64) void pf_refine_kernel(const uint2 *__restrict__ lists, const unsigned *__restrict__ rowcnt, int64_t cap, int parts, int64_t Q,
+__global__ __launch_bounds__(RF_WAVES * 64, 3) void pf_refine_kernel(const uint2 *__restrict__ lists, const unsigned *__restrict__ rowcnt, int64_t cap, int parts, int64_t Q,
                                                                   const float *__restrict__ thr, const float *__restrict__ eps,
                                                                   const float *__restrict__ queries, int64_t ldq, const float *__restrict__ gallery,
                                                                   int64_t ldg, const float *__restrict__ sqq, const float *__restrict__ sqg,
