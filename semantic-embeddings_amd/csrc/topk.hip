@@ -1087,7 +1087,7 @@ __device__ unsigned long long rf_prof[8];      // tuning build, SE_TOPK_VERBOSE:
 #define RF_T(i)
 #endif
 
-template <int METRIC, bool VEC>
+template <int METRIC, bool VEC, bool LONGROWS>
 __global__ __launch_bounds__(RF_WAVES * 64, 3) void pf_refine_kernel(const uint2 *__restrict__ lists, const unsigned *__restrict__ rowcnt, int64_t cap, int parts, int64_t Q,
                                                                   const float *__restrict__ thr, const float *__restrict__ eps,
                                                                   const float *__restrict__ queries, int64_t ldq, const float *__restrict__ gallery,
@@ -1267,7 +1267,7 @@ __global__ __launch_bounds__(RF_WAVES * 64, 3) void pf_refine_kernel(const uint2
             // 0.1 ms to it and keep the direct form.
             int dtot = 0;
             for (int kb = 0; kb < kbs.n; kb++) dtot += kbs.len[kb];
-            bool rows_staged = VEC && m <= (uint32_t)RF_STAGE_M && dtot >= RF_STAGE_D;
+            bool rows_staged = LONGROWS && VEC && m <= (uint32_t)RF_STAGE_M && dtot >= RF_STAGE_D;     // (LONGROWS: its own instantiation -- the staged form's registers cost the short-row kernel 8 % when both lived in one)
             for (int kb = 0; kb + 1 < kbs.n; kb++) rows_staged = rows_staged && (kbs.len[kb] & 3) == 0;
             if (rows_staged) {
                 float *rowbuf = reinterpret_cast<float *>(comp + RF_STAGE_M);          // [RF_CPR][RF_PITCH]: the part of comp above the results
@@ -1516,10 +1516,11 @@ static int retrieve_topk_prefilter(const float *queries, int64_t ldq, const floa
         const bool verbose = kTuning && tuning_env("SE_TOPK_VERBOSE");
 
         const int64_t rgrid = (rows + RF_WAVES - 1) / RF_WAVES < 8192 ? (rows + RF_WAVES - 1) / RF_WAVES : 8192;
-#define SE_RF_LAUNCH(M, V) hipLaunchKernelGGL((pf_refine_kernel<M, V>), dim3((unsigned)rgrid), dim3(RF_WAVES * 64), 0, s, lists, rowcnt, L.cap, L.parts, rows, thr, eps, qs, ldq, \
-                                              gallery, ldg, sq, sqg, kbs, col_offset, k, out_d + q0 * k, out_i + q0 * k, nflag, verbose ? nflag + 2 : nullptr)
-        if (metric == SE_METRIC_COSINE) { if (vec) SE_RF_LAUNCH(SE_METRIC_COSINE, true); else SE_RF_LAUNCH(SE_METRIC_COSINE, false); }
-        else { if (vec) SE_RF_LAUNCH(SE_METRIC_EUCLID, true); else SE_RF_LAUNCH(SE_METRIC_EUCLID, false); }
+#define SE_RF_LAUNCH(M, V, LR) hipLaunchKernelGGL((pf_refine_kernel<M, V, LR>), dim3((unsigned)rgrid), dim3(RF_WAVES * 64), 0, s, lists, rowcnt, L.cap, L.parts, rows, thr, eps, qs, ldq, \
+                                                  gallery, ldg, sq, sqg, kbs, col_offset, k, out_d + q0 * k, out_i + q0 * k, nflag, verbose ? nflag + 2 : nullptr)
+        const bool longrows = vec && d >= RF_STAGE_D;                  // the build with the LDS-staged row gather
+        if (metric == SE_METRIC_COSINE) { if (longrows) SE_RF_LAUNCH(SE_METRIC_COSINE, true, true); else if (vec) SE_RF_LAUNCH(SE_METRIC_COSINE, true, false); else SE_RF_LAUNCH(SE_METRIC_COSINE, false, false); }
+        else { if (longrows) SE_RF_LAUNCH(SE_METRIC_EUCLID, true, true); else if (vec) SE_RF_LAUNCH(SE_METRIC_EUCLID, true, false); else SE_RF_LAUNCH(SE_METRIC_EUCLID, false, false); }
 #undef SE_RF_LAUNCH
         SE_LAUNCH_CHECK();
         if (verbose) {   // -DSE_TUNING build only: synchronises and reports how the lists came out
