@@ -43,16 +43,18 @@ struct RankLds {
     uint32_t tidx[RK_TILE];
 };
 
+// Exclusive prefix sum over the 64 lanes with data-parallel primitives (DPP): four row_shr steps scan each row of 16 lanes, row_bcast15 /
+// row_bcast31 carry the row totals on -- six VALU instructions instead of six ds_bpermute round trips (__shfl_up).
 __device__ __forceinline__ uint32_t wave_excl_scan(uint32_t v, uint32_t &total)
 {
-    const int lane = lane_id();
     uint32_t incl = v;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t t = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += t;
-    }
-    total = __shfl(incl, 63, 64);
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x111, 0xF, 0xF, false);   // row_shr:1
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x112, 0xF, 0xF, false);   // row_shr:2
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x114, 0xF, 0xF, false);   // row_shr:4
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x118, 0xF, 0xF, false);   // row_shr:8
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x142, 0xA, 0xF, false);   // row_bcast15 -> rows 1 and 3
+    incl += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)incl, 0x143, 0xC, 0xF, false);   // row_bcast31 -> rows 2 and 3
+    total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     return incl - v;
 }
 
@@ -241,6 +243,12 @@ __global__ __launch_bounds__(RK_THREADS) void rank_rows_kernel(const float *__re
 #define SE_RR_THREADS 512   // 512 (8 waves, 2 per SIMD, <= 256 VGPRs) or 768 (12 waves, 3 per SIMD, <= 168 VGPRs)
 #endif
 constexpr int RR_THREADS = SE_RR_THREADS;
+// instantiations (keys per thread) of the 512-thread build; -DSE_RR_DEV: a quick-to-compile subset for kernel work (NOT a product build)
+#ifdef SE_RR_DEV
+#define SE_RR_CASES_512 SE_RR_CASE(8) SE_RR_CASE(72) SE_RR_CASE(98)
+#else
+#define SE_RR_CASES_512 SE_RR_CASE(2) SE_RR_CASE(8) SE_RR_CASE(12) SE_RR_CASE(20) SE_RR_CASE(30) SE_RR_CASE(40) SE_RR_CASE(46) SE_RR_CASE(52) SE_RR_CASE(58) SE_RR_CASE(64) SE_RR_CASE(72) SE_RR_CASE(80) SE_RR_CASE(88) SE_RR_CASE(98) SE_RR_CASE(104)
+#endif
 constexpr int RR_WAVES = RR_THREADS / WAVE;
 constexpr int RR_SCAN_THREADS = 512;                  // threads that scan the packed counters (2 words each of the 1024 per wave)
 constexpr int RR_SCAN_WAVES = RR_SCAN_THREADS / WAVE;
@@ -406,6 +414,9 @@ constexpr int RR_WIDE_WORDS = 2048;   // counter words per wave of the 12-bit pa
 #ifndef SE_RR_TWO
 #define SE_RR_TWO 1                   // build parameter: 0 = never take the two-pass path below
 #endif
+#ifndef SE_RR_IMG
+#define SE_RR_IMG 1                   // build parameter: 0 = never take the image path (two passes on a 24-bit image + repair)
+#endif
 // Two-pass path of the long-row kernel: when all keys of a row but at most RR_TWO_OUT lie within RR_TWO_SPAN codes below its largest
 // key (Euclidean-distance rows of one data set do: the outliers are the query's own distance and its near-duplicates; the reference's
 // cosine rows -- -dot, both signs around zero, ~2^31 codes wide -- do not), the row is
@@ -414,6 +425,22 @@ constexpr int RR_WIDE_WORDS = 2048;   // counter words per wave of the 12-bit pa
 // operations per key.  Rows that do not qualify take the three passes.
 constexpr uint32_t RR_TWO_SPAN = (1u << 24) - 3u;
 constexpr int RR_TWO_OUT = 256;
+// Image path (VAR 3; round 5): rows whose keys do NOT fit a 2^24-code window -- the reference's cosine rows, -dot of both signs -- are
+// sorted on a monotone 24-bit IMAGE of the key, q = bits(fl(v + c)) - bits(c / 2) with c = the power of two that puts every |v| of
+// the row below 0.75 c (fl(v + c) lies in [c / 4, 7 c / 4]: rounding is monotone non-decreasing, so the image order never contradicts
+// the key order; below c / 2 the subtraction saturates at 0), again in two 12-bit passes -- and then REPAIRED: keys that share an
+// image (~1.3 % of a 50,000-column cosine row: the image's ulp is c 2^-24 below c and c 2^-23 above it) sit next to each other in index
+// order after the stable sort, and only their true (key, index) order can differ.  To SEE equal images at the final positions the low 8
+// image bits travel through pass 0 and are scattered as a one-byte TAG next to the index in pass 1 (8 instead of 12 random LDS
+// operations per key); a linear scan of the tags finds the maximal runs of equal tags (every block of equal images is inside one;
+// 1 / 256 of the other neighbours are false positives, which the repair leaves in place because their keys are in order), the runs
+// go to a worklist, and one thread per run gathers the true keys from the row (L2 / Infinity Cache) and puts the run into canonical
+// order.  A row with a run above RR_IMG_RUN entries, a full worklist, or keys the image cannot take (NaN, infinities, all zero) is
+// sorted again with the three passes by the same workgroup (and the workgroup backs off from the image path for a while).
+constexpr int RR_IMG_RUN = 8;          // longest run the repair sorts (entries)
+constexpr int RR_IMG_WL = 3072;        // worklist entries (run start | length << 16)
+constexpr int RR_IMG_MAX_ITEMS = 98;   // instantiations above this have no room for tags + worklist next to the exchange buffer
+constexpr uint32_t RR_IMG_NAN_PADHI = 0xFF0u;   // most significant image digit of the padding slots (real images end at 0xE00)
 // Counters are 16 bits wide, two per LDS word (8 waves x 2048 digits x 2 B = 32 KB next to the 100 KB exchange
 // buffer): a wave holds at most 64 x 104 keys and a destination is < 53,248, so neither half can carry into the
 // other.  The returning add is done on the word with the increment shifted into the digit's half.
@@ -499,6 +526,16 @@ struct RRRankHW {
     }
 };
 
+// LDS bytes in front of wave_tot / the exchange buffer: the dedicated per-wave counters, or (image path) the tag plane + worklist,
+// whichever is larger (the two are never live together: the image path's passes both use the counters aliased onto the exchange buffer)
+template <int ITEMS, bool HWORD, int VAR>
+constexpr size_t rr_region0_bytes()
+{
+    const size_t cnt = (size_t)RR_WAVES * (HWORD ? (size_t)(1 << RR_HW_BITS) / 2 : (size_t)RK_NB) * sizeof(uint32_t);
+    const size_t img = (size_t)RR_THREADS * ITEMS + 32 + (size_t)RR_IMG_WL * sizeof(uint32_t);   // tags (+ 32 B: the scan reads one group ahead), worklist
+    return (VAR == 3 && img > cnt) ? img : cnt;
+}
+
 // SEG (rows of more than RR_MAX_N columns, see rank_runs below): the kernel sorts SEGMENTS of rows -- "row" v of the loop is segment
 // v & (2^shift - 1) of matrix row v >> shift -- and instead of ranks it leaves each segment as a sorted RUN in three 16-bit planes
 // (segment-local index, key bits 16-31, key bits 0-15; 512 x ITEMS entries each, the padding sorted last) for the merge kernel.
@@ -509,7 +546,7 @@ struct RankSeg {
     int64_t plane_elems;  // virtual rows x 512 x ITEMS
 };
 
-template <int ITEMS, bool PROF, bool HWORD, int VAR, bool SEG = false>   // VAR: 0 plain, 1 group-peeling rank phase of the last pass, 2 two-pass path for rows that qualify
+template <int ITEMS, bool PROF, bool HWORD, int VAR, bool SEG = false>   // VAR: 0 plain, 1 group-peeling rank phase of the last pass, 2 two-pass path for rows that qualify, 3 two passes on a 24-bit image + repair
 __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_kernel(const float *__restrict__ pdist, int64_t ldp, int64_t Q,
                                                                     int N, void *rank, int64_t ldr, int idx64, int vec_ok,
                                                                     unsigned long long *prof, const uint32_t *skew_flag, const RankSeg seg)
@@ -529,10 +566,16 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
     // they ALIAS it: the buffer is idle from the last exchange read of the previous pass to the first scatter of this one (two extra
     // barriers per row keep the other waves' reads / counter look-ups on the right side of that reuse).
     constexpr bool WIDE = HWORD && ((size_t)RR_THREADS * ITEMS * sizeof(uint16_t) >= (size_t)RR_WAVES * RR_WIDE_WORDS * sizeof(uint32_t));
+    constexpr bool IMG = WIDE && VAR == 3;                              // image path (see RR_IMG_*)
+    static_assert(VAR != 3 || (WIDE && ITEMS <= RR_IMG_MAX_ITEMS && !SEG), "image path: long-row instantiations with room for the tag plane");
     uint32_t *wcnt = reinterpret_cast<uint32_t *>(rr_raw);              // [RR_WAVES][CNT_WORDS]
-    uint32_t *wave_tot = wcnt + RR_WAVES * CNT_WORDS;                   // [8] (+pad)
+    uint32_t *wave_tot = reinterpret_cast<uint32_t *>(rr_raw + rr_region0_bytes<ITEMS, HWORD, VAR>());   // [8] (+pad)
     uint16_t *xbuf = reinterpret_cast<uint16_t *>(wave_tot + 32);       // [RR_THREADS * ITEMS]
+    [[maybe_unused]] uint8_t *tagb = rr_raw;                            // image path: one tag byte per final position (aliases the idle dedicated counters)
+    [[maybe_unused]] uint32_t *wlist = reinterpret_cast<uint32_t *>(rr_raw + (size_t)RR_THREADS * ITEMS + 32);   // image path: [RR_IMG_WL]
+    [[maybe_unused]] uint32_t *ictl = wave_tot + 24;                    // image path: [0] worklist cursor, [1] row given up
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    [[maybe_unused]] const int wave_s = __builtin_amdgcn_readfirstlane(wave);   // the wave's number as a scalar
     const int wpos0 = wave * (ITEMS * WAVE) + lane;                     // position of (step s) = wpos0 + 64 s
     const uint32_t xb = lds_off(xbuf);                                  // exchange buffer, byte address
     const uint32_t rb = xb + 2u * (uint32_t)wpos0;                      // this lane's read slot of step 0
@@ -600,11 +643,15 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
         opaque(wpos);
 #pragma unroll
         for (int s = 0; s < ITEMS; s++) RR_LOAD_ONE(drow, wpos, s, n0)
-        RR_CANON(n0)
+        if constexpr (!IMG) RR_CANON(n0)   // (image path: the keys stay raw until the row has chosen between the image and the canonical key)
     }
     uint32_t pf_sink = 0;
     [[maybe_unused]] int rr_pass = -1;   // profile build: pass index for the per-pass phase times
-    for (int64_t row = blockIdx.x; row < Q; row += gridDim.x) {
+    // image path, all wave-uniform: `img_redo` = this row's image sort was given up, sort it again with the three passes; after a
+    // give-up the workgroup takes the three passes directly for the next 1, 2, 4 ... 32 rows before it tries the image again
+    [[maybe_unused]] bool img_redo = false;
+    [[maybe_unused]] int img_skip = 0, img_penalty = 0;
+    for (int64_t row = blockIdx.x; row < Q;) {
         const bool more = row + gridDim.x < Q;
         [[maybe_unused]] const int n_next = row_len(more ? row + gridDim.x : row);
         // a wave whose slots are ALL padding (rows well below the instantiation's capacity) sits the passes out: its counters stay zero,
@@ -615,6 +662,55 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
         // ---- does the row qualify for the two-pass path?  (uniform per row; before the index registers exist: only the keys are live) ----
         bool two = false;
         [[maybe_unused]] int n_out = 0;
+        if constexpr (IMG) {
+            const int n_row = row_len(row);
+            bool attempt = !img_redo && img_skip == 0;
+            if (!img_redo && img_skip > 0) img_skip--;
+            uint32_t cbits = 0, base = 0;
+            if (attempt) {
+                // largest magnitude of the row as an integer maximum (NaN and infinities come out on top and disqualify the row)
+                uint32_t mb = 0;
+#pragma unroll
+                for (int s = 0; s + 1 < ITEMS; s += 2) mb = max(max(mb, key[s] & 0x7FFFFFFFu), key[s + 1] & 0x7FFFFFFFu);   // v_max3_u32
+                if constexpr (ITEMS & 1) mb = max(mb, key[ITEMS - 1] & 0x7FFFFFFFu);
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) mb = max(mb, (uint32_t)__shfl_xor((int)mb, off, 64));
+                if (lane == 0) wave_tot[wave] = mb;
+                if (tid == 0) { ictl[0] = 0; ictl[1] = 0; }
+                wg_barrier();
+#pragma unroll
+                for (int w = 0; w < RR_WAVES; w++) mb = max(mb, wave_tot[w]);
+                mb = (uint32_t)__builtin_amdgcn_readfirstlane((int)mb);
+                // c = 2^(e + 1) with 2^e * 1.5 >= max |v|: every |v| <= 0.75 c.  Finite, not tiny (2^-100 <= max |v| < 2^126).
+                const uint32_t e = (mb >> 23) + ((mb & 0x7FFFFFu) > 0x400000u ? 1u : 0u);
+                two = mb >= 0x0D800000u && mb < 0x7E800000u;
+                cbits = (e + 1u) << 23;
+                base = e << 23;
+            }
+            if (two) {
+                const float c = __uint_as_float(cbits);
+                int wpos_ = wpos0;
+                opaque(wpos_);
+                // padding slots: above every real image, spread over 16 most significant digits and (pass 0) one counter per lane
+                const uint32_t pk_ = ((RR_IMG_NAN_PADHI + ((uint32_t)wpos_ & 15u)) << 20) | (((uint32_t)wpos_ & 63u) << 14);
+                const uint32_t tb = lds_off(tagb) + (uint32_t)wpos_;            // tag plane, this lane's slot of step 0
+#pragma unroll
+                for (int s = 0; s < ITEMS; s++) {
+                    const uint32_t t = __float_as_uint(__uint_as_float(key[s]) + c);
+                    const uint32_t q = __builtin_elementwise_sub_sat(t, base);        // 0 .. 0xE00000
+                    // tag of column (wpos + 64 s) = the low 8 image bits, written IN COLUMN ORDER: consecutive lanes, consecutive bytes
+                    asm volatile("ds_write_b8 %0, %1 offset:%2" ::"v"(tb), "v"(q), "n"(s * WAVE) : "memory");
+                    key[s] = q << 8;
+                }
+                if (wave_s * (ITEMS * WAVE) + ITEMS * WAVE > n_row) {   // wave-uniform: only the wave(s) that hold padding slots
+#pragma unroll
+                    for (int s = 0; s < ITEMS; s++) key[s] = (wpos_ + s * WAVE >= n_row) ? pk_ : key[s];
+                }
+            } else {
+                RR_CANON(n_row)
+            }
+            RR_T(8)
+        }
         if constexpr (WIDE && VAR == 2) {
             uint32_t *stat = wave_tot;                                  // [0, 8): per-wave maxima, [8, 16): per-wave counts below the window
             uint2 *outl = reinterpret_cast<uint2 *>(wcnt);              // (key, position) of the keys below the window (the dedicated counters are idle on this path)
@@ -880,13 +976,162 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
                 wg_barrier();
             }
         }
+        // ---- image path: the exchange buffer is sorted by (image, index); put the runs of equal tags into (key, index) order ----
+        [[maybe_unused]] bool img_fail = false;
+        if constexpr (IMG) {
+            if (two) {
+                // (per-row opaque copies: otherwise hipcc hoists every row-invariant mask / offset of this block out of the row loop and
+                // keeps ~40 of them in scratch -- the reloads cost more than the whole scan)
+                int n_row = row_len(row);
+                int tsc = wave_s * WAVE + (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));   // (tid itself lives in scratch by now)
+                opaque(n_row);
+                opaque(tsc);
+                const float *drow_cur = row_ptr(row);
+                // (1) scan: the tag of final position i is tagb[xbuf[i]] (the tags were written in column order).  Groups of 8 positions, group
+                // G = tid + RR_THREADS g: one conflict-free 16-byte read of the indices, 9 random tag reads (the 9th: the next group's first
+                // position), E = "tag(i) == tag(i + 1)" by byte-parallel arithmetic on the packed tags.  Every pair with equal tags goes to
+                // the worklist (bit 8 b + 4 h of a group's word: position 4 h + b); ONE returning add per thread reserves its slots and
+                // only the (rare) set bits are walked -- nothing in this phase waits for LDS inside a divergent loop.  Pairs that reach
+                // into the padding become empty entries.
+                constexpr int NS = RR_THREADS * ITEMS;
+                constexpr int NG = (NS / 8 + RR_THREADS - 1) / RR_THREADS;   // groups per thread
+                uint32_t S[NG];
+                uint32_t nstart = 0;
+                // software pipeline: indices of all groups first (NG 16-byte reads in flight), then the tag reads of group g + 1 are issued
+                // before the arithmetic of group g
+                uint4 xg[NG];
+                uint32_t nxg[NG];
+#pragma unroll
+                for (int g = 0; g < NG; g++) {
+                    const int b0 = (tsc + RR_THREADS * g) * 8;
+                    const int bs = b0 < n_row - 1 ? b0 : 0;
+                    xg[g] = *reinterpret_cast<const uint4 *>(xbuf + bs);
+                    nxg[g] = xbuf[bs + 8 < NS ? bs + 8 : bs];
+                }
+                uint32_t t[2][9];
+                auto tag_reads = [&](int g, uint32_t (&tt)[9]) {
+                    const uint32_t xi[4] = {xg[g].x, xg[g].y, xg[g].z, xg[g].w};
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        tt[2 * j] = tagb[xi[j] & 0xFFFFu];
+                        tt[2 * j + 1] = tagb[xi[j] >> 16];
+                    }
+                    tt[8] = tagb[nxg[g]];
+                };
+                tag_reads(0, t[0]);
+#pragma unroll
+                for (int g = 0; g < NG; g++) {
+                    if (g + 1 < NG) tag_reads(g + 1, t[(g + 1) & 1]);
+                    const uint32_t (&tc)[9] = t[g & 1];
+                    const bool live = (tsc + RR_THREADS * g) * 8 < n_row - 1;
+                    const uint32_t A = tc[0] | (tc[1] << 8) | (tc[2] << 16) | (tc[3] << 24), B = tc[4] | (tc[5] << 8) | (tc[6] << 16) | (tc[7] << 24);
+                    const uint32_t zA = A ^ __builtin_amdgcn_alignbyte(B, A, 1), zB = B ^ __builtin_amdgcn_alignbyte(tc[8], B, 1);   // byte i: tag(i) ^ tag(i + 1)
+                    const uint32_t uA = (zA & 0x7F7F7F7Fu) + 0x7F7F7F7Fu, uB = (zB & 0x7F7F7F7Fu) + 0x7F7F7F7Fu;               // bit 7 of byte i: the low 7 bits of the byte are not all zero
+                    const uint32_t eA = __builtin_amdgcn_bitop3_b32(uA, zA, 0x80808080u, 0x02), eB = __builtin_amdgcn_bitop3_b32(uB, zB, 0x80808080u, 0x02);   // ~u & ~z & mask
+                    S[g] = live ? ((eA >> 7) | (eB >> 3)) : 0u;
+                    nstart += (uint32_t)__popc(S[g]);
+                }
+                uint32_t slot = 0;
+                {
+                    // (plain returning add per lane: hipcc's atomic optimizer would turn atomicAdd into a 64-step scalar loop per wave)
+                    const uint32_t ca = lds_off(&ictl[0]);
+                    asm volatile("ds_add_rtn_u32 %0, %1, %2\n\ts_waitcnt lgkmcnt(0)" : "=v"(slot) : "v"(ca), "v"(nstart) : "memory");
+                }
+#pragma unroll
+                for (int g = 0; g < NG; g++) {
+                    uint32_t st = S[g];
+                    const int b0 = (tsc + RR_THREADS * g) * 8;
+                    while (st) {
+                        const int bit = __builtin_ctz(st);
+                        st &= st - 1u;
+                        const int pos = b0 + (bit & 4) + (bit >> 3);
+                        if (slot < (uint32_t)RR_IMG_WL) wlist[slot] = pos < n_row - 1 ? (uint32_t)pos : 0xFFFFFFFFu;
+                        slot++;
+                    }
+                }
+                wg_barrier();
+                const uint32_t nwork = ictl[0];
+                img_fail = nwork > (uint32_t)RR_IMG_WL;
+                RR_T(9)
+                if (!img_fail) {
+                    // (2) repair: worklist entries dealt round-robin over the threads, GB per thread in flight.  An entry is a pair of equal
+                    // tags; the thread whose pair has no such pair in front of it owns the run: it finds the length from the tags behind the
+                    // pair (2, 3 or "4 and more"), gathers the true keys from the row (L2 / Infinity Cache; all loads of all its runs in
+                    // flight together) and puts runs of 2 and 3 -- nearly all -- into (key, index) order in registers; longer runs take a
+                    // loop (up to RR_IMG_RUN entries; beyond that the row is given up).  Equal keys keep their places: the sort was stable,
+                    // so equal images are already in index order.
+                    constexpr int GB = 2;
+#pragma unroll 1
+                    for (uint32_t e0 = 0; e0 < nwork; e0 += RR_THREADS * GB) {
+                        uint32_t pp[GB], im[GB], ia[GB], ib[GB], ic[GB], id[GB], tm[GB], t0[GB], t2[GB], t3[GB], ka[GB], kb[GB], kc[GB];
+#pragma unroll
+                        for (int k = 0; k < GB; k++) {
+                            const uint32_t e = e0 + (uint32_t)(k * RR_THREADS + tsc);
+                            pp[k] = e < nwork ? wlist[e] : 0xFFFFFFFFu;
+                        }
+#pragma unroll
+                        for (int k = 0; k < GB; k++) {
+                            const uint32_t p = pp[k] != 0xFFFFFFFFu ? pp[k] : 0u;
+                            im[k] = xbuf[p ? p - 1u : 0u]; ia[k] = xbuf[p]; ib[k] = xbuf[p + 1];
+                            ic[k] = xbuf[p + 2 < (uint32_t)NS ? p + 2 : p]; id[k] = xbuf[p + 3 < (uint32_t)NS ? p + 3 : p];
+                        }
+#pragma unroll
+                        for (int k = 0; k < GB; k++) {
+                            tm[k] = tagb[im[k]]; t0[k] = tagb[ia[k]]; t2[k] = tagb[ic[k]]; t3[k] = tagb[id[k]];
+                            ka[k] = __float_as_uint(drow_cur[ia[k]]);
+                            kb[k] = __float_as_uint(drow_cur[ib[k]]);
+                            kc[k] = __float_as_uint(drow_cur[ic[k] < (uint32_t)n_row ? ic[k] : 0u]);   // (position p + 2 may be padding)
+                        }
+#pragma unroll
+                        for (int k = 0; k < GB; k++) {
+                            if (pp[k] == 0xFFFFFFFFu) continue;
+                            const uint32_t p = pp[k];
+                            if (p != 0u && tm[k] == t0[k]) continue;                  // the pair in front has equal tags too: its owner takes this run
+                            const bool three = (int)p + 2 < n_row && t2[k] == t0[k];
+                            const bool more4 = three && (int)p + 3 < n_row && t3[k] == t0[k];
+                            const uint32_t ca = rr_key(ka[k], false, 0u), cb = rr_key(kb[k], false, 0u), cc = rr_key(kc[k], false, 0u);
+                            if (!three) {
+                                if (ca > cb) { xbuf[p] = (uint16_t)ib[k]; xbuf[p + 1] = (uint16_t)ia[k]; }
+                            } else if (!more4) {
+                                // ranks by counting; ties keep the input order (a before b before c)
+                                const uint32_t ra = (cb < ca) + (cc < ca), rb = (ca <= cb) + (cc < cb), rc = (ca <= cc) + (cb <= cc);
+                                if (ra != 0u || rb != 1u) {
+                                    xbuf[p + ra] = (uint16_t)ia[k]; xbuf[p + rb] = (uint16_t)ib[k]; xbuf[p + rc] = (uint16_t)ic[k];
+                                }
+                            } else {
+                                // rare: 4 .. RR_IMG_RUN entries.  Everything in registers (unrolled, predicated); ranks by counting.
+                                int len = 4;
+                                while (len <= RR_IMG_RUN && (int)p + len < n_row && tagb[xbuf[p + len]] == t0[k]) len++;
+                                if (len > RR_IMG_RUN) { ictl[1] = 1u; continue; }
+                                uint32_t idx[RR_IMG_RUN], kk[RR_IMG_RUN];
+#pragma unroll
+                                for (int j = 0; j < RR_IMG_RUN; j++) idx[j] = xbuf[p + (uint32_t)(j < len ? j : 0)];
+#pragma unroll
+                                for (int j = 0; j < RR_IMG_RUN; j++) kk[j] = rr_key(__float_as_uint(drow_cur[idx[j]]), false, 0u);
+#pragma unroll
+                                for (int j = 0; j < RR_IMG_RUN; j++) {
+                                    uint32_t r = 0;
+#pragma unroll
+                                    for (int i = 0; i < RR_IMG_RUN; i++)
+                                        if (i != j) r += (i < len && (kk[i] < kk[j] || (kk[i] == kk[j] && i < j))) ? 1u : 0u;
+                                    if (j < len) xbuf[p + r] = (uint16_t)idx[j];
+                                }
+                            }
+                        }
+                    }
+                    wg_barrier();
+                    img_fail = ictl[1] != 0u;
+                }
+                RR_T(10)
+            }
+        }
         // ---- the exchange buffer now holds the ranking: canonicalise the next row's keys (waits for its loads), then stream the ranks out ----
         // (the loads sit after the pass loop, not inside its last iteration: a re-definition of the key registers on the `break` path makes
         // hipcc copy all ITEMS index registers there, and a separate straight-line instance of the last pass -- measured, DESIGN.md 5.2 --
         // pushes the 98-key build into scratch; the row was prefetched into L2 during the last pass.  They are issued BEFORE the rank
         // stores and waited for after them: the memory pipeline serves them first and the write-out covers most of their latency.)
         {
-            const float *drow = row_ptr(more ? row + gridDim.x : row);
+            const float *drow = row_ptr((IMG && img_fail) ? row : (more ? row + gridDim.x : row));   // (image path given up: the same row again)
             int wpos = wpos0;
             opaque(wpos);   // per-row opaque: otherwise hipcc hoists ITEMS row-invariant clamps out of the row loop and keeps them live
 #pragma unroll
@@ -894,8 +1139,11 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
         }
         int wt = tid;
         opaque(wt);   // per-row opaque: the write-out offsets are recomputed here instead of living (spilled) across the whole row loop
+        const bool write_out = !IMG || !img_fail;
         if constexpr (SEG) {
             RR_STREAM_PLANE(2, row)
+        } else if (!write_out) {
+            // image path given up: nothing to write, the row is sorted again
         } else if (idx64) {
             int64_t *o = (int64_t *)rank + row * ldr;
             // (the next row's keys are live: no unrolling, the LDS read of the next step is issued before this step's stores instead)
@@ -940,13 +1188,24 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
             }
         }
         RR_T(7)
-        RR_CANON(n_next)
+        if constexpr (!IMG) RR_CANON(n_next)
         if constexpr (PROF) {   // keep the canonicalisation (and with it the wait for the loads) inside the 'load' interval of the phase profile
             _Pragma("unroll") for (int s = 0; s < ITEMS; s++) opaque(key[s]);
         }
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf_sink) : : "memory");   // prefetch dwords landed too: the sink register is free again, nothing is outstanding
         RR_T(0)
         // (the next row's pass-0 barriers order these reads before its first exchange write)
+        if constexpr (IMG) {
+            if (img_fail) {
+                img_redo = true;
+                img_penalty = img_penalty ? (img_penalty < 16 ? 2 * img_penalty : 32) : 1;
+                img_skip = img_penalty;
+            } else {
+                if (two) img_penalty = 0;
+                img_redo = false;
+                row += gridDim.x;
+            }
+        } else row += gridDim.x;
     }
     if (PROF && tid == 0)
     {
@@ -983,10 +1242,10 @@ __global__ __launch_bounds__(256) void rank_skew_detect_kernel(const float *__re
                                                                int shift, int two_ok, uint32_t *__restrict__ flag)
 {
     constexpr int NBIN = 4096;   // values of the most significant digit: 1024 (10 bits, shift 22) or 4096 (12 bits, shift 20)
-    __shared__ uint32_t hist[NBIN];
-    __shared__ uint32_t best, row_max[3], row_below[3];
-    for (int i = threadIdx.x; i < NBIN; i += 256) hist[i] = 0;
-    if (threadIdx.x == 0) best = 0;
+    __shared__ uint32_t hist[NBIN], hash_hist[NBIN];
+    __shared__ uint32_t best, row_max[3], row_below[3], repeats;
+    for (int i = threadIdx.x; i < NBIN; i += 256) { hist[i] = 0; hash_hist[i] = 0; }
+    if (threadIdx.x == 0) { best = 0; repeats = 0; }
     if (threadIdx.x < 3) { row_max[threadIdx.x] = 0; row_below[threadIdx.x] = 0; }
     wg_barrier();
     const int cols = N < 1024 ? N : 1024;
@@ -997,6 +1256,9 @@ __global__ __launch_bounds__(256) void rank_skew_detect_kernel(const float *__re
             const uint32_t k = canon_key(drow[(int64_t)i * N / cols]);
             atomicAdd(&hist[k >> shift], 1u);
             if (k != 0xFFFFFFFFu) atomicMax(&row_max[r], k);
+            // repeated keys among the first 256 sampled columns of the row (hash buckets: 4096 for 768 keys -- ~70 chance hits): rows made of
+            // a few distinct values would give up the image path row by row
+            if (i < 256 && atomicAdd(&hash_hist[((k ^ ((uint32_t)r * 0x3C6EF372u)) * 2654435761u) >> 20], 1u) != 0u) atomicAdd(&repeats, 1u);   // (r: calls of one row sample it three times)
         }
     }
     wg_barrier();
@@ -1015,8 +1277,14 @@ __global__ __launch_bounds__(256) void rank_skew_detect_kernel(const float *__re
     wg_barrier();
     // peeling pays from roughly a 30 % share of one digit (two-valued Euclidean rows: ~50 %; mixed-sign cosine rows: ~10 %)
     if (threadIdx.x == 0) {
-        const bool two = two_ok && row_below[0] <= 4 && row_below[1] <= 4 && row_below[2] <= 4;   // ~N / 1024 keys of the row per sampled key
-        *flag = two ? 2u : ((10u * best >= 3u * 3u * (uint32_t)cols) ? 1u : 0u);
+        const bool two = (two_ok & 1) && row_below[0] <= 4 && row_below[1] <= 4 && row_below[2] <= 4;   // ~N / 1024 keys of the row per sampled key
+        // window fits: two lossless passes.  Otherwise rows without a dominant most significant digit (mixed-sign cosine rows, wide positive
+        // rows) take the image path; every row of it checks itself and falls back to the three passes (plain rank phase) when it must.
+        const bool skewed = 10u * best >= 3u * 3u * (uint32_t)cols;
+        const bool distinct = repeats < 3u * 96u;                       // fewer than ~3 / 8 of the hashed keys met an occupied bucket
+        // (rows of a few distinct values: neither two-pass form spreads them over the counters -- every wave step would queue up on two
+        // or three of them in BOTH passes; the three passes with the group-peeling last pass, or plain, are the better choice)
+        *flag = (two && distinct) ? 2u : (skewed ? 1u : (((two_ok & 2) && distinct) ? 3u : 0u));
     }
 }
 
@@ -1024,8 +1292,9 @@ template <int ITEMS, bool HW, int VAR>
 static int launch_rank_reg_variant(const float *pdist, int64_t ldp, int64_t q, int n, void *rank, int idx64, int64_t ldr,
                                    const uint32_t *skew_flag, hipStream_t s)
 {
-    const size_t cnt_words = HW ? (size_t)(1 << RR_HW_BITS) / 2 : (size_t)RK_NB;   // per wave (packed 16-bit vs 32-bit counters)
-    const size_t lds = (RR_WAVES * cnt_words + 32) * sizeof(uint32_t) + (size_t)RR_THREADS * ITEMS * sizeof(uint16_t);
+    // dedicated counters (packed 16-bit vs 32-bit; image path: tag plane + worklist) + wave_tot + exchange buffer
+    const size_t lds = rr_region0_bytes<ITEMS, HW, VAR>() + 32 * sizeof(uint32_t) + (size_t)RR_THREADS * ITEMS * sizeof(uint16_t);
+    static_assert(rr_region0_bytes<ITEMS, HW, VAR>() + 32 * sizeof(uint32_t) + (size_t)RR_THREADS * ITEMS * sizeof(uint16_t) <= 160 * 1024, "LDS of one CU");
     static const bool profile = tuning_env("SE_RR_PROFILE") != nullptr;   // -DSE_TUNING build only: allocates, synchronises, prints
     auto kern = (kTuning && profile) ? rank_rows_reg_kernel<ITEMS, kTuning && (ITEMS == 98), HW, VAR> : rank_rows_reg_kernel<ITEMS, false, HW, VAR>;
     // per instantiation, computed once (thread-safe static initialisation): resident workgroups = CUs x occupancy
@@ -1057,12 +1326,12 @@ static int launch_rank_reg_variant(const float *pdist, int64_t ldp, int64_t q, i
         SE_HIP_CHECK(hipStreamSynchronize(s));
         SE_HIP_CHECK(hipMemcpy(h, prof, sizeof(h), hipMemcpyDeviceToHost));
         SE_HIP_CHECK(hipFree(prof));
-        static const char *names[8] = {"load", "rank", "scan", "dest", "idx-write", "idx-read", "key-exchange", "write-out"};
+        static const char *names[11] = {"load", "rank", "scan", "dest", "idx-write", "idx-read", "key-exchange", "write-out", "image-map", "tag-scan", "repair"};
         double tot = 0;
-        for (int i = 0; i < 8; i++) tot += (double)h[i];
+        for (int i = 0; i < 11; i++) tot += (double)h[i];
         if (tot > 0) {
             fprintf(stderr, "[se_rank_rows profile] ITEMS=%d hw=%d peel=%d grid=%lld:", ITEMS, (int)HW, VAR, (long long)grid);
-            for (int i = 0; i < 8; i++) fprintf(stderr, " %s %.1f%%", names[i], 100.0 * (double)h[i] / tot);
+            for (int i = 0; i < 11; i++) fprintf(stderr, " %s %.1f%%", names[i], 100.0 * (double)h[i] / tot);
             fprintf(stderr, "  (%.0f cycles per row)\n[se_rank_rows profile] cycles per row by phase and pass:", tot / (double)q);
             for (int i = 1; i < 7; i++) fprintf(stderr, " %s %.0f/%.0f/%.0f", names[i], (double)h[12 + 3 * i] / (double)q, (double)h[13 + 3 * i] / (double)q, (double)h[14 + 3 * i] / (double)q);
             fprintf(stderr, "\n");
@@ -1081,22 +1350,26 @@ static int launch_rank_reg(const float *pdist, int64_t ldp, int64_t q, int n, vo
     // long rows (12-bit last digit, counters aliased onto the exchange buffer: WIDE in the kernel) also have the two-pass variant
     constexpr bool wide = (size_t)RR_THREADS * ITEMS * sizeof(uint16_t) >= (size_t)RR_WAVES * RR_WIDE_WORDS * sizeof(uint32_t);
     constexpr bool two_ok = wide && SE_RR_TWO;
-    static const char *force = tuning_env("SE_RANK_PEEL");   // -DSE_TUNING build only: "0" / "1" / "2" pins the variant
+    constexpr bool img_ok = wide && SE_RR_IMG && ITEMS <= RR_IMG_MAX_ITEMS && RR_THREADS == 512;
+    static const char *force = tuning_env("SE_RANK_PEEL");   // -DSE_TUNING build only: "0" / "1" / "2" / "3" pins the variant
     if (force || !scratch) {
         if (force && force[0] == '1') return launch_rank_reg_variant<ITEMS, true, 1>(pdist, ldp, q, n, rank, idx64, ldr, nullptr, s);
         if (force && force[0] == '2' && two_ok) return launch_rank_reg_variant<ITEMS, true, two_ok ? 2 : 0>(pdist, ldp, q, n, rank, idx64, ldr, nullptr, s);
+        if (force && force[0] == '3' && img_ok) return launch_rank_reg_variant<ITEMS, true, img_ok ? 3 : 0>(pdist, ldp, q, n, rank, idx64, ldr, nullptr, s);
         return launch_rank_reg_variant<ITEMS, true, 0>(pdist, ldp, q, n, rank, idx64, ldr, nullptr, s);
     }
     uint32_t *flag = (uint32_t *)scratch + 16;   // (words 0-1 belong to the capability probe)
     // first bit of the most significant digit: 20 for the instantiations whose last pass is 12 bits wide, else 22
     const int top_shift = wide ? 20 : 2 * RR_HW_BITS;
-    hipLaunchKernelGGL(rank_skew_detect_kernel, dim3(1), dim3(256), 0, s, pdist, ldp, q, n, top_shift, two_ok ? 1 : 0, flag);
+    hipLaunchKernelGGL(rank_skew_detect_kernel, dim3(1), dim3(256), 0, s, pdist, ldp, q, n, top_shift, (two_ok ? 1 : 0) | (img_ok ? 2 : 0), flag);
     SE_LAUNCH_CHECK();
     int rc = launch_rank_reg_variant<ITEMS, true, 0>(pdist, ldp, q, n, rank, idx64, ldr, flag, s);
     if (rc != SE_OK) return rc;
     rc = launch_rank_reg_variant<ITEMS, true, 1>(pdist, ldp, q, n, rank, idx64, ldr, flag, s);
-    if (rc != SE_OK || !two_ok) return rc;
-    return launch_rank_reg_variant<ITEMS, true, two_ok ? 2 : 0>(pdist, ldp, q, n, rank, idx64, ldr, flag, s);
+    if (rc != SE_OK) return rc;
+    if (two_ok) rc = launch_rank_reg_variant<ITEMS, true, two_ok ? 2 : 0>(pdist, ldp, q, n, rank, idx64, ldr, flag, s);
+    if (rc != SE_OK || !img_ok) return rc;
+    return launch_rank_reg_variant<ITEMS, true, img_ok ? 3 : 0>(pdist, ldp, q, n, rank, idx64, ldr, flag, s);
 }
 
 // ---- rows of more than RR_MAX_N columns: sorted runs + merge tree -----------------------------------------------------------------
@@ -1586,8 +1859,15 @@ __global__ void rank_selftest_fill_kernel(float *pd, int64_t ld, int rows, int n
     h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
     float v;
     if (mode == 2) v = 1.0f + (float)(h % 3001u) * (1.0f / 8192.0f);              // one binade: the two-pass window holds every key
+    else if (mode == 3) {
+        // image path: mixed signs on a 2^-24 grid around zero below one key of magnitude 1 (c = 2: 2 / 4 grid points share an image).  Row 0 / 1:
+        // a few hundred / thousand colliding pairs (repaired in place); row 2: more runs than the worklist holds; row 3: runs above the cap -- both re-sorted
+        const uint32_t span = 1u << (22 - 2 * (r & 3));
+        v = ((float)(h % span) - (float)(span / 2)) * (1.0f / 16777216.0f);
+        if (c == 17) v = -1.0f;
+    }
     else v = ((float)(h % 2001u) - 1000.0f) * (1.0f / 1024.0f);                     // mixed signs, +-0 included (canon: -0 == +0)
-    if (mode != 2 && (h >> 20) % 97u == 0) v = -0.0f;
+    if (mode < 2 && (h >> 20) % 97u == 0) v = -0.0f;
     if (mode == 1 && c % 1013 == 5) v = __builtin_nanf("");                         // a few NaN keys: sorted last, index order
     pd[r * ld + c] = v;
 }
@@ -1651,6 +1931,10 @@ extern "C" int se_rank_rows_init(void *workspace, int64_t workspace_bytes, se_st
     fill(RI_N_LONG, 2);
     if ((rc = audit("long rows, two-pass", RI_N_LONG, launch_rank_reg_variant<IL, true, 2>(pd, ld, RI_ROWS, RI_N_LONG, rk, 0, ld, nullptr, s)))) return rc;
 #endif
+#if SE_RR_IMG && SE_RR_THREADS == 512
+    fill(RI_N_LONG, 3);
+    if ((rc = audit("long rows, image path", RI_N_LONG, launch_rank_reg_variant<IL, true, 3>(pd, ld, RI_ROWS, RI_N_LONG, rk, 0, ld, nullptr, s)))) return rc;
+#endif
 #if SE_RR_THREADS == 512
     if (rank_runs_ok(RI_N_SEG) && rank_runs_items(RI_N_SEG) == IL) {
         fill(RI_N_SEG, 1);
@@ -1698,7 +1982,7 @@ extern "C" int se_rank_rows(const float *pdist, int64_t ldp, int64_t q, int64_t 
         int rc = SE_ERR_INVALID;
 #define SE_RR_CASE(I) if (rc == SE_ERR_INVALID && items <= I) rc = launch_rank_reg<I>(pdist, ldp, q, (int)n, rank, idx64, ldr, hw, scratch, s);
 #if SE_RR_THREADS == 512
-        SE_RR_CASE(2) SE_RR_CASE(8) SE_RR_CASE(12) SE_RR_CASE(20) SE_RR_CASE(30) SE_RR_CASE(40) SE_RR_CASE(46) SE_RR_CASE(52) SE_RR_CASE(58) SE_RR_CASE(64) SE_RR_CASE(72) SE_RR_CASE(80) SE_RR_CASE(88) SE_RR_CASE(98) SE_RR_CASE(104)
+        SE_RR_CASES_512
 #else
         SE_RR_CASE(2) SE_RR_CASE(6) SE_RR_CASE(14) SE_RR_CASE(28) SE_RR_CASE(44) SE_RR_CASE(56) SE_RR_CASE(66) SE_RR_CASE(70)
 #endif
@@ -1724,7 +2008,7 @@ extern "C" int se_rank_rows(const float *pdist, int64_t ldp, int64_t q, int64_t 
         if (nbad > (uint32_t)RC_CAP || row_stride > 1) {   // more than the list holds, or only a sample was looked at: redo the whole call
 #define SE_RR_CASE(I) if (items <= I) return launch_rank_reg<I>(pdist, ldp, q, (int)n, rank, idx64, ldr, false, scratch, s);
 #if SE_RR_THREADS == 512
-            SE_RR_CASE(2) SE_RR_CASE(8) SE_RR_CASE(12) SE_RR_CASE(20) SE_RR_CASE(30) SE_RR_CASE(40) SE_RR_CASE(46) SE_RR_CASE(52) SE_RR_CASE(58) SE_RR_CASE(64) SE_RR_CASE(72) SE_RR_CASE(80) SE_RR_CASE(88) SE_RR_CASE(98) SE_RR_CASE(104)
+            SE_RR_CASES_512
 #else
             SE_RR_CASE(2) SE_RR_CASE(6) SE_RR_CASE(14) SE_RR_CASE(28) SE_RR_CASE(44) SE_RR_CASE(56) SE_RR_CASE(66) SE_RR_CASE(70)
 #endif
@@ -1738,7 +2022,7 @@ extern "C" int se_rank_rows(const float *pdist, int64_t ldp, int64_t q, int64_t 
             int rc3 = SE_ERR_INVALID;
 #define SE_RR_CASE(I) if (rc3 == SE_ERR_INVALID && items <= I) rc3 = launch_rank_reg<I>(pdist + row * ldp, ldp, 1, (int)n, rrow, idx64, ldr, false, nullptr, s);
 #if SE_RR_THREADS == 512
-            SE_RR_CASE(2) SE_RR_CASE(8) SE_RR_CASE(12) SE_RR_CASE(20) SE_RR_CASE(30) SE_RR_CASE(40) SE_RR_CASE(46) SE_RR_CASE(52) SE_RR_CASE(58) SE_RR_CASE(64) SE_RR_CASE(72) SE_RR_CASE(80) SE_RR_CASE(88) SE_RR_CASE(98) SE_RR_CASE(104)
+            SE_RR_CASES_512
 #else
             SE_RR_CASE(2) SE_RR_CASE(6) SE_RR_CASE(14) SE_RR_CASE(28) SE_RR_CASE(44) SE_RR_CASE(56) SE_RR_CASE(66) SE_RR_CASE(70)
 #endif
@@ -1754,12 +2038,17 @@ extern "C" int se_rank_rows(const float *pdist, int64_t ldp, int64_t q, int64_t 
         // RR_MAX_N < n <= 8 RR_MAX_N: 2 / 4 / 8 sorted runs per row (hardware-ordered register-resident kernel on the segments) + merge tree
         const int items = rank_runs_items(n);
         int rc = SE_ERR_INVALID;
+#ifdef SE_RR_DEV
+        if (items != 98) return fail(SE_ERR_INVALID, "se_rank_rows: -DSE_RR_DEV build");
+        rc = launch_rank_runs<98>(pdist, ldp, q, (int)n, rank, idx64, ldr, workspace, s);
+#else
         if (items == 64) rc = launch_rank_runs<64>(pdist, ldp, q, (int)n, rank, idx64, ldr, workspace, s);
         else if (items == 72) rc = launch_rank_runs<72>(pdist, ldp, q, (int)n, rank, idx64, ldr, workspace, s);
         else if (items == 80) rc = launch_rank_runs<80>(pdist, ldp, q, (int)n, rank, idx64, ldr, workspace, s);
         else if (items == 88) rc = launch_rank_runs<88>(pdist, ldp, q, (int)n, rank, idx64, ldr, workspace, s);
         else if (items == 98) rc = launch_rank_runs<98>(pdist, ldp, q, (int)n, rank, idx64, ldr, workspace, s);
         else rc = launch_rank_runs<104>(pdist, ldp, q, (int)n, rank, idx64, ldr, workspace, s);
+#endif
         if (rc != SE_OK) return rc;
         int dev = 0;
         const bool have_dev = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64;

@@ -213,6 +213,120 @@ def test_rank_rows_two_pass_path(sehip, n):
     assert np.array_equal(got64, want[:3])
 
 
+def image_path_rows(rng, n):
+    """Rows aimed at the image path of the register-resident kernel (detector flag 3: two passes on a 24-bit image of the key + repair
+    of the keys that share an image): collisions of every run length, runs whose sorted positions straddle the scan's group
+    boundaries, rows the image cannot take (NaN, infinities, all zero, tiny), rows that overflow the worklist or the run cap (sorted
+    again with three passes), exponent-choice boundaries."""
+    rows = []
+    rows.append((0.1 * rng.standard_normal(n)).astype(np.float32))                       # 0: cosine-like
+    v = (0.1 * rng.standard_normal(n)).astype(np.float32)                                 # 1: self distance just below -1, exact duplicates
+    v[7] = np.float32(-1.0000001)
+    v[n // 2] = v[3]
+    v[n - 1] = v[3]
+    rows.append(v)
+    g = (rng.integers(0, 1 << 21, size=n) - (1 << 20)).astype(np.float32) * np.float32(2.0 ** -24)   # 2: grid near zero under a magnitude-1 key
+    g[0] = -1.0
+    rows.append(g)
+    g = (rng.integers(0, 1 << 15, size=n) - (1 << 14)).astype(np.float32) * np.float32(2.0 ** -24)   # 3: dense grid: worklist overflow / long runs
+    g[5] = 1.0
+    rows.append(g)
+    rows.append(np.exp(rng.uniform(-3, 3, size=n)).astype(np.float32))                   # 4: all positive, wide
+    rows.append(rng.choice(np.array([0.5, -0.25, 0.125, 0.7], dtype=np.float32), size=n))   # 5: four values: every image a long run
+    z = (1e-3 * rng.standard_normal(n)).astype(np.float32)                                # 6: zeros of both signs among small values
+    z[::7] = 0.0
+    z[3::7] = -0.0
+    rows.append(z)
+    w = (0.1 * rng.standard_normal(n)).astype(np.float32)                                 # 7: NaN / inf present: not an image row
+    w[11] = np.nan
+    w[n - 3] = np.inf
+    rows.append(w)
+    rows.append(np.zeros(n, dtype=np.float32))                                            # 8: all zero
+    base = np.sort((0.3 * rng.random(n) + 0.1).astype(np.float32))                        # 9: runs of 2 .. 9 keys inside one image cell
+    v = base.copy()                                                                       #    (positive: image ulp 2^-22 for c = 2), every 109 sorted positions
+    for start in range(100, n - 20, 109):
+        L = 2 + (start // 109) % 8
+        lo = np.float32(np.floor(base[start] * 2 ** 22) / 2 ** 22)
+        v[start:start + L] = lo + np.arange(L, 0, -1).astype(np.float32) * np.float32(2.0 ** -25)   # descending by index: the repair reverses them
+    v[0] = -1.0
+    rows.append(v)
+    rows.append(v[rng.permutation(n)])                                                    # 10: the same keys in random columns
+    a = (0.4 * rng.standard_normal(n)).astype(np.float32)                                 # 11 / 12: largest magnitude exactly 1.5 / just above
+    a[1] = 1.5
+    rows.append(a)
+    b = a.copy()
+    b[1] = np.float32(1.5000001)
+    rows.append(b)
+    rows.append((1e-35 * rng.standard_normal(n)).astype(np.float32))                     # 13: below 2^-100: three passes
+    rows.append((1e37 * rng.standard_normal(n)).astype(np.float32))                      # 14: huge magnitudes
+    rows.append((-200.0 + 20.0 * rng.standard_normal(n)).astype(np.float32))             # 15: negative, narrow
+    c = (0.05 * rng.standard_normal(n)).astype(np.float32)                                # 16: clustered: 40 centres + 1e-6 noise
+    c = (rng.choice(c[:40], size=n) + 1e-6 * rng.standard_normal(n)).astype(np.float32)
+    rows.append(c)
+    d = (0.1 * rng.standard_normal(n)).astype(np.float32)                                 # 17: every key 2 .. 6 times (tie runs in index order)
+    d = np.repeat(d[: n // 2], 6)[:n][rng.permutation(n)]
+    rows.append(d)
+    return np.stack(rows)
+
+
+@pytest.mark.parametrize("n", [32768, 36000, 40961, 45000, 50000, 50176])
+def test_rank_rows_image_path(sehip, n):
+    """Cosine-like calls (mixed signs, no dominant most significant digit: detector flag 3) of the long-row instantiations."""
+    rng = np.random.default_rng(n)
+    pd = image_path_rows(rng, n)
+    pd = np.concatenate([pd, pd[::-1]], axis=0)        # (a workgroup's back-off state sees fit and unfit rows in both orders)
+    got = sehip.rank_rows(dev(pd)).cpu().numpy()
+    want = ro.canon_rank_rows(pd)
+    for r in range(pd.shape[0]):
+        assert np.array_equal(got[r], want[r]), r
+    got64 = sehip.rank_rows(dev(pd[:4]), idx64=True).cpu().numpy()
+    assert np.array_equal(got64, want[:4])
+
+
+def test_rank_rows_image_path_many_rows_per_workgroup(sehip):
+    """600 cosine rows at 50,000 columns with unfit rows mixed in: every workgroup sorts several rows, gives some up and backs off."""
+    rng = np.random.default_rng(77)
+    n = 50000
+    x = rng.standard_normal((n, 64)).astype(np.float32)
+    x /= np.linalg.norm(x, axis=1, keepdims=True)
+    pd = np.ascontiguousarray(-(x[:600] @ x.T))
+    pd[5::97] = rng.choice(np.array([0.5, -0.25], dtype=np.float32), size=(len(pd[5::97]), n))
+    got = sehip.rank_rows(dev(pd)).cpu().numpy()
+    assert np.array_equal(got, ro.canon_rank_rows(pd))
+
+
+def test_rank_rows_detector_picks_the_variant_in_subprocess():
+    """Which build the skew detector selects (the phase profile of the tuning build names the variant that ran): the reference's cosine
+    rows take the image path (3), its Euclidean rows the two lossless passes (2), four-valued rows (no dominant digit, but nothing an
+    image could separate) the plain three passes (0), two-valued rows the group-peeling build (1)."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np, torch\n"
+        "sys.path[:0] = %r\n"
+        "import sehip\n"
+        "rng = np.random.default_rng(1)\n"
+        "n = 50000\n"
+        "for name, pd in (('cos', 0.1 * rng.standard_normal((300, n))), ('euc', 200.0 + 20.0 * rng.standard_normal((300, n))),\n"
+        "                 ('few', rng.choice(np.array([1.0, 2.0, 3.0, 4.0]), size=(300, n))),\n"
+        "                 ('two', rng.choice(np.array([1.0, 2.0]), size=(300, n)))):\n"
+        "    print('CASE', name, file=sys.stderr, flush=True)\n"
+        "    sehip.rank_rows(torch.from_numpy(pd.astype(np.float32)).cuda())\n"
+        "    torch.cuda.synchronize()\n"
+    ) % ([PKG_DIR, ROOT_DIR],)
+    env = dict(os.environ, SE_RR_PROFILE="1", SEHIP_LIB=os.path.join(PKG_DIR, "sehip", "libsehip_tuning.so"))
+    out = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout
+    seen = {}
+    case = None
+    for line in out.stdout.splitlines():
+        if line.startswith("CASE"):
+            case = line.split()[1]
+        elif "[se_rank_rows profile] ITEMS=98" in line and case:
+            seen.setdefault(case, set()).add(line.split("peel=")[1].split()[0])
+    assert seen == {"cos": {"3"}, "euc": {"2"}, "few": {"0"}, "two": {"1"}}, (seen, out.stdout[-2000:])
+
+
 def test_rank_rows_strided_and_unaligned_output(sehip):
     """Row pitches that are not multiples of 16 bytes (scalar write-out) and a strided input."""
     pdw = gauss(6, 3001, seed=5)
@@ -249,9 +363,9 @@ def test_rank_rows_ballot_kernel_in_subprocess():
     assert "hardware-ordered" not in out.stdout
 
 
-@pytest.mark.parametrize("peel", ["0", "1", "2"])
+@pytest.mark.parametrize("peel", ["0", "1", "2", "3"])
 def test_rank_rows_pinned_peel_variants_in_subprocess(peel):
-    """All builds of the hardware-ordered kernel (plain / group-peeling last pass / two-pass path, the last one for long rows only) on
+    """All builds of the hardware-ordered kernel (plain / group-peeling last pass / two-pass path / image path, the last two for long rows only) on
     every row shape, whatever the skew detector would choose: SE_RANK_PEEL pins the build (read once per process, hence the subprocess).  Long rows use
     the 12-bit last digit whose counters alias the exchange buffer; all-positive rows make lane 0's digit group large."""
     import subprocess

@@ -14,7 +14,7 @@ sys.path[:0] = [os.path.join(ROOT, "semantic-embeddings_amd"), ROOT]
 
 
 def make_rows(rng, q, n):
-    kind = rng.integers(0, 5)
+    kind = rng.integers(0, 9)
     if kind == 0:      # Euclidean-like: positive, two or three exponents
         base = rng.choice([3.0, 50.0, 200.0, 1e4, 1e-3])
         pd = (base * (1.0 + 0.12 * rng.standard_normal((q, n)))).astype(np.float32)
@@ -25,8 +25,21 @@ def make_rows(rng, q, n):
         pd = rng.choice((100.0 + rng.integers(0, 40, size=9)).astype(np.float32), size=(q, n))
     elif kind == 3:    # negative narrow range (window below a negative maximum)
         pd = (-200.0 + 20.0 * rng.standard_normal((q, n))).astype(np.float32)
-    else:              # wide positive
+    elif kind == 4:    # wide positive
         pd = np.exp(rng.uniform(-20, 20, size=(q, n))).astype(np.float32)
+    elif kind == 5:    # image path: a 2^-24 grid around zero under one key of magnitude 1 -- colliding images at a density the draw picks
+        span = 1 << int(rng.integers(14, 24))
+        pd = ((rng.integers(0, span, size=(q, n)) - span // 2).astype(np.float32) * np.float32(2.0 ** -24))
+        pd[:, int(rng.integers(0, n))] = rng.choice(np.array([1.0, -1.0, 0.7, -1.0000001], dtype=np.float32))
+    elif kind == 6:    # image path: clustered (a few centres + tiny noise: long runs of near-ties inside few images)
+        cen = (0.2 * rng.standard_normal(int(rng.integers(5, 200)))).astype(np.float32)
+        pd = (rng.choice(cen, size=(q, n)) + np.float32(10.0 ** rng.uniform(-9, -5)) * rng.standard_normal((q, n))).astype(np.float32)
+    elif kind == 7:    # image path: cosine-like with every key repeated 2 .. 20 times (exact-tie runs, index order)
+        rep = int(rng.integers(2, 21))
+        pd = np.repeat((0.1 * rng.standard_normal((q, n // rep + 1))).astype(np.float32), rep, axis=1)[:, :n]
+        pd = np.take_along_axis(pd, rng.permuted(np.tile(np.arange(n), (q, 1)), axis=1), axis=1)
+    else:              # image path: all keys of a row inside one binade of either sign
+        pd = (rng.choice(np.array([1.0, -1.0], dtype=np.float32), size=(q, 1)) * (1.0 + rng.random((q, n)))).astype(np.float32) * np.float32(2.0 ** int(rng.integers(-20, 20)))
     for r in range(q):
         m = int(rng.choice([0, 0, 1, 2, 17, 255, 256, 257, 300]))
         if m:
