@@ -49,6 +49,11 @@ RANK_LDS_FLOOR_CYCLES_PER_KEY = 73000.0 / 50000.0
 # the two-pass path (rows whose keys lie within 2^24 codes of their maximum: the synthetic Euclidean rows do): 7 random + 3 linear
 # LDS operations per key instead of 12 + 5
 RANK_LDS_FLOOR_CYCLES_PER_KEY_TWO_PASS = 43300.0 / 50000.0
+# the image path (round 5; cosine rows: two passes on a 24-bit image of the key + tag scan + repair): the 7 random + 3 linear
+# operations of the two passes, one linear tag write and one random tag read per key (784 wave-instructions each per 50,000-column
+# row at 6.4 / 3.5 / 5.9 cycles), the scan's linear index read (0.25 per key)
+RANK_LDS_FLOOR_CYCLES_PER_KEY_IMAGE = (43300.0 + 784 * 3.5 + 784 * 5.9 + 196 * 3.5) / 50000.0
+MFMA_F16_PEAK_TFLOPS = 2500.0   # dense fp16 = bf16 peak (MI355X_MICROARCH.md)
 SHADER_CLOCK_GHZ = 2.4
 N_CUS = 256
 
@@ -296,8 +301,11 @@ def bench_retrieval(args, rank, world):
     # algorithmic bytes / flops per launch
     pd_bytes, pd_full, pd_exec, pd_floor = pdist_cost_model(q, n, d, symmetric=queries0 is None)
     rk_bytes = 4.0 * q * n + 4.0 * q * n
-    two_pass = metric == sehip.METRIC_EUCLID and n >= 32768      # what the ranking kernel's detector selects for these rows
-    rk_lds_floor_ms = (RANK_LDS_FLOOR_CYCLES_PER_KEY_TWO_PASS if two_pass else RANK_LDS_FLOOR_CYCLES_PER_KEY) * q * n / (N_CUS * SHADER_CLOCK_GHZ * 1e9) * 1e3
+    # what the ranking kernel's detector selects for these rows (tests/test_gpu_retrieval.py::test_rank_rows_detector_picks_the_variant...)
+    two_pass = metric == sehip.METRIC_EUCLID and 32768 <= n <= 53248
+    image = metric == sehip.METRIC_COSINE and 32768 <= n <= 50176
+    rk_floor_cpk = RANK_LDS_FLOOR_CYCLES_PER_KEY_TWO_PASS if two_pass else (RANK_LDS_FLOOR_CYCLES_PER_KEY_IMAGE if image else RANK_LDS_FLOOR_CYCLES_PER_KEY)
+    rk_lds_floor_ms = rk_floor_cpk * q * n / (N_CUS * SHADER_CLOCK_GHZ * 1e9) * 1e3
     pms, rms = kms["pairwise_dist"], kms["rank_rows"]
     kernels = {
         "pairwise_dist": {"ms": pms, "algorithmic_GB": pd_bytes / 1e9, "GBps": pd_bytes / 1e6 / pms, "frac_hbm": pd_bytes / 1e6 / pms / HBM_PEAK_GBS,
@@ -308,7 +316,9 @@ def bench_retrieval(args, rank, world):
                           "frac_of_floor": pd_floor / pms},
         "rank_rows": {"ms": rms, "algorithmic_GB": rk_bytes / 1e9, "GBps": rk_bytes / 1e6 / rms, "frac_hbm": rk_bytes / 1e6 / rms / HBM_PEAK_GBS,
                       "lds_floor_ms": rk_lds_floor_ms, "frac_of_lds_floor": rk_lds_floor_ms / rms,
-                      "lds_floor": ("2-pass LSD radix on 24 significant key bits, 10" if two_pass else "3-pass LSD radix, 17.25") +
+                      "variant": "two lossless passes (window)" if two_pass else ("image path: two passes on a 24-bit image + tag scan + repair" if image else "three passes"),
+                      "lds_floor": ("2-pass LSD radix on 24 significant key bits, 10" if two_pass else
+                                    ("2-pass LSD radix on a 24-bit image + tag write / read + scan, 12.25" if image else "3-pass LSD radix, 17.25")) +
                                    " LDS wave-instructions per 64 keys at their measured throughput (DESIGN.md 5.2), 256 CUs x 2.4 GHz"},
     }
     dominant = max(("pairwise_dist", "rank_rows"), key=lambda k: kms[k])
@@ -338,6 +348,9 @@ def bench_retrieval(args, rank, world):
     }
     if args.verify:
         out.update(verify_last_step(last, pd, rk, metric, world))
+        # scalars the driver's parsed subset keeps (it drops nested objects below `roofline` / `config`)
+        out["roofline"]["verified"] = out["verified"]
+        out["config"]["verified"] = out["verified"]
     return out, feats_h, rk
 
 
@@ -422,13 +435,54 @@ def bench_topk_all_pairs(args, feats_h, reps=3, k=251):
         ts.append(a.elapsed_time(b))
     ms = float(np.median(ts))
     n, dd = feats_h.shape
-    tiles = (n + 127) // 128
-    executed = (tiles * (tiles + 1) // 2) * 128.0 * 128.0 * 2.0 * dd          # upper-triangle tiles, filtered in both orientations
     self_first = bool((i[:, 0] == torch.arange(n, device="cuda", dtype=torch.int32)).all().item()) if args.metric == "cosine" else None
-    return {"ms": ms, "k": k, "Mpairs_per_sec": float(n) * n / ms / 1e3, "algorithmic_GB": (8.0 * n * dd + 8.0 * n * k) / 1e9,
-            "flops_executed": executed, "TFLOPs_executed": executed / 1e9 / ms, "frac_mfma_f32": executed / 1e9 / ms / MFMA_F32_PEAK_TFLOPS,
-            "vs_distance_plus_ranking": "replaces pairwise_dist + rank_rows of the step above when only the first k ranks are consumed",
-            "every_query_finds_itself_first": self_first}
+    out = {"ms": ms, "k": k, "Mpairs_per_sec": float(n) * n / ms / 1e3, "algorithmic_GB": (8.0 * n * dd + 8.0 * n * k) / 1e9,
+           "vs_distance_plus_ranking": "replaces pairwise_dist + rank_rows of the step above when only the first k ranks are consumed",
+           "every_query_finds_itself_first": self_first}
+    out.update(topk_phase_rooflines(run, n, n, dd, k, shared_image=True))
+    return out
+
+
+def topk_phase_rooflines(run, q, n, d, k, shared_image):
+    """One more call of a fused distance + top-k leg with the library's phase events on (se_phase_timing: HIP events on the launch
+    stream behind every phase of se_retrieve_topk) -> a roofline object per dominant phase, from what the phase EXECUTES:
+      filter      fp16 matrix-core pass over the scaled half-precision images: 2 q n kp flop (kp = d padded to a multiple of 128) / time
+                  against the dense fp16 peak;
+      refinement  the exact fp32 chains of the survivors: every recomputed entry gathers one gallery row (4 d bytes) / time against HBM
+                  peak (the counter is the library's own: entries recomputed, summed over the queries);
+    and the bytes the whole call moves against SURVEY.md 8d's algorithmic 4 (q + n) d + 8 q k."""
+    import sehip
+    try:
+        sehip.phase_timing(True)
+        run()
+        phases, cnt = sehip.phase_timing_read()
+    finally:
+        sehip.phase_timing(False)
+    kp = (d + 127) // 128 * 128
+    S = 4096 if n >= 65536 else 2048                                   # sampled gallery rows of the threshold pass (topk.hip: fused_plan_compute)
+    filt_ms, ref_ms = phases.get("filter"), phases.get("refine")
+    res = {"phase_ms": phases}
+    if filt_ms:
+        fl = 2.0 * q * n * kp
+        res["roofline_filter"] = {"kernel": "pf_big_kernel" if kp >= 256 else "pf_tile_kernel", "bound": "mfma", "achieved": fl / 1e9 / filt_ms,
+                                  "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fl / 1e9 / filt_ms / MFMA_F16_PEAK_TFLOPS, "dtype": "f16",
+                                  "flops_executed": fl, "ms": filt_ms}
+    if ref_ms and cnt:
+        gathered = 4.0 * d * cnt["recomputed"]
+        lists = 8.0 * cnt["candidates"]
+        res["roofline_refine"] = {"kernel": "pf_refine_kernel", "bound": "hbm", "achieved": (gathered + lists) / 1e6 / ref_ms, "peak": HBM_PEAK_GBS,
+                                  "unit": "GB/s", "frac": (gathered + lists) / 1e6 / ref_ms / HBM_PEAK_GBS, "ms": ref_ms,
+                                  "gathered_row_bytes": gathered, "list_bytes": lists,
+                                  "recomputed_per_query": cnt["recomputed"] / max(1, cnt["queries"]),
+                                  "candidates_per_query": cnt["candidates"] / max(1, cnt["queries"]), "queries_redone_exactly": cnt["redone"]}
+        algo = 4.0 * (q + n) * d + 8.0 * q * k
+        images = (4.0 * d + 2.0 * kp) * (n if shared_image else q + n)          # fp32 rows read + half-precision images written
+        moved = images + 2.0 * kp * (n + q) + 2.0 * kp * S + gathered + 2.0 * lists + 8.0 * q * k
+        res["traffic_vs_algorithmic"] = {"moved_bytes_model": moved, "algorithmic_bytes": algo, "ratio": moved / algo,
+                                         "why": "bit-exact results need the exact fp32 chain for every survivor of the half-precision bound: each "
+                                                "recomputed entry re-reads one fp32 gallery row (the gather term dominates); the images are read "
+                                                "once per pass out of L2 / Infinity Cache and are counted once"}
+    return res
 
 
 def verify_last_step(last, pd, rk, metric, world):
@@ -584,11 +638,16 @@ def bench_sharded_gallery(args, rank, world, reps=2):
                       if kblocks is not None else "one fp32 FMA chain",
                       "parallelism": "gallery sharded %d ways, ONE RCCL all-gather of the packed per-shard top-k lists, canonical merge" % world},
            "all_gather_bytes_per_rank": Q * K * 8, "all_gather_GBps_per_rank": (world - 1) * Q * K * 8 / 1e6 / gat if world > 1 else None,
-           "local_topk_TFLOPs": flops / 1e9 / loc, "local_topk_frac_mfma_f32": flops / 1e9 / loc / MFMA_F32_PEAK_TFLOPS,
-           "local_topk_note": "useful flops 2 Q N D over the time of the whole call, against the fp32 MFMA peak (the exact path's pipe); "
-                              "the pre-filter of the call runs on the bf16 pipe, see DESIGN.md 5.3",
+           "local_topk_useful_TFLOPs": flops / 1e9 / loc,
+           "local_topk_note": "useful flops 2 Q N D over the time of the whole call (no peak applies to it: the call bounds the distances on "
+                              "the fp16 matrix cores and computes exact fp32 chains only for the survivors -- see roofline_filter / roofline_refine)",
            "merged_lists_sorted_with_index_tiebreak": sorted_ok, "merged_indices_in_range": in_range, "scaling": "weak",
            "data": "synthetic"}
+    try:
+        out.update(topk_phase_rooflines(lambda: sehip.retrieve_topk(queries, shard, K, metric=sehip.METRIC_COSINE, col_offset=off, kblocks=kblocks, out=(d, i)),
+                                        Q, NS, D, K, shared_image=False))
+    except Exception as e:      # noqa: BLE001 -- a measuring aid must not lose the leg
+        out["phase_ms"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if args.verify:
         try:
             from oracle import verify
@@ -731,6 +790,15 @@ def main(argv=None):
                     out["train"]["cpu_baseline"] = cpu_baseline_train(args)
                 except Exception as e:
                     out["train"]["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    if isinstance(out.get("roofline"), dict) and isinstance(out.get("config"), dict) and not args.dry and args.workload != "train":
+        # scalars mirrored to where the driver's parsed subset keeps them
+        sg, cb = out.get("sharded_gallery"), out.get("cpu_baseline")
+        if isinstance(sg, dict) and "verified" in sg:
+            out["roofline"]["sharded_gallery_verified"] = out["config"]["sharded_gallery_verified"] = sg["verified"]
+        if isinstance(cb, dict) and isinstance(cb.get("same_node_parity"), dict):
+            v = cb["same_node_parity"].get("gpu_vs_host_rows_differing_outside_ties")
+            out["roofline"]["same_node_rows_differing_outside_ties"] = v
+            cb["gpu_vs_host_rows_differing_outside_ties"] = v
     try:
         out["rccl"] = comm_identity(world, dry=args.dry)
         mg = multi_gpu_summary(out, world)

@@ -57,6 +57,21 @@ const char *se_last_error(void);
 /* host: name of the GPU architecture the embedded code objects were built for ("gfx950") */
 const char *se_build_arch(void);
 
+/*
+ * Phase timing -- a measuring aid (bench.py's per-leg rooflines), not part of any result.  se_phase_timing(1): from now on the
+ * multi-kernel entry points (se_retrieve_topk) record a HIP event on their stream behind each of their phases ("convert", "sample",
+ * "threshold", "filter", "refine", "fallback") and count, per query, the candidates of the filter pass and the entries the
+ * refinement recomputed exactly; se_phase_timing(0) (the default state) switches it off.  One process-wide switch; calls made while
+ * it is on must not run concurrently.
+ * se_phase_timing_read: waits for the last recorded event and returns the number of phases written to names_host / ms_host (HOST
+ * arrays of `cap` entries, either may be NULL; a phase that ran several times appears several times, in order); counters_host (HOST,
+ * 5 int64 or NULL) receives the statistics words of the last se_retrieve_topk call -- [1] queries redone exactly, [2] entries
+ * recomputed with the exact chain, [3] candidates listed, [4] queries -- or -1 each; the workspace of that call must still be alive.
+ * The recording restarts empty afterwards.  Negative return value: an SE_ERR_* code.
+ */
+int se_phase_timing(int on);
+int se_phase_timing_read(const char **names_host, float *ms_host, int cap, int64_t *counters_host);
+
 /* ------------------------------------------------------------------------------------------
  * Training side
  * ------------------------------------------------------------------------------------------ */
@@ -93,6 +108,21 @@ int se_cosine_loss_bwd(const void *x, int x_dtype, int64_t ldx, const int64_t *l
                        const float *emb, int64_t lde, const float *grad_loss_i, float grad_scale,
                        int64_t B, int64_t D, int64_t C, void *dx, int dx_dtype, int64_t lddx,
                        se_stream_t stream);
+
+/*
+ * Squared-distance loss of `--loss mse` against the gathered class embedding, and its backward.
+ * Replaces: utils.squared_distance (utils.py:34-36) as the training loss (learn_image_embeddings.py:160-163) on
+ *           y_true = embedding[y] (transform_inputs, learn_image_embeddings.py:48-50), and the utils.mean_distance metric
+ *           (utils.py:39-41) of the same compile() call.
+ *   loss_i [B] f32 = sum_d (x_d - emb[y]_d)^2;  dist_i [B] f32 = sqrt(loss_i) (may be NULL);  loss_mean [1] (may be NULL).
+ *   bwd: dx [B, D] (f32 / bf16) = 2 w (x - emb[y]), w = grad_loss_i[row] (NULL: the scalar grad_scale, e.g. 1 / B).
+ */
+int se_sqdist_loss_fwd(const void *x, int x_dtype, int64_t ldx, const int64_t *labels, const float *emb,
+                       int64_t lde, int64_t B, int64_t D, int64_t C, float *loss_i, float *dist_i,
+                       float *loss_mean, se_stream_t stream);
+int se_sqdist_loss_bwd(const void *x, int x_dtype, int64_t ldx, const int64_t *labels, const float *emb,
+                       int64_t lde, const float *grad_loss_i, float grad_scale, int64_t B, int64_t D,
+                       int64_t C, void *dx, int dx_dtype, int64_t lddx, se_stream_t stream);
 
 /*
  * Stand-alone L2-normalisation head and its backward.
@@ -284,17 +314,19 @@ int se_topk_merge_packed(const void *packed, int parts, int64_t q, int k, float 
  * Same arithmetic as se_pairwise_dist (sequential fp32 FMA chain, optional K-block list `kblocks` -- HOST pointer, may be
  * NULL -- for d > 448, evaluate_retrieval.py:59 on OpenBLAS) and the same canonical order as se_rank_rows: out_i[i, :] ==
  * the first k entries of se_rank_rows(se_pairwise_dist(queries, gallery))[i], out_d the distances, bit for bit.
- * Galleries of >= 16384 rows (k <= 512): the Q x N distances are first BOUNDED, not computed -- a pass on the bf16 matrix cores over
- * bf16-rounded copies of the operands gives d~ with |d~ - d| <= eps(query) (a rigorous bound from the operands' actual rounding
- * residuals).  A sample of <= 4096 gallery rows gives every query a threshold, the full pass appends the few
+ * Galleries of >= 16384 rows (k <= 512): the Q x N distances are first BOUNDED, not computed -- a pass on the fp16 matrix cores
+ * (v_mfma_f32_32x32x16_f16) over half-precision IMAGES of the operands (each matrix scaled by one power of two so that its largest
+ * entry sits just below 2^14, entries below fp16's normal range flushed to zero, columns padded to a multiple of 128) gives d~
+ * with |d~ - d| <= eps(query) (a rigorous bound from the operands' actual rounding residuals).  A sample of <= 4096 gallery rows gives every query a threshold, the full pass appends the few
  * items with d~ <= threshold to per-query candidate lists, and a per-query kernel recomputes, with the exact fp32 chain, the items
  * within 2 eps of the list's k-th smallest d~, sorts them and accepts the first k once it has proved that nothing outside that set
  * can precede them; queries it cannot prove (short / overflowing lists, NaN rows, tie groups of thousands) are redone exactly over the
- * whole gallery.  The output does not depend on what the bf16 pass computed.  Smaller galleries go through a [rows, n] distance slab
+ * whole gallery.  The output does not depend on what the half-precision pass computed.  Smaller galleries go through a [rows, n] distance slab
  * in the workspace; k > 512 through the fp32 form of the same passes.
  *   metric: SE_METRIC_COSINE or SE_METRIC_EUCLID (then sqq [q], sqg [n] = se_row_sqnorm of the operands).
- *   workspace: se_retrieve_topk_workspace_bytes(q, n, d, ldg, k) bytes, 256-byte aligned (candidate lists, bf16 operand copies:
- *   2 bytes x (n + q) x d rounded up to a multiple of 64, scratch rows of the exact fallback).
+ *   workspace: se_retrieve_topk_workspace_bytes(q, n, d, ldg, k) bytes, 256-byte aligned -- the ONLY supported way to size it (it
+ *   holds the candidate sub-lists, the fp16 images at 2 bytes x (n + q) x (d rounded up to a multiple of 128), per-row norms and
+ *   bounds, and the scratch rows of the exact fallback; the split between them follows the pass geometry chosen for (q, n, d)).
  */
 int64_t se_retrieve_topk_workspace_bytes(int64_t q, int64_t n, int64_t d, int64_t ldg, int k);
 int se_retrieve_topk(const float *queries, int64_t ldq, const float *gallery, int64_t ldg,

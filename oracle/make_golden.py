@@ -313,7 +313,31 @@ def cifar_pipeline_goldens():
     print("cifar_pipeline", out["test_X"].shape, out["train_X"].shape, "mean", out["mean"].ravel(), "restricted", out["restricted_test_X"].shape)
 
 
+def big_retrieval_golden(er):
+    """Round 5: ONE larger reference-produced retrieval fixture -- 4,096 clustered items (CIFAR-100 class embedding + noise, 64 exact
+    duplicates), D = 100, both branches of the reference (cosine and the CLI-default Euclidean) -- so that the reference-ranking gate
+    is exercised beyond 256 rows.  The file keeps the features and the reference's ranking of 128 evenly spread + random query rows per
+    branch (uint16 indices); the rankings are the output of the imported, unmodified evaluate_retrieval.pairwise_retrieval."""
+    e_cifar, _ = load_embedding("cifar100.unitsphere")
+    rng = np.random.default_rng(11)
+    n = 4096
+    y = rng.integers(0, 100, size=n)
+    x = (e_cifar[y] + 0.1 * rng.standard_normal((n, 100))).astype(np.float32)
+    x[n - 64:] = x[:64]                                   # exact duplicate rows: exact ties in every ranking
+    rows = np.unique(np.concatenate([np.linspace(0, n - 1, 96).astype(np.int64), rng.integers(0, n, size=40), np.arange(n - 8, n)]))[:128]
+    out = {"features": x, "labels": y.astype(np.int16), "rows": rows.astype(np.int32)}
+    for name, norm in (("cos", True), ("euc", False)):
+        rank = ref_ranking(er, x, norm)
+        assert rank.shape == (n, n) and rank.max() < 65536
+        out["ref_ranking_rows_" + name] = rank[rows].astype(np.uint16)
+        print("big", name, rank.shape)
+    np.savez_compressed(os.path.join(OUT, "bigretrieval_cluster.npz"), **out)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "big":       # only the round-5 large retrieval fixture
+        big_retrieval_golden(ref_import.import_reference("evaluate_retrieval"))
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "cifar":     # only the round-3 data-pipeline fixture
         cifar_pipeline_goldens()
         return
@@ -431,6 +455,7 @@ def main():
     lr_schedule_goldens()
     topk_goldens(er)
     cifar_pipeline_goldens()
+    big_retrieval_golden(er)
     print("done ->", OUT)
 
 

@@ -158,6 +158,63 @@ __global__ __launch_bounds__(256) void cosine_loss_bwd_kernel(
     }
 }
 
+// ---- squared-distance loss of `--loss mse` (utils.squared_distance, utils.py:34-36; metric utils.mean_distance, :39-41) ----
+// One wave per row, like the cosine head: loss_i = sum_d (x_d - E[y]_d)^2 (fp32 FMA accumulation per lane, wave tree), dist_i = sqrt(loss_i)
+// when asked for; backward dx = 2 w (x - E[y]), w = grad_loss_i[row] or the scalar grad_scale.
+template <bool BF16>
+__global__ __launch_bounds__(256) void sqdist_loss_fwd_kernel(const void *__restrict__ x, int64_t ldx, const int64_t *__restrict__ labels,
+                                                              const float *__restrict__ emb, int64_t lde, int64_t B, int64_t D, int64_t C,
+                                                              float *__restrict__ loss_i, float *__restrict__ dist_i, int vec_ok)
+{
+    const int wave = threadIdx.x >> 6, lane = lane_id();
+    for (int64_t row = (int64_t)blockIdx.x * LOSS_ROWS_PER_BLOCK + wave; row < B; row += (int64_t)gridDim.x * LOSS_ROWS_PER_BLOCK) {
+        const char *xrow = (const char *)x + row * ldx * (BF16 ? 2 : 4);
+        int64_t y = labels[row];
+        y = y < 0 ? 0 : (y >= C ? C - 1 : y);
+        const float *trow = emb + y * lde;
+        float s = 0.f;
+        if (vec_ok && !BF16) {
+            const float4 *xv = (const float4 *)xrow, *tv = (const float4 *)trow;
+            for (int64_t i = lane; i < D / 4; i += WAVE) {
+                const float4 p = xv[i], q = tv[i];
+                const float a = p.x - q.x, b = p.y - q.y, c = p.z - q.z, e = p.w - q.w;
+                s = fmaf(a, a, s); s = fmaf(b, b, s); s = fmaf(c, c, s); s = fmaf(e, e, s);
+            }
+        } else {
+            for (int64_t i = lane; i < D; i += WAVE) {
+                const float a = load_x<BF16>(xrow, i) - trow[i];
+                s = fmaf(a, a, s);
+            }
+        }
+        s = wave_sum(s);
+        if (lane == 0) {
+            loss_i[row] = s;
+            if (dist_i) dist_i[row] = sqrtf(s);
+        }
+    }
+}
+
+template <bool BF16, bool DX_BF16>
+__global__ __launch_bounds__(256) void sqdist_loss_bwd_kernel(const void *__restrict__ x, int64_t ldx, const int64_t *__restrict__ labels,
+                                                              const float *__restrict__ emb, int64_t lde, const float *__restrict__ grad_loss_i,
+                                                              float grad_scale, int64_t B, int64_t D, int64_t C, void *__restrict__ dx, int64_t lddx)
+{
+    const int wave = threadIdx.x >> 6, lane = lane_id();
+    for (int64_t row = (int64_t)blockIdx.x * LOSS_ROWS_PER_BLOCK + wave; row < B; row += (int64_t)gridDim.x * LOSS_ROWS_PER_BLOCK) {
+        const char *xrow = (const char *)x + row * ldx * (BF16 ? 2 : 4);
+        int64_t y = labels[row];
+        y = y < 0 ? 0 : (y >= C ? C - 1 : y);
+        const float *trow = emb + y * lde;
+        const float w2 = 2.0f * (grad_loss_i ? grad_loss_i[row] : grad_scale);
+        char *drow = (char *)dx + row * lddx * (DX_BF16 ? 2 : 4);
+        for (int64_t i = lane; i < D; i += WAVE) {
+            const float v = w2 * (load_x<BF16>(xrow, i) - trow[i]);
+            if constexpr (DX_BF16) ((uint16_t *)drow)[i] = f32_to_bf16(v);
+            else ((float *)drow)[i] = v;
+        }
+    }
+}
+
 // Stand-alone l2norm head (utils.py:125-127) for inference / feature dumps and for callers that
 // keep the Keras-style ``Lambda(l2norm)`` layer separate from the loss.
 template <bool BF16>
@@ -460,6 +517,52 @@ extern "C" int se_cosine_loss_bwd(const void *x, int x_dtype, int64_t ldx, const
     int64_t blocks = (B + LOSS_ROWS_PER_BLOCK - 1) / LOSS_ROWS_PER_BLOCK;
     if (blocks > 256 * 32) blocks = 256 * 32;
 #define SE_BWD(XB, DB) hipLaunchKernelGGL((cosine_loss_bwd_kernel<XB, DB>), dim3((unsigned)blocks), dim3(256), 0, s, x, ldx, labels, emb, lde, grad_loss_i, grad_scale, B, D, C, dx, lddx, vec_ok)
+    if (bf && dbf) SE_BWD(true, true);
+    else if (bf) SE_BWD(true, false);
+    else if (dbf) SE_BWD(false, true);
+    else SE_BWD(false, false);
+#undef SE_BWD
+    SE_LAUNCH_CHECK();
+    return SE_OK;
+}
+
+extern "C" int se_sqdist_loss_fwd(const void *x, int x_dtype, int64_t ldx, const int64_t *labels, const float *emb, int64_t lde,
+                                  int64_t B, int64_t D, int64_t C, float *loss_i, float *dist_i, float *loss_mean, se_stream_t stream)
+{
+    if (B < 0 || D <= 0 || C <= 0) return fail(SE_ERR_INVALID, "se_sqdist_loss_fwd: bad shape B=%lld D=%lld C=%lld", (long long)B, (long long)D, (long long)C);
+    if (B == 0) return SE_OK;
+    if (!x || !labels || !emb || !loss_i) return fail(SE_ERR_INVALID, "se_sqdist_loss_fwd: null pointer");
+    if (ldx < D || lde < D) return fail(SE_ERR_INVALID, "se_sqdist_loss_fwd: leading dimension < D");
+    if (x_dtype != SE_DTYPE_F32 && x_dtype != SE_DTYPE_BF16) return fail(SE_ERR_INVALID, "se_sqdist_loss_fwd: bad dtype %d", x_dtype);
+    hipStream_t s = (hipStream_t)stream;
+    const bool bf = x_dtype == SE_DTYPE_BF16;
+    const int vec_ok = !bf && (D % 4 == 0) && (ldx % 4 == 0) && (lde % 4 == 0) && aligned16(x) && aligned16(emb);
+    int64_t blocks = (B + LOSS_ROWS_PER_BLOCK - 1) / LOSS_ROWS_PER_BLOCK;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    if (bf) hipLaunchKernelGGL(sqdist_loss_fwd_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, x, ldx, labels, emb, lde, B, D, C, loss_i, dist_i, vec_ok);
+    else hipLaunchKernelGGL(sqdist_loss_fwd_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, x, ldx, labels, emb, lde, B, D, C, loss_i, dist_i, vec_ok);
+    SE_LAUNCH_CHECK();
+    if (loss_mean) {
+        hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, s, (const float *)loss_i, B, loss_mean);
+        SE_LAUNCH_CHECK();
+    }
+    return SE_OK;
+}
+
+extern "C" int se_sqdist_loss_bwd(const void *x, int x_dtype, int64_t ldx, const int64_t *labels, const float *emb, int64_t lde,
+                                  const float *grad_loss_i, float grad_scale, int64_t B, int64_t D, int64_t C, void *dx, int dx_dtype,
+                                  int64_t lddx, se_stream_t stream)
+{
+    if (B < 0 || D <= 0 || C <= 0) return fail(SE_ERR_INVALID, "se_sqdist_loss_bwd: bad shape");
+    if (B == 0) return SE_OK;
+    if (!x || !labels || !emb || !dx) return fail(SE_ERR_INVALID, "se_sqdist_loss_bwd: null pointer");
+    if (ldx < D || lde < D || lddx < D) return fail(SE_ERR_INVALID, "se_sqdist_loss_bwd: leading dimension < D");
+    hipStream_t s = (hipStream_t)stream;
+    const bool bf = x_dtype == SE_DTYPE_BF16, dbf = dx_dtype == SE_DTYPE_BF16;
+    if ((x_dtype != SE_DTYPE_F32 && !bf) || (dx_dtype != SE_DTYPE_F32 && !dbf)) return fail(SE_ERR_INVALID, "se_sqdist_loss_bwd: bad dtype");
+    int64_t blocks = (B + LOSS_ROWS_PER_BLOCK - 1) / LOSS_ROWS_PER_BLOCK;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+#define SE_BWD(XB, DB) hipLaunchKernelGGL((sqdist_loss_bwd_kernel<XB, DB>), dim3((unsigned)blocks), dim3(256), 0, s, x, ldx, labels, emb, lde, grad_loss_i, grad_scale, B, D, C, dx, lddx)
     if (bf && dbf) SE_BWD(true, true);
     else if (bf) SE_BWD(true, false);
     else if (dbf) SE_BWD(false, true);

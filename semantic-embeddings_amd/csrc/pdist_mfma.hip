@@ -183,17 +183,29 @@ __device__ __forceinline__ void pd_tile_coords(uint32_t t, int tiles_m, int tile
 
 
 // Stage [PD_SR][PD_SP] in LDS -> global rows: thread t moves 16 bytes, 32 lanes cover one 512-byte row segment.
-__device__ __forceinline__ void pd_stream_rows(const float *stage, float *gbase, uint32_t ldo, int nrows, int ncols, bool fast, bool nt, bool dry)
+// EUC (the Euclidean matrix output): the stage holds the raw dot products v and the distance is finished HERE, where a thread's four
+// columns are the same in every pass -- fl(fl(|row|^2 + |col|^2) - 2 v), spelled as one add and one FMA (2 v is exact, so the FMA rounds
+// the same exact difference).  rown / coln: squared norms of the staged rows / columns in LDS (rown[0] = first staged row).
+template <bool EUC>
+__device__ __forceinline__ void pd_stream_rows(const float *stage, float *gbase, uint32_t ldo, int nrows, int ncols, bool fast, bool nt, bool dry,
+                                               const float *rown = nullptr, const float *coln = nullptr)
 {
-    const int tid = threadIdx.x;
+    int tid = threadIdx.x;
+    if (EUC) asm volatile("" : "+v"(tid));   // opaque per call: otherwise hipcc hoists the ~20 per-pass LDS / global offsets of the Euclidean form out of the tile loop and parks them in scratch
     const int r0 = tid >> 5, c4 = (tid & 31) * 4;
     constexpr int RPP = PD_THREADS / 32;                         // rows per pass of the workgroup
     char *gb = (char *)gbase;                                    // uniform base + 32-bit byte offsets
     const uint32_t ldo4 = ldo * 4u;
+    float4 cn = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (EUC) cn = *(const float4 *)&coln[c4];
 #pragma unroll
     for (int p = 0; p < PD_SR / RPP; p++) {
         const int row = p * RPP + r0;
-        const float4 v = *(const float4 *)&stage[row * PD_SP + c4];
+        float4 v = *(const float4 *)&stage[row * PD_SP + c4];
+        if (EUC) {
+            const float rn = rown[row];
+            v = make_float4(fmaf(-2.0f, v.x, rn + cn.x), fmaf(-2.0f, v.y, rn + cn.y), fmaf(-2.0f, v.z, rn + cn.z), fmaf(-2.0f, v.w, rn + cn.w));
+        }
         if (dry) { asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w)); continue; }   // tuning aid: stage traffic without HBM writes
         float *dp = (float *)(gb + ((uint32_t)row * ldo4 + (uint32_t)c4 * 4u));
         if (fast) {
@@ -230,6 +242,13 @@ __global__ __launch_bounds__(PD_THREADS, (PD_WAVES / 4) * PD_WGS_PER_CU) void pd
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *sA = smem;
     float *sB = smem + PD_BM * PD_LD;
+    // Euclidean matrix output: |a|^2 of the tile's 128 rows and |b|^2 of its 128 columns, behind the operands (the epilogue stage aliases
+    // the operands, not this).  Fetched by LDS-DMA (global_load_lds_dword: no register holds them -- the kernel sits at the 128-VGPR
+    // limit of four waves per SIMD) at the top of the tile's last chunk, i.e. under its MFMA phase.
+    constexpr bool EUC_OUT = METRIC == SE_METRIC_EUCLID && EPI == EPI_STORE;
+    [[maybe_unused]] float *sN = smem + (PD_BM + PD_BN) * PD_LD;      // [PD_BM + PD_BN]
+    typedef __attribute__((address_space(1))) const void pd_gptr_t;
+    typedef __attribute__((address_space(3))) void pd_lptr_t;
 
     // ---- this workgroup's tile list: XCD-contiguous band, round-robin inside the XCD ----
     const int64_t b = blockIdx.x, G = gridDim.x;
@@ -313,6 +332,19 @@ __global__ __launch_bounds__(PD_THREADS, (PD_WAVES / 4) * PD_WGS_PER_CU) void pd
         // operand reads, 3.5 -> 3.9 ms.)
         const bool last_chunk = (c + 1 == nchunks);
         const bool have_next = it + 1 < total;
+        if (EUC_OUT && last_chunk) {
+            // norms of the tile in LDS (its epilogue follows this chunk's MFMA phase; the previous tile's epilogue is behind us): waves 0-1 its
+            // rows, waves 2-3 its columns, one dword per lane straight into sN (clamped: rows / columns outside the matrix are never written).
+            // Issued BEFORE the operand prefetch below: loads return in order, so once those registers have landed, so have these.
+            const int w_ = threadIdx.x >> 6;                       // wave-uniform
+            if (w_ < (PD_BM + PD_BN) / 64) {
+                const int t_ = threadIdx.x & (PD_BM - 1);
+                const bool rows_ = w_ < PD_BM / 64;
+                const int64_t i_ = rows_ ? (cur_m0 + t_ < Q ? cur_m0 + t_ : Q - 1) : (cur_n0 + t_ < N ? cur_n0 + t_ : N - 1);
+                const float *src_ = (rows_ ? sqa : sqb) + i_;
+                __builtin_amdgcn_global_load_lds((pd_gptr_t *)src_, (pd_lptr_t *)(sN + w_ * 64), 4, 0, 0);
+            }
+        }
         if (have_next) {
             const int nc = last_chunk ? 0 : c + 1;
             if (nc == 0) pd_tile_coords<SYM>((uint32_t)(band_beg + wg_in_xcd) + (tile_i + 1u) * (uint32_t)wgs_per_xcd, tiles_m, tiles_n, m0, n0);
@@ -373,6 +405,7 @@ __global__ __launch_bounds__(PD_THREADS, (PD_WAVES / 4) * PD_WGS_PER_CU) void pd
 
         // ---- tile finished: accumulators (col = lane & 31, row = (r&3) + 8*(r>>2) + 4*hi) -> global ----
         if (last_chunk) {
+            if (EUC_OUT) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tile's norms have landed in sN (hipcc does not track the LDS side of the DMA); the epilogue's first barrier publishes them
             if (flags & PDF_NO_STORE) {
 #pragma unroll
                 for (int j = 0; j < NB; j++)
@@ -578,24 +611,10 @@ __global__ __launch_bounds__(PD_THREADS, (PD_WAVES / 4) * PD_WGS_PER_CU) void pd
                 int lr0 = wm * PD_WROWS + 4 * hi;                                 // + mi * 32 + (r&3) + 8*(r>>2)
                 asm volatile("" : "+v"(lr0));   // opaque per tile: nothing of the epilogue is hoisted out of the tile loop
                 // (values are finished at the point of use: a [2][16] copy of the tile would cost 32 more VGPRs)
+                // (Euclidean: the stage takes the raw dot products, pd_stream_rows finishes them with the norms staged in sN)
 #define PD_VAL(MI_, J, R)                                                                                                    \
-    pd_finish<METRIC>(MULTI_KB ? tot[(MI_) * 2 + (J)][R] : acc[(MI_) * 2 + (J)][R],                                            \
-                      METRIC == SE_METRIC_EUCLID ? sa_[MI_][((R) & 3) + 4 * ((R) >> 2)] : 0.f, METRIC == SE_METRIC_EUCLID ? sb_[J] : 0.f)
-                float sa_[PD_MI][16], sb_[2];   // Euclidean epilogue only: |a|^2 of this lane's 16 rows per block, |b|^2 of its 2 columns
-                if (METRIC == SE_METRIC_EUCLID) {
-#pragma unroll
-                    for (int j = 0; j < 2; j++) {
-                        const int lc = wn * 64 + j * 32 + col;
-                        sb_[j] = sqb[cur_n0 + (lc < cols_here ? lc : cols_here - 1)];
-                    }
-#pragma unroll
-                    for (int mi = 0; mi < PD_MI; mi++)
-#pragma unroll
-                        for (int r = 0; r < 16; r++) {
-                            const int lr = lr0 + mi * 32 + (r & 3) + 8 * (r >> 2);
-                            sa_[mi][r] = sqa[cur_m0 + (lr < rows_here ? lr : rows_here - 1)];
-                        }
-                }
+    (METRIC == SE_METRIC_EUCLID ? (MULTI_KB ? tot[(MI_) * 2 + (J)][R] : acc[(MI_) * 2 + (J)][R])                               \
+                                : pd_finish<METRIC>(MULTI_KB ? tot[(MI_) * 2 + (J)][R] : acc[(MI_) * 2 + (J)][R], 0.f, 0.f))
 #pragma unroll
                 for (int h = 0; h < PD_BM / PD_SR; h++) {
                     wg_barrier();   // operands of the last chunk / the previous stage contents are no longer needed
@@ -613,8 +632,8 @@ __global__ __launch_bounds__(PD_THREADS, (PD_WAVES / 4) * PD_WGS_PER_CU) void pd
                     PD_T(7)
                     wg_barrier();
                     PD_T(8)
-                    pd_stream_rows(smem, out + ((cur_m0 + h * PD_SR) * (int64_t)ldo + cur_n0), ldo, rows_here - h * PD_SR, cols_here, fast, nt,
-                                   flags & PDF_NO_GSTORE);
+                    pd_stream_rows<EUC_OUT>(smem, out + ((cur_m0 + h * PD_SR) * (int64_t)ldo + cur_n0), ldo, rows_here - h * PD_SR, cols_here, fast, nt,
+                                            flags & PDF_NO_GSTORE, sN + h * PD_SR, sN + PD_BM);
                     PD_T(9)
                 }
                 if (mirror) {
@@ -637,8 +656,8 @@ __global__ __launch_bounds__(PD_THREADS, (PD_WAVES / 4) * PD_WGS_PER_CU) void pd
                         PD_T(7)
                         wg_barrier();
                         PD_T(8)
-                        pd_stream_rows(smem, out + ((cur_n0 + h * PD_SR) * (int64_t)ldo + cur_m0), ldo, cols_here - h * PD_SR, rows_here, fast, nt,
-                                       flags & PDF_NO_GSTORE);
+                        pd_stream_rows<EUC_OUT>(smem, out + ((cur_n0 + h * PD_SR) * (int64_t)ldo + cur_m0), ldo, cols_here - h * PD_SR, rows_here, fast, nt,
+                                                flags & PDF_NO_GSTORE, sN + PD_BM + h * PD_SR, sN);
                         PD_T(9)
                     }
                 }
@@ -692,7 +711,7 @@ static int launch_pdist3(const float *a, int64_t lda, const float *b, int64_t ld
 {
     const int tiles_m = (int)((q + PD_BM - 1) / PD_BM), tiles_n = (int)((n + PD_BN - 1) / PD_BN);
     const int64_t ntiles = SYM ? ((int64_t)tiles_n * (tiles_n + 1) / 2) : ((int64_t)tiles_m * tiles_n);
-    const size_t lds = (size_t)(PD_BM + PD_BN) * PD_LD * sizeof(float);
+    const size_t lds = ((size_t)(PD_BM + PD_BN) * PD_LD + (METRIC == SE_METRIC_EUCLID && EPI == EPI_STORE ? PD_BM + PD_BN : 0)) * sizeof(float);
     if (ntiles >= ((int64_t)1 << 31) || (int64_t)PD_GROUP_M * tiles_n >= ((int64_t)1 << 31) || (SYM && tiles_n > 65535))
         return fail(SE_ERR_UNSUPPORTED, "se_pairwise_dist: %lld output tiles exceed the 32-bit tile counter -- split the call", (long long)ntiles);
     int flags = 0;

@@ -65,6 +65,7 @@ struct PfArgs {
     float *gm; int64_t gm_ld;          // PF_GROUPMIN
     const float *thr;                  // PF_FILTER: [queries] thresholds (distance units); NaN = nothing but NaN passes
     unsigned *rowcnt; uint2 *lists; int64_t cap;
+    int spill; uint2 *spill_lists; unsigned *spill_cnt;   // PF_FILTER: sub-list slots of the query's SHARED spill region [queries][spill * cap], its fill counters [queries] (see pf_spill_append)
     int64_t sqa_stride;                // Euclidean epilogue: |a|^2 of gallery row r is sqa[r * sqa_stride]
     float *out; int64_t ldo;           // PF_STORE
     unsigned long long *prof;          // tuning build: phase cycle counters (SE_PF_PROFILE=1)
@@ -105,7 +106,10 @@ __device__ __forceinline__ int pf_scale_exp(float m)
     int ex;
     (void)frexpf(m, &ex);
     int e = 14 - ex;
-    return e < -120 ? -120 : (e > 120 ? 120 : e);
+    // |e| <= 60: the filter passes undo the scales of BOTH operand images with ldexpf(1, +-(ea + eb)), which must stay finite (a matrix whose
+    // largest entry is below 2^-46 gets a coarser image -- more of it flushes to zero, its residual norms and with them eps grow: slower, not wrong);
+    // the lower end cannot bind: regular magnitudes are < PF_REG_LIMIT = 2^60
+    return e < -60 ? -60 : (e > 60 ? 60 : e);
 }
 
 __global__ __launch_bounds__(256) void pf_convert_kernel(const float *__restrict__ x, int64_t ldx, int64_t n, int d, int kp,
@@ -134,8 +138,10 @@ __global__ __launch_bounds__(256) void pf_convert_kernel(const float *__restrict
                 const float xs = v[i] * sc;
                 _Float16 hh = (_Float16)xs;                                       // round to nearest even
                 if (__builtin_fabsf(xs) < 6.103515625e-05f) hh = (_Float16)0.f;   // below fp16's normal range: flushed HERE, never a denormal input
-                const float hv = (float)hh * isc;                                 // the image in the operand's own units (exact: power-of-two scale)
-                const float rv = v[i] - hv;
+                // image and residual in SCALED units (magnitudes up to 2^14): the squares of entries far below the matrix' largest one would
+                // underflow in the operand's own units and drop out of the norms -- and eps must be a true bound
+                const float hv = (float)hh;
+                const float rv = xs - hv;                                         // exact (xs = v 2^e, hv its fp16 rounding or 0)
                 sn = __builtin_fmaf(hv, hv, sn);
                 sr = __builtin_fmaf(rv, rv, sr);
                 bad = bad || !(__builtin_fabsf(v[i]) < PF_REG_LIMIT);             // NaN, inf or |v| >= 2^60
@@ -147,7 +153,9 @@ __global__ __launch_bounds__(256) void pf_convert_kernel(const float *__restrict
         sr = wave_sum(sr);
         const bool any_bad = __ballot(bad) != 0ull;
         // upper bounds of the two norms: the fp32 sums above carry a relative error < (d / 64 + 8) 2^-24 < 2^-9 for d <= 2^20
-        float nn = sqrtf(sn) * 1.002f + 1e-37f, rr = sqrtf(sr) * 1.002f + 1e-37f;
+        // + 2^-52 (scaled units): squares below 2^-126 -- entries below 2^-63 -- are lost to the sums: d 2^-126 <= 2^-106 in all for d <= 2^20.
+        // Back in the operand's units (exact power-of-two scale, floored at the smallest normal number).
+        float nn = (sqrtf(sn) * 1.002f + 2.220446e-16f) * isc + 1.1754944e-38f, rr = (sqrtf(sr) * 1.002f + 2.220446e-16f) * isc + 1.1754944e-38f;
         if (any_bad) {
             nn = rr = __builtin_nanf("");
             for (int c0 = lane * 4; c0 < kp; c0 += 256) *(uint2 *)(orow + c0) = make_uint2(0x7E007E00u, 0x7E007E00u);   // all-NaN image (fp16 quiet NaN)
@@ -170,6 +178,50 @@ __global__ __launch_bounds__(256) void pf_convert_kernel(const float *__restrict
         if (c) atomicAdd(&ctl[2], c);
         if (blockIdx.x == 0) ctl[4] = (unsigned)e;
     }
+}
+
+// A query's candidates of (gallery range p, tile sequence j) go to sub-list p gj + j, which ONE workgroup fills through a slot counter in
+// LDS.  A gallery sorted by class puts a query's neighbours into a few adjacent tiles, i.e. into two to four of the sub-lists, which
+// then overflow while the others stay empty (round 4: every query of a class-sorted ILSVRC-sized shard went to the exact fallback, 127x
+// the time).  So every query also has a spill region of `spill` more sub-list slots that all its sub-lists share (a separate array: the
+// sub-lists keep their compact pitch -- interleaved with them the spill slots cost the filter pass 12 % at 50k x 50k): an entry
+// that finds its own sub-list full takes the next place there (one global atomic on the query's spill counter -- rare on shuffled
+// galleries).  pf_spill_counts_kernel afterwards turns the counters into what the refinement reads:
+// min(count, cap) per real sub-list, the spill region cut into `spill` full / partial / empty virtual sub-lists (cap + 1 in the last
+// one when even the spill region overflowed: the query is redone exactly).
+__device__ __forceinline__ void pf_spill_append(const PfArgs &fa, int64_t query, int nsub, uint2 entry)
+{
+    const unsigned s = atomicAdd(&fa.spill_cnt[query], 1u);
+    if ((int64_t)s < (int64_t)fa.spill * fa.cap) fa.spill_lists[query * fa.spill * fa.cap + s] = entry;
+}
+
+__global__ __launch_bounds__(256) void pf_spill_counts_kernel(unsigned *__restrict__ rowcnt, const unsigned *__restrict__ spill_cnt, int64_t queries, int nsub,
+                                                              int spill, int64_t cap)
+{
+    // one thread per counter word (coalesced): real sub-lists are clamped in place, virtual ones derived from the query's spill count
+    const int nct = nsub + spill;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= queries * nct) return;
+    const int64_t q = i / nct;
+    const int p = (int)(i - q * nct);
+    if (p < nsub) {
+        const unsigned c = rowcnt[i];
+        if (c > (unsigned)cap) rowcnt[i] = (unsigned)cap;
+        return;
+    }
+    const int64_t S = spill_cnt[q], left = S - (int64_t)(p - nsub) * cap;
+    unsigned v = (unsigned)(left <= 0 ? 0 : (left < cap ? left : cap));
+    if (p == nct - 1 && S > (int64_t)spill * cap) v = (unsigned)cap + 1u;
+    rowcnt[i] = v;
+}
+
+int pf_spill_counts(unsigned *rowcnt, const unsigned *spill_cnt, int64_t queries, int nsub, int spill, int64_t cap, hipStream_t s)
+{
+    if (queries <= 0 || spill <= 0) return SE_OK;
+    const int64_t words = queries * (nsub + spill);
+    hipLaunchKernelGGL(pf_spill_counts_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, s, rowcnt, spill_cnt, queries, nsub, spill, cap);
+    SE_LAUNCH_CHECK();
+    return SE_OK;
 }
 
 // ---- tile loop --------------------------------------------------------------------------------------------------------------------
@@ -522,7 +574,8 @@ __global__ __launch_bounds__(PF_THREADS, PF_WGS_PER_CU) void pf_tile_kernel(
                         const int lr = lr0 + (i >> 4) * 32 + (i & 3) + 8 * ((i >> 2) & 3);
                         const float a = mine[i];
                         const float v = pf_finish<METRIC>(a * unscale, METRIC == SE_METRIC_EUCLID ? tSqRow[lr] : 0.f, sbq);
-                        if (slot < (unsigned)fa.cap) lst[slot] = make_uint2(__float_as_uint(v), (uint32_t)(cur_m0 + lr));
+                        if (__builtin_expect(slot < (unsigned)fa.cap, 1)) lst[slot] = make_uint2(__float_as_uint(v), (uint32_t)(cur_m0 + lr));
+                        else pf_spill_append(fa, cur_n0 + lc, nsub, make_uint2(__float_as_uint(v), (uint32_t)(cur_m0 + lr)));
                         slot++;
                     }
                 }
@@ -542,7 +595,7 @@ __global__ __launch_bounds__(PF_THREADS, PF_WGS_PER_CU) void pf_tile_kernel(
         if (last_chunk && job_ends && EPI == PF_FILTER && threadIdx.x < PF_BN) {
             // the job is complete: its slot counters -> rowcnt[query][sub-list] (counts above the capacity mark an overflow: the query is redone)
             const int64_t qc = (int64_t)cur.tn * PF_BN + threadIdx.x;
-            if (qc < NB) fa.rowcnt[qc * nsub + (cur.p * gj + gj_j)] = jobCnt[threadIdx.x];
+            if (qc < NB) fa.rowcnt[qc * (nsub + fa.spill) + (cur.p * gj + gj_j)] = jobCnt[threadIdx.x];
         }
         if (have_next) {
             pf_stage(sA, ra);
@@ -844,7 +897,8 @@ __global__ __launch_bounds__(PB_THREADS, 1) void pf_big_kernel(
                         const int lr = lr0 + (2 * h + (i >> 4)) * 32 + (i & 3) + 8 * ((i >> 2) & 3);
                         const float a = mine[i];
                         const float v = pf_finish<METRIC>(a * unscale, METRIC == SE_METRIC_EUCLID ? tSqRow[lr] : 0.f, sbq);
-                        if (slot < (unsigned)fa.cap) lst[slot] = make_uint2(__float_as_uint(v), (uint32_t)(cur_m0 + lr));
+                        if (__builtin_expect(slot < (unsigned)fa.cap, 1)) lst[slot] = make_uint2(__float_as_uint(v), (uint32_t)(cur_m0 + lr));
+                        else pf_spill_append(fa, cur_n0 + lc, nsub, make_uint2(__float_as_uint(v), (uint32_t)(cur_m0 + lr)));
                         slot++;
                     }
                 }
@@ -854,7 +908,7 @@ __global__ __launch_bounds__(PB_THREADS, 1) void pf_big_kernel(
             if (job_ends) {
                 // the job is complete: its slot counters -> rowcnt[query][sub-list] (counts above the capacity mark an overflow: the query is redone)
                 const int64_t qc = (int64_t)cur.tn * PB_BN + threadIdx.x;
-                if (qc < NB) fa.rowcnt[qc * nsub + (cur.p * gj + gj_j)] = jobCnt[threadIdx.x];
+                if (qc < NB) fa.rowcnt[qc * (nsub + fa.spill) + (cur.p * gj + gj_j)] = jobCnt[threadIdx.x];
             }
             if (!have_next) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the last (unused) requests must have landed before this workgroup's LDS is handed on
@@ -1039,7 +1093,7 @@ int pf_pass(int epi, const PfGeom *geom, int metric, const uint16_t *gallery, in
 {
     PfArgs fa;
     fa.gm = pa.gm; fa.gm_ld = pa.gm_ld; fa.thr = pa.thr; fa.rowcnt = pa.rowcnt; fa.lists = pa.lists; fa.cap = pa.cap;
-    fa.sqa_stride = pa.sqa_stride; fa.out = pa.out; fa.ldo = pa.ldo; fa.prof = nullptr;
+    fa.sqa_stride = pa.sqa_stride; fa.out = pa.out; fa.ldo = pa.ldo; fa.prof = nullptr; fa.spill = pa.spill; fa.spill_lists = pa.spill_lists; fa.spill_cnt = pa.spill_cnt;
     const PfGeom g = geom ? *geom : pf_geometry(n_a, n_q, 1, 0);
     if (g.big) {
         if (epi != PF_FILTER) return fail(SE_ERR_INVALID, "pre-filter pass: the 256 x 256 kernel only filters");

@@ -1886,7 +1886,13 @@ extern "C" int se_rank_rows_init(void *workspace, int64_t workspace_bytes, se_st
     hipStream_t s = (hipStream_t)stream;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return fail(SE_ERR_HIP, "se_rank_rows_init: no current device");
-    if (!rank_hw_order_ok(workspace, workspace_bytes, s)) {       // SE_RANK_SAFE, or the probe refuted the lane order: ballot kernels, nothing to audit
+    if (!rank_hw_order_ok(workspace, workspace_bytes, s)) {
+        // SE_RANK_SAFE, or the probe refuted the lane order: ballot kernels, nothing to audit.  A probe that could NOT run (stream under
+        // capture, a failed synchronise / copy) leaves the verdict open: the device must not count as audited then -- a later se_rank_rows
+        // could probe successfully and would run the hardware-ordered kernels with neither this self-test nor its first-call guard.
+        static const bool forced_safe = getenv("SE_RANK_SAFE") != nullptr;
+        if (!forced_safe && rr_hw_state[dev].load(std::memory_order_acquire) == 0)
+            return fail(SE_ERR_HIP, "se_rank_rows_init: the capability probe could not run on this stream (under capture?); the device stays unaudited");
         rr_checked[dev].store(1, std::memory_order_release);
         return SE_OK;
     }

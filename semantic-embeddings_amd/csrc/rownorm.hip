@@ -8,9 +8,10 @@
 // as ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), tail added sequentially, larger rows split recursively
 // at n/2 rounded down to a multiple of 8).  The order of the additions decides the rounding, so
 // the kernels reproduce exactly that tree.  Two kernels:
-//   * rownorm_kernel (D < 256): one LANE walks one row in NumPy's order; the rows of a workgroup are staged
+//   * rownorm_kernel (D < 8, D > 4096): one LANE walks one row in NumPy's order; the rows of a workgroup are staged
 //     through LDS with coalesced loads first, so HBM sees each byte once, streaming.
-//   * rownorm_wave_kernel (256 <= D <= 4096): one WAVE per row.  The row is staged in LDS with coalesced 16-byte
+//   * rownorm_small_kernel (8 <= D <= 248): 8 or 4 rows per wave at a time, one 8-lane group per NumPy leaf (below).
+//   * rownorm_wave_kernel (249 <= D <= 4096): one WAVE per row.  The row is staged in LDS with coalesced 16-byte
 //     loads; the tree's leaves (host-computed from D: the tree depends on nothing else) are dealt eight at a time to
 //     the eight 8-lane groups of the wave, lane u of a group running accumulator r[u] of its leaf (<= 16 sequential
 //     adds); the ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)) combination is a 3-step xor butterfly inside the group (IEEE
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(RN_ROWS) void rownorm_kernel(float *__restrict__ x,
 }
 
 // ---- one wave per row (256 <= D <= 4096) ------------------------------------------------------------------------------------
-constexpr int RW_MAX_LEAVES = 64, RW_MAX_D = 4096, RW_MIN_D = 256;
+constexpr int RW_MAX_LEAVES = 64, RW_MAX_D = 4096, RW_MIN_D = 249;   // (from 249 columns on a row has three leaves or more, all >= 64 long)
 struct RowTree {
     int nleaves, nprog;
     uint16_t off[RW_MAX_LEAVES];           // first column of leaf i
@@ -210,6 +211,69 @@ __global__ __launch_bounds__(256) void rownorm_wave_kernel(float *__restrict__ x
     }
 }
 
+// ---- short rows (8 <= D <= 248; the headline's D = 100): the same leaf arithmetic with SEVERAL rows per wave -------------------------
+// Such a row is one NumPy leaf (D <= 128) or two (split at (D / 2) rounded down to a multiple of 8; the right one is <= 128 long up to
+// D = 248, from 249 on it splits again: rownorm_wave_kernel), so the eight
+// 8-lane groups of a wave take 8 or 4 rows at a time: group g runs leaf g % nl of row g / nl exactly like rownorm_wave_kernel does
+// (accumulator u per lane, xor butterfly, sequential tail), a two-leaf row adds left + right, and all 64 lanes stream the rows in and
+// out.  (The one-lane-per-row kernel it replaces here kept its recursion stack in scratch -- 132 VGPRs + 528 B -- and moved 0.6 TB/s.)
+constexpr int RS_MIN_D = 8;
+template <bool NORMALIZE>
+__global__ __launch_bounds__(256) void rownorm_small_kernel(float *__restrict__ x, int64_t ldx, int64_t n, int d, float *__restrict__ sq)
+{
+    extern __shared__ __attribute__((aligned(16))) float rs_lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int dpad = (d + 3) & ~3;
+    const int nl = d > RN_CHUNK ? 2 : 1, rpi = 8 / nl;
+    int n2 = d / 2;
+    n2 -= n2 % 8;
+    float *stage = rs_lds + wave * (8 * dpad);                          // [rpi][dpad]
+    const int grp = lane >> 3, u = lane & 7;
+    const int rr = grp / nl, li = grp - rr * nl;
+    const int lo = li ? n2 : 0, ln = nl == 1 ? d : (li ? d - n2 : n2);
+    const int body = ln - (ln % 8);
+    for (int64_t r0 = ((int64_t)blockIdx.x * nw + wave) * rpi; r0 < n; r0 += (int64_t)gridDim.x * nw * rpi) {
+        const int rows = (int)((n - r0 < rpi) ? (n - r0) : rpi);
+        for (int q = 0; q < rows; q++) {
+            const float *xr = x + (r0 + q) * ldx;
+            for (int c = lane; c < d; c += 64) stage[q * dpad + c] = xr[c];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const float *a = stage + (rr < rows ? rr : 0) * dpad + lo;
+        float acc = a[u] * a[u];
+        for (int i = 8; i < body; i += 8) { const float v = a[i + u]; acc = acc + v * v; }
+        acc = acc + __shfl_xor(acc, 1, 64);                              // ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7))
+        acc = acc + __shfl_xor(acc, 2, 64);
+        acc = acc + __shfl_xor(acc, 4, 64);
+        if (u == 0) for (int i = body; i < ln; i++) { const float v = a[i]; acc = acc + v * v; }
+        float ss = __shfl(acc, lane & ~7, 64);                           // the leaf's sum, on every lane of its group
+        if (nl == 2) ss = __shfl(ss, (grp & ~1) * 8, 64) + __shfl(ss, (grp | 1) * 8, 64);   // left + right
+        if (!NORMALIZE) {
+            if (u == 0 && li == 0 && rr < rows) sq[r0 + rr] = ss;
+        } else {
+            for (int q = 0; q < rows; q++) {
+                const float nrm = sqrtf(__shfl(ss, q * nl * 8, 64));
+                float *xr = x + (r0 + q) * ldx;
+                for (int c = lane; c < d; c += 64) xr[c] = stage[q * dpad + c] / nrm;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");           // the next rows overwrite the stage
+    }
+}
+
+template <bool NORMALIZE>
+static int launch_rownorm_small(float *x, int64_t ldx, int64_t n, int d, float *sq, hipStream_t s)
+{
+    const int dpad = (d + 3) & ~3, waves = 4;
+    const size_t lds = (size_t)waves * 8 * dpad * sizeof(float);          // <= 32 KB
+    const int rpi = d > RN_CHUNK ? 4 : 8;
+    int64_t grid = (n + (int64_t)waves * rpi - 1) / ((int64_t)waves * rpi);
+    if (grid > 256 * 16) grid = 256 * 16;
+    hipLaunchKernelGGL((rownorm_small_kernel<NORMALIZE>), dim3((unsigned)grid), dim3(waves * 64), lds, s, x, ldx, n, d, sq);
+    SE_LAUNCH_CHECK();
+    return SE_OK;
+}
+
 template <bool NORMALIZE>
 static int launch_rownorm_wave(float *x, int64_t ldx, int64_t n, int d, float *sq, hipStream_t s)
 {
@@ -238,6 +302,7 @@ extern "C" int se_row_sqnorm(const float *x, int64_t ldx, int64_t n, int64_t d, 
     if (n == 0) return SE_OK;
     if (!x || !sq || ldx < d) return fail(SE_ERR_INVALID, "se_row_sqnorm: bad argument");
     if (d >= RW_MIN_D && d <= RW_MAX_D) return launch_rownorm_wave<false>(const_cast<float *>(x), ldx, n, (int)d, sq, (hipStream_t)stream);
+    if (d >= RS_MIN_D && d < RW_MIN_D) return launch_rownorm_small<false>(const_cast<float *>(x), ldx, n, (int)d, sq, (hipStream_t)stream);
     hipLaunchKernelGGL(rownorm_kernel<false>, dim3((unsigned)((n + RN_ROWS - 1) / RN_ROWS)), dim3(RN_ROWS), 0,
                        (hipStream_t)stream, const_cast<float *>(x), ldx, n, (int)d, sq);
     SE_LAUNCH_CHECK();
@@ -250,6 +315,7 @@ extern "C" int se_normalize_rows(float *x, int64_t ldx, int64_t n, int64_t d, se
     if (n == 0) return SE_OK;
     if (!x || ldx < d) return fail(SE_ERR_INVALID, "se_normalize_rows: bad argument");
     if (d >= RW_MIN_D && d <= RW_MAX_D) return launch_rownorm_wave<true>(x, ldx, n, (int)d, (float *)nullptr, (hipStream_t)stream);
+    if (d >= RS_MIN_D && d < RW_MIN_D) return launch_rownorm_small<true>(x, ldx, n, (int)d, (float *)nullptr, (hipStream_t)stream);
     hipLaunchKernelGGL(rownorm_kernel<true>, dim3((unsigned)((n + RN_ROWS - 1) / RN_ROWS)), dim3(RN_ROWS), 0,
                        (hipStream_t)stream, x, ldx, n, (int)d, (float *)nullptr);
     SE_LAUNCH_CHECK();

@@ -14,6 +14,12 @@ namespace se {
 char *err_buf();
 int fail(int code, const char *fmt, ...);
 
+// Phase timing (se_phase_timing / se_phase_timing_read, include/sehip.h): when switched on, multi-kernel entry points record a HIP
+// event on their stream behind each phase.  Off (the default): one relaxed atomic load per mark.
+void phase_mark(const char *name, hipStream_t s);
+bool phase_timing_on();
+void phase_note_counters(const unsigned *dev_counters, long long rows);   // se_retrieve_topk: where its 4 statistics words live
+
 #define SE_HIP_CHECK(expr)                                                                     \
     do {                                                                                       \
         hipError_t e__ = (expr);                                                               \
@@ -122,6 +128,7 @@ struct PfPassArgs {
     float *gm; int64_t gm_ld;          // sample pass: [queries, gm_ld] group minima of d~ (d~: the half-precision distance)
     const float *thr;                  // filter pass: [queries] thresholds (NaN: only NaN values pass)
     unsigned *rowcnt; uint2 *lists; int64_t cap;     // cap: entries per (query, sub-list)
+    int spill; uint2 *spill_lists; unsigned *spill_cnt;   // filter pass: sub-list slots of every query's shared spill region, [queries][spill * cap]; fill counters [queries]
     int64_t sqa_stride;
     float *out; int64_t ldo;           // PF_EPI_STORE (tuning build): d~ matrix [gallery rows, queries]
 };
@@ -137,6 +144,8 @@ int pf_convert(const float *x, int64_t ldx, int64_t n, int64_t d, uint16_t *out,
 // nsub = parts * gj.  want_parts = 0: as many ranges as keep every XCD busy for >= ~4 rounds.
 struct PfGeom { int gi, gj, parts, tpp, big; };      // big: the 256 x 256 filter kernel (long rows) instead of the 128 x 128 one
 PfGeom pf_geometry(int64_t n_a, int64_t n_q, int want_parts, int kp);    // kp: padded columns of the FILTER pass this is for; 0: sample pass
+// filter pass with a spill region: counters [queries][nsub + spill] -> per-sub-list counts as the refinement reads them (prefilter.hip)
+int pf_spill_counts(unsigned *rowcnt, const unsigned *spill_cnt, int64_t queries, int nsub, int spill, int64_t cap, hipStream_t s);
 int pf_pass(int epi, const PfGeom *geom, int metric, const uint16_t *gallery, int64_t lda, const uint16_t *queries, int64_t ldq, const float *sqg,
             const float *sqq, int64_t n_a, int64_t n_q, int kp, const unsigned *ctl_g, const unsigned *ctl_q, const PfPassArgs &pa, hipStream_t s);
 

@@ -1,7 +1,43 @@
 // se_core.hip -- library-level entry points of include/sehip.h (version, error text).
 #include "se_common.h"
+#include <atomic>
+#include <mutex>
 
 namespace se {
+
+// ---- phase timing: a measuring aid of the product library (bench.py's per-leg rooflines), off unless se_phase_timing(1) ----
+constexpr int PT_CAP = 96;
+static std::atomic<int> pt_on{0};
+static std::mutex pt_mu;                       // guards everything below
+static int pt_n = 0;
+static hipEvent_t pt_ev[PT_CAP];
+static bool pt_ev_made[PT_CAP];
+static const char *pt_name[PT_CAP];
+static const unsigned *pt_counters = nullptr;
+static long long pt_rows = 0;
+
+bool phase_timing_on() { return pt_on.load(std::memory_order_relaxed) != 0; }
+
+void phase_mark(const char *name, hipStream_t s)
+{
+    if (!phase_timing_on()) return;
+    std::lock_guard<std::mutex> lk(pt_mu);
+    if (pt_n >= PT_CAP) return;
+    if (!pt_ev_made[pt_n]) {
+        if (hipEventCreate(&pt_ev[pt_n]) != hipSuccess) return;
+        pt_ev_made[pt_n] = true;
+    }
+    if (hipEventRecord(pt_ev[pt_n], s) != hipSuccess) return;
+    pt_name[pt_n++] = name;
+}
+
+void phase_note_counters(const unsigned *dev_counters, long long rows)
+{
+    if (!phase_timing_on()) return;
+    std::lock_guard<std::mutex> lk(pt_mu);
+    pt_counters = dev_counters;
+    pt_rows = rows;
+}
 
 char *err_buf()
 {
@@ -20,6 +56,40 @@ int fail(int code, const char *fmt, ...)
 
 }  // namespace se
 
-extern "C" int se_version(void) { return 300; /* 0.3.0: se_retrieve_topk takes K-blocks and ldg (fused distance + top-k) */ }
+extern "C" int se_version(void) { return 310; /* 0.3.1: se_phase_timing / se_phase_timing_read */ }
 extern "C" const char *se_last_error(void) { return se::err_buf(); }
 extern "C" const char *se_build_arch(void) { return "gfx950"; }
+
+extern "C" int se_phase_timing(int on)
+{
+    std::lock_guard<std::mutex> lk(se::pt_mu);
+    se::pt_n = 0;
+    se::pt_counters = nullptr;
+    se::pt_on.store(on ? 1 : 0, std::memory_order_relaxed);
+    return SE_OK;
+}
+
+extern "C" int se_phase_timing_read(const char **names_host, float *ms_host, int cap, int64_t *counters_host)
+{
+    std::lock_guard<std::mutex> lk(se::pt_mu);
+    int out = 0;
+    if (se::pt_n > 0) SE_HIP_CHECK(hipEventSynchronize(se::pt_ev[se::pt_n - 1]));
+    for (int i = 1; i < se::pt_n && out < cap; i++) {
+        float ms = 0.f;
+        SE_HIP_CHECK(hipEventElapsedTime(&ms, se::pt_ev[i - 1], se::pt_ev[i]));
+        if (names_host) names_host[out] = se::pt_name[i];
+        if (ms_host) ms_host[out] = ms;
+        out++;
+    }
+    if (counters_host) {
+        counters_host[0] = counters_host[1] = counters_host[2] = counters_host[3] = counters_host[4] = -1;
+        if (se::pt_counters) {
+            unsigned h[4];
+            SE_HIP_CHECK(hipMemcpy(h, se::pt_counters, sizeof(h), hipMemcpyDeviceToHost));
+            for (int i = 0; i < 4; i++) counters_host[i] = (int64_t)h[i];
+            counters_host[4] = (int64_t)se::pt_rows;
+        }
+    }
+    se::pt_n = 0;
+    return out;
+}

@@ -1088,7 +1088,7 @@ __device__ unsigned long long rf_prof[8];      // tuning build, SE_TOPK_VERBOSE:
 #endif
 
 template <int METRIC, bool VEC, bool LONGROWS>
-__global__ __launch_bounds__(RF_WAVES * 64, 3) void pf_refine_kernel(const uint2 *__restrict__ lists, const unsigned *__restrict__ rowcnt, int64_t cap, int parts, int64_t Q,
+__global__ __launch_bounds__(RF_WAVES * 64, 3) void pf_refine_kernel(const uint2 *__restrict__ lists, const uint2 *__restrict__ spill_lists, int nsub, const unsigned *__restrict__ rowcnt, int64_t cap, int parts, int64_t Q,
                                                                   const float *__restrict__ thr, const float *__restrict__ eps,
                                                                   const float *__restrict__ queries, int64_t ldq, const float *__restrict__ gallery,
                                                                   int64_t ldg, const float *__restrict__ sqq, const float *__restrict__ sqg,
@@ -1108,7 +1108,9 @@ __global__ __launch_bounds__(RF_WAVES * 64, 3) void pf_refine_kernel(const uint2
         const int64_t urow = __builtin_amdgcn_readfirstlane((int)row);          // (Q < 2^31: the launcher checks)
         RF_T(7)
         // the query's candidates: `parts` sub-lists (one per gallery range of the filter pass) of up to `cap` entries each
-        const uint2 *lst = lists + urow * parts * cap;
+        // (sub-lists [0, nsub): the filter pass's own, [nsub, parts): the query's spill region cut into sub-list slots -- a separate array)
+        const uint2 *lst_main = lists + urow * nsub * cap, *lst_spill = spill_lists + urow * (parts - nsub) * cap;
+        auto sub_list = [&](int p) -> const uint2 * { return p < nsub ? lst_main + (int64_t)p * cap : lst_spill + (int64_t)(p - nsub) * cap; };
         const unsigned *cnts = rowcnt + urow * parts;
         unsigned total = 0;
         bool ok = true;
@@ -1152,7 +1154,7 @@ __global__ __launch_bounds__(RF_WAVES * 64, 3) void pf_refine_kernel(const uint2
                     }
                     const uint32_t ec = e < total ? e : 0u;
                     const int pc = e < total ? lo : 0;
-                    val[i] = lst[(int64_t)pc * cap + (ec - (e < total ? pre[pc] : 0u))];
+                    val[i] = sub_list(pc)[ec - (e < total ? pre[pc] : 0u)];
                 }
 #pragma unroll
                 for (int i = 0; i < 8; i++) {
@@ -1181,7 +1183,7 @@ __global__ __launch_bounds__(RF_WAVES * 64, 3) void pf_refine_kernel(const uint2
                     }
                 } else {
                     for (int p = 0; p < parts; p++) {
-                        const uint2 *lp = lst + p * cap;
+                        const uint2 *lp = sub_list(p);
                         const unsigned cp = cnts[p];
                         for (unsigned e = lane; e < cp; e += 64) {
                             const uint32_t key = canon_key(__uint_as_float(lp[e].x));
@@ -1237,7 +1239,7 @@ __global__ __launch_bounds__(RF_WAVES * 64, 3) void pf_refine_kernel(const uint2
                     }
                 } else
                 for (int p = 0; p < parts; p++) {
-                    const uint2 *lp = lst + p * cap;
+                    const uint2 *lp = sub_list(p);
                     const unsigned cp = cnts[p];
                     for (unsigned e0 = 0; e0 < cp; e0 += 64) {
                         const unsigned e = e0 + lane;
@@ -1367,8 +1369,9 @@ struct FusedLayout {
     // pre-filter path only (parts: sub-lists per query, cap: entries per sub-list, geom: the filter pass's job geometry)
     int parts;
     PfGeom geom;
-    int64_t cap, off_eps, off_ctl, off_gimg, off_gnrm, off_gres, off_qimg, off_qnrm, off_qres;
+    int64_t cap, off_eps, off_ctl, off_gimg, off_gnrm, off_gres, off_qimg, off_qnrm, off_qres, off_spill;
     int kp;
+    int nsub, spill;        // pre-filter: real sub-lists per query (filter geometry) + slots of the shared spill region; parts = nsub + spill
 };
 static bool prefilter_wanted(const FusedPlan &p, int k)
 {
@@ -1386,10 +1389,15 @@ static FusedLayout fused_layout(int64_t q, int64_t n, int64_t d, const FusedPlan
         // the half-precision thresholds admit a window of 4 eps more than the exact ones the plan was made for: 1.5x the planned total,
         // cut into the filter pass's gallery parts (+ room for the relative fluctuation of a small share)
         L.geom = pf_geometry(n, q, 0, pf_padded_dim(d));
-        L.parts = L.geom.parts * L.geom.gj;
+        L.nsub = L.geom.parts * L.geom.gj;
         const int64_t total_cap = align256((int64_t)p.cap * 3 / 2);
-        L.cap = (total_cap / L.parts + 32 + 15) / 16 * 16;
-        if (const char *e = tuning_env("SE_TOPK_CAP")) L.cap = atoi(e) / L.parts > 0 ? atoi(e) / L.parts : 1;
+        L.cap = (total_cap / L.nsub + 32 + 15) / 16 * 16;
+        if (const char *e = tuning_env("SE_TOPK_CAP")) L.cap = atoi(e) / L.nsub > 0 ? atoi(e) / L.nsub : 1;
+        // + a spill region of as many sub-list slots again, shared by the query's sub-lists (prefilter.hip: pf_spill_append): a gallery
+        // sorted by class sends a query's candidates to two or three of them
+        L.spill = L.nsub;
+        if (const char *e = tuning_env("SE_TOPK_SPILL")) L.spill = atoi(e);
+        L.parts = L.nsub + L.spill;
         const int64_t per_row = L.parts * (L.cap * 8 + 4) + (int64_t)p.G * 4 + 16;
         qt = ((int64_t)4 << 30) / per_row / 128 * 128;
     } else {
@@ -1401,9 +1409,10 @@ static FusedLayout fused_layout(int64_t q, int64_t n, int64_t d, const FusedPlan
     L.qt = qt;
     L.off_tau = 0;
     L.off_cnt = align256(qt * 4);
-    L.off_gm = L.off_cnt + align256(qt * L.parts * 4 + 16);       // [qt (x parts)] candidate counts + 4 control words (flagged-query counters)
+    L.off_gm = L.off_cnt + align256(qt * L.parts * 4 + 16 + qt * 4);   // [qt (x parts)] candidate counts + 4 control words (flagged-query counters) + [qt] spill counts
     L.off_lists = L.off_gm + align256(qt * p.G * 4);
-    L.off_scratch = L.off_lists + align256(qt * L.parts * L.cap * 8);
+    L.off_spill = L.off_lists + align256(qt * (pf ? L.nsub : L.parts) * L.cap * 8);
+    L.off_scratch = L.off_spill + align256(qt * (pf ? L.spill : 0) * L.cap * 8);
     L.total = L.off_scratch + align256((int64_t)FB_GRID * n * 4);
     if (pf) {
         L.kp = pf_padded_dim(d);
@@ -1477,7 +1486,7 @@ static int retrieve_topk_prefilter(const float *queries, int64_t ldq, const floa
     float *thr = (float *)(ws + L.off_tau), *eps = (float *)(ws + L.off_eps);
     unsigned *rowcnt = (unsigned *)(ws + L.off_cnt), *ctl = (unsigned *)(ws + L.off_ctl);
     float *gm = (float *)(ws + L.off_gm);
-    uint2 *lists = (uint2 *)(ws + L.off_lists);
+    uint2 *lists = (uint2 *)(ws + L.off_lists), *spill_lists = (uint2 *)(ws + L.off_spill);
     float *scratch = (float *)(ws + L.off_scratch);
     uint16_t *gimg = (uint16_t *)(ws + L.off_gimg), *qimg = (uint16_t *)(ws + L.off_qimg);
     float *gnrm = (float *)(ws + L.off_gnrm), *gres = (float *)(ws + L.off_gres), *qnrm = (float *)(ws + L.off_qnrm), *qres = (float *)(ws + L.off_qres);
@@ -1486,8 +1495,10 @@ static int retrieve_topk_prefilter(const float *queries, int64_t ldq, const floa
     const size_t lds_sel = (size_t)P * 8 + (TK_NB + TK_WAVES + 1 + 4) * sizeof(uint32_t);
     const bool vec = (ldg % 4 == 0) && ((((uintptr_t)gallery) & 15) == 0);
     // ---- gallery image (once per call) ----
+    phase_mark("start", s);
     SE_HIP_CHECK(hipMemsetAsync(ctl, 0, 256, s));
     if (const int rc = pf_convert(gallery, ldg, n, d, gimg, gnrm, gres, ctl, s)) return rc;
+    phase_mark("convert", s);
     for (int64_t q0 = 0; q0 < q; q0 += L.qt) {
         const int64_t rows = (q - q0 < L.qt) ? (q - q0) : L.qt;
         const float *qs = queries + q0 * ldq;
@@ -1501,28 +1512,37 @@ static int retrieve_topk_prefilter(const float *queries, int64_t ldq, const floa
             SE_HIP_CHECK(hipMemsetAsync(ctl + 8, 0, 32, s));
             if (const int rc = pf_convert(qs, ldq, rows, d, qimg, qnrm, qres, ctl + 8, s)) return rc;
             qi = qimg; qn = qnrm; qr = qres; qc = ctl + 8;
+            phase_mark("convert", s);
         }
         unsigned *nflag = rowcnt + rows * L.parts;                     // [1] queries handed to the exact kernel; [2..3] statistics (tuning)
-        SE_HIP_CHECK(hipMemsetAsync(rowcnt, 0, (size_t)rows * L.parts * 4 + 16, s));
-        PfPassArgs pa = {gm, p.G, thr, rowcnt, lists, L.cap, p.step, nullptr, 0};
+        unsigned *spill_cnt = nflag + 4;                               // [rows] entries in every query's spill region
+        SE_HIP_CHECK(hipMemsetAsync(rowcnt, 0, (size_t)rows * L.parts * 4 + 16 + (size_t)rows * 4, s));
+        PfPassArgs pa = {gm, p.G, thr, rowcnt, lists, L.cap, L.spill, spill_lists, spill_cnt, p.step, nullptr, 0};
         int rc = pf_pass(PF_EPI_GROUPMIN, nullptr, metric, gimg, p.step * (int64_t)kp, qi, kp, sqg, sq, p.S, rows, kp, ctl, qc, pa, s);
         if (rc != SE_OK) return rc;
+        phase_mark("sample", s);
         hipLaunchKernelGGL(pf_thr_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, gm, (int64_t)p.G, rows, p.G, p.j, qn, qr, ctl, metric, (int)d, kp,
                            kbs.n, thr, eps);
         SE_LAUNCH_CHECK();
         pa.sqa_stride = 1;
+        phase_mark("threshold", s);
         rc = pf_pass(PF_EPI_FILTER, &L.geom, metric, gimg, kp, qi, kp, sqg, sq, n, rows, kp, ctl, qc, pa, s);
         if (rc != SE_OK) return rc;
+        if ((rc = pf_spill_counts(rowcnt, spill_cnt, rows, L.nsub, L.spill, L.cap, s)) != SE_OK) return rc;
+        phase_mark("filter", s);
         const bool verbose = kTuning && tuning_env("SE_TOPK_VERBOSE");
+        const bool count = verbose || phase_timing_on();               // [2..3] of nflag: entries recomputed exactly / candidates, summed over the queries
+        phase_note_counters(nflag, rows);
 
         const int64_t rgrid = (rows + RF_WAVES - 1) / RF_WAVES < 8192 ? (rows + RF_WAVES - 1) / RF_WAVES : 8192;
-#define SE_RF_LAUNCH(M, V, LR) hipLaunchKernelGGL((pf_refine_kernel<M, V, LR>), dim3((unsigned)rgrid), dim3(RF_WAVES * 64), 0, s, lists, rowcnt, L.cap, L.parts, rows, thr, eps, qs, ldq, \
-                                                  gallery, ldg, sq, sqg, kbs, col_offset, k, out_d + q0 * k, out_i + q0 * k, nflag, verbose ? nflag + 2 : nullptr)
+#define SE_RF_LAUNCH(M, V, LR) hipLaunchKernelGGL((pf_refine_kernel<M, V, LR>), dim3((unsigned)rgrid), dim3(RF_WAVES * 64), 0, s, lists, spill_lists, L.nsub, rowcnt, L.cap, L.parts, rows, thr, eps, qs, ldq, \
+                                                  gallery, ldg, sq, sqg, kbs, col_offset, k, out_d + q0 * k, out_i + q0 * k, nflag, count ? nflag + 2 : nullptr)
         const bool longrows = vec && d >= RF_STAGE_D;                  // the build with the LDS-staged row gather
         if (metric == SE_METRIC_COSINE) { if (longrows) SE_RF_LAUNCH(SE_METRIC_COSINE, true, true); else if (vec) SE_RF_LAUNCH(SE_METRIC_COSINE, true, false); else SE_RF_LAUNCH(SE_METRIC_COSINE, false, false); }
         else { if (longrows) SE_RF_LAUNCH(SE_METRIC_EUCLID, true, true); else if (vec) SE_RF_LAUNCH(SE_METRIC_EUCLID, true, false); else SE_RF_LAUNCH(SE_METRIC_EUCLID, false, false); }
 #undef SE_RF_LAUNCH
         SE_LAUNCH_CHECK();
+        phase_mark("refine", s);
         if (verbose) {   // -DSE_TUNING build only: synchronises and reports how the lists came out
             SE_HIP_CHECK(hipStreamSynchronize(s));
 #ifdef SE_TUNING
@@ -1557,6 +1577,7 @@ static int retrieve_topk_prefilter(const float *queries, int64_t ldq, const floa
             hipLaunchKernelGGL(topk_fallback_kernel<SE_METRIC_EUCLID>, dim3((unsigned)fgrid), dim3(TK_THREADS), ((lds_sel + 15) & ~(size_t)15) + FB_ROWBUF_BYTES, s, qs, ldq, gallery, ldg, sq, sqg,
                                rows, (int)n, (int)d, kbs, col_offset, k, P, (int)((lds_sel + 15) & ~(size_t)15), scratch, out_d + q0 * k, out_i + q0 * k, nflag);
         SE_LAUNCH_CHECK();
+        phase_mark("fallback", s);
     }
     return SE_OK;
 }
@@ -1686,7 +1707,7 @@ extern "C" int se_tuning_prefilter_probe(const float *queries, int64_t ldq, cons
     SE_HIP_CHECK(hipMemsetAsync(gm, 0, (size_t)q * 4, s));
     if (const int rc = pf_convert(gallery, ldg, n, d, gimg, gnrm, gres, ctl, s)) return rc;
     if (const int rc = pf_convert(queries, ldq, q, d, qimg, qnrm, qres, ctl + 8, s)) return rc;
-    PfPassArgs pa = {nullptr, 0, nullptr, nullptr, nullptr, 0, 1, out_dt, ldo};
+    PfPassArgs pa = {nullptr, 0, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, 1, out_dt, ldo};
     if (const int rc = pf_pass(PF_EPI_STORE, nullptr, metric, gimg, kp, qimg, kp, sqg, sqq, n, q, kp, ctl, ctl + 8, pa, s)) return rc;
     hipLaunchKernelGGL(pf_thr_kernel, dim3((unsigned)((q + 3) / 4)), dim3(256), 0, s, gm, (int64_t)1, q, 1, 1, qnrm, qres, ctl, metric, (int)d, kp, nkb, thr, out_eps);
     SE_LAUNCH_CHECK();

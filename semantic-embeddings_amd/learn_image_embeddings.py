@@ -250,7 +250,7 @@ def main(argv=None):
         metrics = [accuracy if onehot_like else utils.nn_accuracy(emb_dev, dot_prod_sim=True)]
         metrics += [utils.top_k_acc(k) if onehot_like else utils.nn_accuracy(emb_dev, dot_prod_sim=True, k=k) for k in args.top_k_acc]
     else:
-        loss = lambda y, o: utils.squared_distance(emb_dev[y], o)
+        loss = utils.SquaredDistanceLoss(emb_dev)          # fused gather + squared distance (se_sqdist_loss_fwd / bwd)
         metrics = [accuracy if args.embedding == 'onehot' else utils.nn_accuracy(emb_dev, dot_prod_sim=False)]
         metrics += [utils.top_k_acc(k) if args.embedding == 'onehot' else utils.nn_accuracy(emb_dev, dot_prod_sim=False, k=k) for k in args.top_k_acc]
     embedding_layer_name = {'inv_corr': 'l2norm', 'softmax_corr': 'softmax'}.get(args.loss, 'embedding')

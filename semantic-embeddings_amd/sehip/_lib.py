@@ -20,8 +20,8 @@ TOPK_MAX = 2048
 
 # every symbol include/sehip.h declares (checked by tests/test_abi.py)
 EXPORTS = (
-    "se_version", "se_last_error", "se_build_arch",
-    "se_cosine_loss_fwd", "se_cosine_loss_bwd", "se_l2norm_fwd", "se_l2norm_bwd", "se_nn_accuracy_workspace_bytes", "se_nn_accuracy",
+    "se_version", "se_last_error", "se_build_arch", "se_phase_timing", "se_phase_timing_read",
+    "se_cosine_loss_fwd", "se_cosine_loss_bwd", "se_sqdist_loss_fwd", "se_sqdist_loss_bwd", "se_l2norm_fwd", "se_l2norm_bwd", "se_nn_accuracy_workspace_bytes", "se_nn_accuracy",
     "se_labelembed_aux_floats", "se_labelembed_loss_fwd", "se_labelembed_loss_bwd",
     "se_devise_aux_floats", "se_devise_loss_fwd", "se_devise_loss_bwd",
     "se_row_sqnorm", "se_normalize_rows", "se_pairwise_dist",
@@ -71,8 +71,12 @@ def lib():
     L.se_version.restype = c_int
     L.se_last_error.restype = ctypes.c_char_p
     L.se_build_arch.restype = ctypes.c_char_p
+    L.se_phase_timing.argtypes = [c_int]
+    L.se_phase_timing_read.argtypes = [ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(c_f), c_int, ctypes.POINTER(c_i64)]
     L.se_cosine_loss_fwd.argtypes = [vp, c_int, c_i64, vp, vp, c_i64, c_i64, c_i64, c_i64, vp, c_i64, vp, vp, vp, vp]
     L.se_cosine_loss_bwd.argtypes = [vp, c_int, c_i64, vp, vp, c_i64, vp, c_f, c_i64, c_i64, c_i64, vp, c_int, c_i64, vp]
+    L.se_sqdist_loss_fwd.argtypes = [vp, c_int, c_i64, vp, vp, c_i64, c_i64, c_i64, c_i64, vp, vp, vp, vp]
+    L.se_sqdist_loss_bwd.argtypes = [vp, c_int, c_i64, vp, vp, c_i64, vp, c_f, c_i64, c_i64, c_i64, vp, c_int, c_i64, vp]
     L.se_l2norm_fwd.argtypes = [vp, c_int, c_i64, c_i64, c_i64, vp, c_i64, vp, vp]
     L.se_l2norm_bwd.argtypes = [vp, c_i64, vp, c_i64, vp, c_i64, c_i64, vp, c_i64, vp]
     L.se_nn_accuracy_workspace_bytes.argtypes = [c_i64, c_i64]

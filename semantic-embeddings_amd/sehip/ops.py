@@ -114,6 +114,65 @@ def cosine_embedding_loss(x, labels, embedding, reduction="mean", return_normali
     return (loss_i, xhat) if return_normalized else loss_i
 
 
+def sqdist_loss_forward(x, labels, embedding, want_dist=False):
+    """``se_sqdist_loss_fwd``: loss_i = sum_d (x - E[y])^2 (utils.squared_distance on transform_inputs' gather, utils.py:34-36,
+    learn_image_embeddings.py:48-50) and, on request, dist_i = sqrt(loss_i) (utils.mean_distance, utils.py:39-41).
+    Returns (loss_i, dist_i | None, loss_mean)."""
+    require_gpu(x, labels, embedding)
+    _rows(x, "x"); _rows(embedding, "embedding")
+    B, D = x.shape
+    C = embedding.shape[0]
+    if embedding.shape[1] != D or embedding.dtype != torch.float32:
+        raise SehipError("embedding must be float32 [C, %d]" % D)
+    if labels.dtype != torch.int64 or labels.numel() != B or not labels.is_contiguous():
+        raise SehipError("labels must be a contiguous int64 [B] tensor")
+    loss_i = torch.empty((B,), dtype=torch.float32, device=x.device)
+    dist_i = torch.empty((B,), dtype=torch.float32, device=x.device) if want_dist else None
+    loss_mean = torch.empty((1,), dtype=torch.float32, device=x.device)
+    check(lib().se_sqdist_loss_fwd(ptr(x), _dtype_code(x), x.stride(0), ptr(labels), ptr(embedding), embedding.stride(0), B, D, C,
+                                   ptr(loss_i), ptr(dist_i), ptr(loss_mean), stream_ptr()), "se_sqdist_loss_fwd")
+    return loss_i, dist_i, loss_mean
+
+
+def sqdist_loss_backward(x, labels, embedding, grad_loss_i=None, grad_scale=1.0, out_dtype=None):
+    """``se_sqdist_loss_bwd``: dx = 2 w (x - E[y])."""
+    require_gpu(x, labels, embedding, grad_loss_i)
+    _rows(x, "x"); _rows(embedding, "embedding")
+    B, D = x.shape
+    C = embedding.shape[0]
+    dx = torch.empty((B, D), dtype=out_dtype or x.dtype, device=x.device)
+    if grad_loss_i is not None:
+        grad_loss_i = grad_loss_i.to(torch.float32).contiguous()
+    check(lib().se_sqdist_loss_bwd(ptr(x), _dtype_code(x), x.stride(0), ptr(labels), ptr(embedding), embedding.stride(0), ptr(grad_loss_i),
+                                   ctypes.c_float(grad_scale), B, D, C, ptr(dx), _dtype_code(dx), D, stream_ptr()), "se_sqdist_loss_bwd")
+    return dx
+
+
+class _SquaredDistanceLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, labels, embedding):
+        x = x if x.stride(-1) == 1 else x.contiguous()
+        loss_i, _, _ = sqdist_loss_forward(x, labels, embedding)
+        ctx.save_for_backward(x, labels, embedding)
+        return loss_i
+
+    @staticmethod
+    def backward(ctx, grad_loss_i):
+        x, labels, embedding = ctx.saved_tensors
+        return sqdist_loss_backward(x, labels, embedding, grad_loss_i.contiguous()), None, None
+
+
+def squared_distance_loss(x, labels, embedding, reduction="none"):
+    """Differentiable ``utils.squared_distance(embedding[labels], x)`` (the `--loss mse` training loss) in one HIP launch forward,
+    one backward; ``reduction``: "none" (Keras-style per-sample tensor), "mean" or "sum"."""
+    loss_i = _SquaredDistanceLoss.apply(x, labels, embedding)
+    if reduction == "mean":
+        return loss_i.mean()
+    if reduction == "sum":
+        return loss_i.sum()
+    return loss_i
+
+
 class _L2Norm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
@@ -380,6 +439,28 @@ def release_workspace(device=None):
     else:
         dev = torch.device(device)
         _ws_cache.pop(dev.index if dev.index is not None else torch.cuda.current_device(), None)
+
+
+def phase_timing(on=True):
+    """``se_phase_timing``: switch the library's phase events on / off (a measuring aid: bench.py's per-leg rooflines)."""
+    check(lib().se_phase_timing(1 if on else 0), "se_phase_timing")
+
+
+def phase_timing_read():
+    """``se_phase_timing_read`` -> (dict phase -> total ms since the last read, counters or None).  counters = {"redone", "recomputed",
+    "candidates", "queries"} of the last ``retrieve_topk`` call (its workspace -- the per-device cache -- is still alive)."""
+    cap = 96
+    names = (ctypes.c_char_p * cap)()
+    ms = (ctypes.c_float * cap)()
+    cnt = (ctypes.c_int64 * 5)()
+    n = lib().se_phase_timing_read(names, ms, cap, cnt)
+    if n < 0:
+        check(n, "se_phase_timing_read")
+    out = {}
+    for i in range(n):
+        out[names[i].decode()] = out.get(names[i].decode(), 0.0) + float(ms[i])
+    counters = None if cnt[4] < 0 else {"redone": int(cnt[1]), "recomputed": int(cnt[2]), "candidates": int(cnt[3]), "queries": int(cnt[4])}
+    return out, counters
 
 
 def rank_rows_workspace_bytes(q, n):

@@ -79,6 +79,24 @@ class CosineEmbeddingLoss(object):
         return loss_i
 
 
+class SquaredDistanceLoss(object):
+    """The fused form of ``transform_inputs`` + ``squared_distance`` (the `--loss mse` training loss, learn_image_embeddings.py:48-50,
+    160-163; utils.py:34-36): ``loss(labels[B] int64, features[B, D]) -> [B]``, one HIP launch forward and one backward.  With
+    gathered embeddings as ``y_true`` (the reference's convention) it is ``squared_distance`` itself."""
+
+    name = 'squared_distance'
+
+    def __init__(self, embedding):
+        self.embedding = embedding
+
+    def __call__(self, y_true, y_pred):
+        if not _is_labels(y_true):
+            return squared_distance(y_true, y_pred)
+        if y_pred.is_cuda and y_pred.dim() == 2 and y_pred.dtype in (torch.float32, torch.bfloat16):
+            return sehip.squared_distance_loss(y_pred, y_true, self.embedding)
+        return squared_distance(self.embedding[y_true], y_pred)
+
+
 def l2norm(x):
     """L2-normalises a tensor along the last axis (utils.py:125-127), HIP kernel + autograd."""
     return sehip.l2norm(x)

@@ -271,6 +271,58 @@ def test_hip_nn_accuracy_vs_reference_lines(sehip, path, k):
         assert np.array_equal(via_rows, got), name
 
 
+@pytest.mark.parametrize("path", LOSS_REF)
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_sqdist_loss_kernels_vs_reference_lines_and_fp64_gradient(sehip, path, dtype):
+    """se_sqdist_loss_fwd / bwd (the `--loss mse` training loss and its mean_distance metric, utils.py:34-41 on transform_inputs'
+    gather): values against the reference's own lines (tests/golden/loss_ref_*: float32 = its precision, float64), gradient against
+    the closed form 2 w (x - E[y]) in float64 and against torch autograd through the three-op mirror; per-sample and scalar weights,
+    f32 and bf16 features, strided rows; the Keras-style wrapper on labels and on gathered embeddings."""
+    import utils as host_utils
+    g = np.load(path)
+    E = _ref_embedding(path)
+    x, y = g["x"], g["labels"]
+    Ed, yd = dev(E.astype(np.float32)), dev(y)
+    if dtype == "bf16":
+        xd = dev(x).to(torch.bfloat16)
+        x64 = xd.float().cpu().numpy().astype(np.float64)
+        want = ((x64 - E[y]) ** 2).sum(-1)
+        tol = 1e-5 * max(1.0, want.max())
+    else:
+        xd = dev(x)
+        x64 = x.astype(np.float64)
+        want = g["squared_distance_64"]
+        tol = 1e-5 * max(1.0, want.max())
+    loss_i, dist_i, mean = sehip.sqdist_loss_forward(xd, yd, Ed, want_dist=True)
+    assert np.abs(loss_i.cpu().numpy() - want).max() <= tol
+    assert np.abs(dist_i.cpu().numpy() - np.sqrt(want)).max() <= 1e-5 * max(1.0, np.sqrt(want).max())
+    assert abs(float(mean) - want.mean()) <= tol
+    if dtype == "f32":
+        assert np.abs(loss_i.cpu().numpy() - g["squared_distance_32"]).max() <= LOSS_TOL * max(1.0, want.max())
+        assert np.abs(dist_i.cpu().numpy() - g["mean_distance_32"]).max() <= LOSS_TOL * max(1.0, np.sqrt(want).max())
+    # backward: scalar weight and per-sample weights
+    w = np.random.default_rng(3).random(len(y)).astype(np.float32)
+    dx = sehip.sqdist_loss_backward(xd, yd, Ed, grad_scale=1.0 / len(y), out_dtype=torch.float32).cpu().numpy()
+    assert np.abs(dx - 2.0 / len(y) * (x64 - E[y])).max() <= 1e-6 * max(1.0, np.abs(x64).max())
+    dxw = sehip.sqdist_loss_backward(xd, yd, Ed, grad_loss_i=dev(w), out_dtype=torch.float32).cpu().numpy()
+    assert np.abs(dxw - 2.0 * w[:, None] * (x64 - E[y])).max() <= 1e-6 * max(1.0, np.abs(x64).max())
+    # autograd: the fused op == the three-op mirror (torch autograd), Keras-style wrapper on labels / gathered embeddings
+    xa = xd.float().clone().requires_grad_(True)
+    xb = xd.float().clone().requires_grad_(True)
+    la = host_utils.SquaredDistanceLoss(Ed)(yd, xa)
+    lb = host_utils.squared_distance(Ed[yd], xb)
+    assert float((la - lb).abs().max()) <= tol
+    (la * dev(w)).sum().backward()
+    (lb * dev(w)).sum().backward()
+    assert float((xa.grad - xb.grad).abs().max()) <= 1e-5 * max(1.0, float(xb.grad.abs().max()))
+    assert float((host_utils.SquaredDistanceLoss(Ed)(Ed[yd], xa.detach()) - lb.detach()).abs().max()) == 0.0
+    # strided feature rows (a [B, D] view of a wider matrix)
+    wide = torch.zeros((len(y), x.shape[1] + 3), dtype=xd.dtype, device="cuda")
+    wide[:, 1:1 + x.shape[1]] = xd
+    ls, _, _ = sehip.sqdist_loss_forward(wide[:, 1:1 + x.shape[1]], yd, Ed)
+    assert float((ls - loss_i).abs().max()) <= tol
+
+
 @pytest.mark.parametrize("B,D,C", [(1, 1, 1), (5, 7, 3), (128, 100, 100), (70, 200, 333), (33, 1000, 1000)])
 @pytest.mark.parametrize("by_label", [True, False])
 def test_devise_ranking_loss_fwd_bwd(sehip, B, D, C, by_label):

@@ -35,7 +35,7 @@ def gauss(n, d, seed=0):
 
 # ---------------------------------------------------------------- row norms (NumPy pairwise order)
 
-@pytest.mark.parametrize("d", [1, 5, 7, 8, 9, 63, 64, 100, 127, 128, 129, 200, 255, 256, 257, 555, 1000, 2048, 2500])
+@pytest.mark.parametrize("d", [1, 5, 7, 8, 9, 15, 16, 17, 63, 64, 100, 127, 128, 129, 136, 143, 200, 247, 248, 249, 250, 255, 256, 257, 555, 1000, 2048, 2500])
 def test_row_sqnorm_and_normalize_bit_exact(sehip, d):
     """D < 256: one lane per row; 256 <= D <= 4096: one wave per row (leaves of NumPy's pairwise tree dealt to 8-lane groups)."""
     x = gauss(131, d, seed=d)
@@ -695,6 +695,38 @@ def test_golden_rankings_from_the_imported_reference(sehip, path):
             a = rk[r] if pos is None else np.array([pos[int(v)] for v in rk[r]])
             b = ref[r] if pos is None else np.array([pos[int(v)] for v in ref[r]])
             assert np.array_equal(pdh[r][a], pdh[r][b]), "row %d differs outside a tie group" % r
+
+
+@pytest.mark.parametrize("branch", ["cos", "euc"])
+def test_larger_golden_rankings_from_the_imported_reference(sehip, branch):
+    """Round 5: the reference-ranking gate beyond 256 rows -- 4,096 clustered items with 64 exact duplicate rows, D = 100, both
+    branches (tests/golden/bigretrieval_cluster.npz: the imported reference's rankings of 128 query rows).  Gate 1: distances and
+    EVERY row's ranking equal the canonical oracle; gate 2: the sampled rows equal the reference except inside exact-tie groups."""
+    g = np.load(os.path.join(ROOT_DIR, "tests", "golden", "bigretrieval_cluster.npz"))
+    feats, rows = g["features"].astype(np.float32), g["rows"]
+    x = dev(feats.copy())
+    if branch == "cos":
+        sehip.normalize_rows_(x)
+        pd = sehip.pairwise_dist(x, None, metric=ro.METRIC_COSINE)
+    else:
+        pd = sehip.pairwise_dist(x, None, metric=ro.METRIC_EUCLID)
+    rk = sehip.rank_rows(pd).cpu().numpy().astype(np.int64)
+    pdh = pd.cpu().numpy()
+    cpd, crk = ro.canon_retrieval(feats, branch == "cos")
+    assert np.array_equal(pdh, cpd)
+    assert np.array_equal(rk, crk.astype(np.int64))
+    ref = g["ref_ranking_rows_" + branch].astype(np.int64)
+    differing = 0
+    for i, r in enumerate(rows):
+        if not np.array_equal(rk[r], ref[i]):
+            assert np.array_equal(pdh[r][rk[r]], pdh[r][ref[i]]), "row %d differs outside a tie group" % r
+            differing += 1
+    assert differing > 0     # the duplicates do force exact ties
+    # the fused top-k head of the same problem
+    d, i = sehip.retrieve_topk(x, x, 251, metric=ro.METRIC_COSINE if branch == "cos" else ro.METRIC_EUCLID,
+                               sqq=None if branch == "cos" else sehip.row_sqnorm(x), sqg=None if branch == "cos" else sehip.row_sqnorm(x))
+    assert np.array_equal(i.cpu().numpy().astype(np.int64), rk[:, :251])
+    assert np.array_equal(d.cpu().numpy(), np.take_along_axis(pdh, rk[:, :251], axis=1))
 
 
 def test_full_size_properties_50k(sehip):

@@ -41,6 +41,24 @@ def test_canonical_oracle_reproduces_reference_rankings(path):
     assert len(diff_rows) == 0   # Gaussian cosine cases have no exact ties -> identical
 
 
+@pytest.mark.parametrize("branch", ["cos", "euc"])
+def test_oracle_matches_the_larger_reference_fixture(branch):
+    """tests/golden/bigretrieval_cluster.npz (round 5): 4,096 clustered items with 64 exact duplicates, D = 100 -- the rankings of 128
+    query rows as the imported, unmodified reference returned them.  The canonical oracle must equal them except inside exact-tie
+    groups (the reference's argsort is unstable)."""
+    g = np.load(os.path.join(GOLDEN, "bigretrieval_cluster.npz"))
+    feats, rows = g["features"], g["rows"]
+    pd, rk = ro.canon_retrieval(feats, branch == "cos")
+    ref = g["ref_ranking_rows_" + branch].astype(np.int64)
+    ties = 0
+    for i, r in enumerate(rows):
+        mine = rk[r].astype(np.int64)
+        if not np.array_equal(mine, ref[i]):
+            assert np.array_equal(pd[r][mine], pd[r][ref[i]]), "row %d differs outside a tie group" % r
+            ties += 1
+    assert ties > 0          # the duplicate rows do force exact ties: the gate is not vacuous
+
+
 @pytest.mark.parametrize("path", [c for c in CASES if "d555" in c or "d1000" in c])
 def test_single_chain_does_not_reproduce_the_reference_beyond_448(path):
     """The K-block list matters: a single FMA chain over all of D ranks some near-ties differently from the reference."""
