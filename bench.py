@@ -134,6 +134,85 @@ def init_dist(args):
     return rank, world, local
 
 
+def preflight(args, rank, world, local):
+    """Before any large allocation: prove that the communicator this run depends on exists and moves data in the shapes the legs use,
+    and say which rank drives which device.  N > 1 only (the first 8-GPU run of this repository is also its first RCCL run with more
+    than one rank): a 4-byte all-reduce, ONE all_gather_into_tensor of the packed [2, 8, 251] top-k layout of the sharded-gallery leg,
+    the rank -> device -> PCI bus id map gathered through the communicator, and the standalone all-reduce time of the two gradient
+    buffers the training legs exchange (ResNet-110-fc: 7 MB, ResNet-50: 96 MB) as one flat call and as 25 MB buckets.  Any
+    inconsistency ends the run with ONE line naming it.  --dry runs the same sequence on gloo / CPU tensors."""
+    info = {"world": world}
+    if world <= 1:
+        return info
+    dev = "cpu" if args.dry else "cuda"
+    t0 = time.perf_counter()
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    if not args.dry:
+        vis = torch.cuda.device_count()
+        if vis < local_world:
+            raise SystemExit("bench.py preflight: LOCAL_WORLD_SIZE=%d but only %d ROCm device(s) visible to rank %d (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES?)"
+                             % (local_world, vis, rank))
+        if local >= vis:
+            raise SystemExit("bench.py preflight: rank %d has LOCAL_RANK=%d but sees %d device(s)" % (rank, local, vis))
+    one = torch.ones(1, dtype=torch.float32, device=dev)
+    dist.all_reduce(one)
+    if int(one.item()) != world:
+        raise SystemExit("bench.py preflight: 4-byte all-reduce over %d ranks returned %s" % (world, one.item()))
+    packed = torch.full((2, 8, 251), rank, dtype=torch.int32, device=dev)            # the sharded-gallery leg's send block, 8 queries
+    got = torch.empty((world, 2, 8, 251), dtype=torch.int32, device=dev)
+    dist.all_gather_into_tensor(got.view(-1), packed.view(-1))
+    if not bool((got[:, 0, 0, 0].cpu() == torch.arange(world, dtype=torch.int32)).all()):
+        raise SystemExit("bench.py preflight: all_gather_into_tensor of the packed [2, 8, 251] layout returned the blocks out of rank order")
+    # rank -> device -> PCI bus id, through the communicator
+    bus = -1
+    name = "cpu"
+    if not args.dry:
+        p = torch.cuda.get_device_properties(local)
+        name = p.name
+        bus = (int(getattr(p, "pci_domain_id", 0)) << 16) | (int(getattr(p, "pci_bus_id", -1)) << 8) | int(getattr(p, "pci_device_id", 0))
+    me = torch.tensor([rank, local, bus, os.getpid()], dtype=torch.int64, device=dev)
+    seen = torch.empty((world, 4), dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(seen.view(-1), me)
+    rows = seen.cpu().tolist()
+    info["ranks"] = [{"rank": int(r), "local_device": int(d), "pci": ("%04x:%02x:%02x" % (b >> 16, (b >> 8) & 255, b & 255)) if b >= 0 else None, "pid": int(pid)}
+                     for r, d, b, pid in rows]
+    info["device_name"] = name
+    if not args.dry and all(b >= 0 for _, _, b, _ in rows) and len({(b) for _, _, b, _ in rows}) != world:
+        raise SystemExit("bench.py preflight: %d ranks share %d distinct PCI devices -- two ranks drive one GPU (LOCAL_RANK / visible-device mismatch)"
+                         % (world, len({(b) for _, _, b, _ in rows})))
+    # standalone gradient all-reduce of the two training buffers: one flat call vs 25 MB buckets (what engine.BucketedAllReduce issues)
+    sizes = {"resnet110_fc_7MB": 6986752, "resnet50_96MB": 95777792} if not args.dry else {"tiny_64KB": 65536}
+    ar = {}
+    for key, nbytes in sizes.items():
+        buf = torch.zeros(nbytes // 4, dtype=torch.float32, device=dev)
+        bucket = 25 * (1 << 20) // 4
+        res = {}
+        for mode in ("flat", "buckets_25MB"):
+            ts = []
+            for it in range(4):
+                barrier_sync(world, dry=args.dry)
+                t1 = time.perf_counter()
+                if mode == "flat":
+                    dist.all_reduce(buf)
+                else:
+                    works = [dist.all_reduce(buf[o:o + bucket], async_op=True) for o in range(0, buf.numel(), bucket)]
+                    for w in works:
+                        w.wait()
+                barrier_sync(world, dry=args.dry)
+                if it:
+                    ts.append(time.perf_counter() - t1)
+            ms = max_over_ranks(float(np.median(ts)), world, dev) * 1e3
+            res[mode + "_ms"] = ms
+            res[mode + "_busbw_GBps"] = 2.0 * (world - 1) / world * nbytes / 1e6 / ms
+        ar[key] = dict(res, bytes=nbytes)
+        del buf
+    info["grad_allreduce"] = ar
+    info["seconds"] = time.perf_counter() - t0
+    if rank == 0:
+        print("[bench.py preflight] %d ranks, backend %s: %s" % (world, dist.get_backend(), json.dumps(info)), file=sys.stderr, flush=True)
+    return info
+
+
 def barrier_sync(world, dry=False):
     if world > 1:
         dist.barrier()
@@ -738,7 +817,8 @@ def main(argv=None):
     rc = maybe_spawn(args, argv)
     if rc is not None:
         sys.exit(rc)
-    rank, world, _ = init_dist(args)
+    rank, world, local = init_dist(args)
+    pre = preflight(args, rank, world, local)
     if args.dry:
         out = bench_dry(args, rank, world)
     elif args.workload == "train":
@@ -799,6 +879,8 @@ def main(argv=None):
             v = cb["same_node_parity"].get("gpu_vs_host_rows_differing_outside_ties")
             out["roofline"]["same_node_rows_differing_outside_ties"] = v
             cb["gpu_vs_host_rows_differing_outside_ties"] = v
+    if world > 1:
+        out["preflight"] = pre
     try:
         out["rccl"] = comm_identity(world, dry=args.dry)
         mg = multi_gpu_summary(out, world)

@@ -301,6 +301,8 @@ __device__ __forceinline__ uint32_t rr_key(uint32_t u, bool pad, uint32_t pad_ke
     return pad ? pad_key : k;
 }
 
+__device__ __forceinline__ int32_t rr_clamp_i32(int32_t x, int32_t lo, int32_t hi) { return min(max(x, lo), hi); }   // (v_med3_i32)
+
 template <typename T>
 __device__ __forceinline__ void opaque(T &x) { asm volatile("" : "+v"(x)); }   // value barrier: no CSE / hoisting across it
 
@@ -413,6 +415,9 @@ constexpr int RR_HW_BITS = 11;   // digit width of the hardware-ordered variant:
 constexpr int RR_WIDE_WORDS = 2048;   // counter words per wave of the 12-bit pass (4096 packed 16-bit counters)
 #ifndef SE_RR_TWO
 #define SE_RR_TWO 1                   // build parameter: 0 = never take the two-pass path below
+#endif
+#ifndef SE_RR_WO
+#define SE_RR_WO 4                    // build parameter: steps of the int32 write-out loop whose LDS reads are in flight together
 #endif
 #ifndef SE_RR_IMG
 #define SE_RR_IMG 1                   // build parameter: 0 = never take the image path (two passes on a 24-bit image + repair)
@@ -567,6 +572,7 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
     // barriers per row keep the other waves' reads / counter look-ups on the right side of that reuse).
     constexpr bool WIDE = HWORD && ((size_t)RR_THREADS * ITEMS * sizeof(uint16_t) >= (size_t)RR_WAVES * RR_WIDE_WORDS * sizeof(uint32_t));
     constexpr bool IMG = WIDE && VAR == 3;                              // image path (see RR_IMG_*)
+    constexpr bool RAWKEYS = IMG || (WIDE && VAR == 2);                 // the row loop carries RAW keys: each row picks its sort key itself
     static_assert(VAR != 3 || (WIDE && ITEMS <= RR_IMG_MAX_ITEMS && !SEG), "image path: long-row instantiations with room for the tag plane");
     uint32_t *wcnt = reinterpret_cast<uint32_t *>(rr_raw);              // [RR_WAVES][CNT_WORDS]
     uint32_t *wave_tot = reinterpret_cast<uint32_t *>(rr_raw + rr_region0_bytes<ITEMS, HWORD, VAR>());   // [8] (+pad)
@@ -643,7 +649,7 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
         opaque(wpos);
 #pragma unroll
         for (int s = 0; s < ITEMS; s++) RR_LOAD_ONE(drow, wpos, s, n0)
-        if constexpr (!IMG) RR_CANON(n0)   // (image path: the keys stay raw until the row has chosen between the image and the canonical key)
+        if constexpr (!RAWKEYS) RR_CANON(n0)   // (image / window paths: the keys stay raw until the row has chosen between its two-pass key and the canonical key)
     }
     uint32_t pf_sink = 0;
     [[maybe_unused]] int rr_pass = -1;   // profile build: pass index for the per-pass phase times
@@ -712,49 +718,77 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
             RR_T(8)
         }
         if constexpr (WIDE && VAR == 2) {
+            // (round 5: the keys are still RAW float bits here -- the row is canonicalised only if it does not qualify.  For the rows this
+            // path is for -- non-negative distances with a handful of keys below the window -- the order of the raw bits as SIGNED integers
+            // is the canonical order above zero: negative values (the query's own distance can round to -1e-7) are negative integers, i.e.
+            // "below the window" like every other small key, NaN bit patterns exceed +inf's and end up on the top code next to the padding.
+            // 1.5 + 2 + 3 VALU per key instead of the 6 of the canonicalisation + 9: ~7k of a row's ~97k cycles.)
             uint32_t *stat = wave_tot;                                  // [0, 8): per-wave maxima, [8, 16): per-wave counts below the window
             uint2 *outl = reinterpret_cast<uint2 *>(wcnt);              // (key, position) of the keys below the window (the dedicated counters are idle on this path)
-            // (every step below is written for its instruction count: two waves per SIMD execute each of them over 98 keys)
-            // max over the real, non-NaN keys: adding 2^32 - RR_KEY_NAN wraps NaN and padding (RR_KEY_NAN and above) below every real
-            // key's sum (real keys end at +inf's 0xFF800000: no wrap, and their sums are >= the constant itself), so they drop out
-            constexpr uint32_t WRAP = 0u - RR_KEY_NAN;
-            uint32_t mx = 0;
+            const int n_row = row_len(row);
+            // largest key, NaN read as +inf (a window anchored at +inf holds nothing else: the row falls back), negatives as 0
+            int32_t mxi = 0;
 #pragma unroll
-            for (int s = 0; s < ITEMS; s++) mx = max(mx, key[s] + WRAP);
-            mx = mx >= WRAP ? mx - WRAP + 1u : 0u;                       // key + 1 of the largest real key, 0 when the row has none
+            for (int s = 0; s + 1 < ITEMS; s += 2)
+                mxi = max(max(mxi, rr_clamp_i32((int32_t)key[s], 0, 0x7F800000)), rr_clamp_i32((int32_t)key[s + 1], 0, 0x7F800000));
+            if constexpr (ITEMS & 1) mxi = max(mxi, rr_clamp_i32((int32_t)key[ITEMS - 1], 0, 0x7F800000));
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, off, 64));
-            if (lane == 0) stat[wave] = mx;
+            for (int off = 32; off > 0; off >>= 1) mxi = max(mxi, __shfl_xor(mxi, off, 64));
+            if (lane == 0) stat[wave] = (uint32_t)mxi;
             if (tid == 0) stat[2 * RR_WAVES] = 0;                        // cursor of the list
             wg_barrier();
 #pragma unroll
-            for (int w = 0; w < RR_WAVES; w++) mx = max(mx, stat[w]);
-            const uint32_t kmax = mx ? mx - 1u : 0u;
-            // window [lo, kmax]; lo >= 1 (no finite or infinite value has a key below 0x00800000), so lo - 1 exists
-            const uint32_t lo = kmax > RR_TWO_SPAN ? kmax - RR_TWO_SPAN : 1u, lo1 = lo - 1u;
-            uint32_t below_w = 0;                                        // keys of this WAVE below the window: a scalar count
+            for (int w = 0; w < RR_WAVES; w++) mxi = max(mxi, (int32_t)stat[w]);
+            const int32_t kmax = __builtin_amdgcn_readfirstlane(mxi);
+            // window [lo, kmax] in raw-bit space; lo >= 1, so lo - 1 exists.  A key is "below" when (int32) raw < lo.
+            const int32_t lo = kmax > (int32_t)RR_TWO_SPAN ? kmax - (int32_t)RR_TWO_SPAN : 1, lo1 = lo - 1;
+            uint32_t below_l = 0;                                        // this lane's keys below the window (padding slots excluded below)
+            {
+                int wpos = wpos0;
+                opaque(wpos);
 #pragma unroll
-            for (int s = 0; s < ITEMS; s++) below_w += (uint32_t)__popcll(__ballot(key[s] < lo));
+                for (int s = 0; s < ITEMS; s++) below_l += ((int32_t)key[s] < lo) ? 1u : 0u;        // v_cmp + v_addc
+                // padding slots hold a copy of the row's last element: take them out again (only the wave(s) that have any)
+                // (`lo_b`, `lo_c` below: opaque copies -- hipcc otherwise shares the 98 compare masks between the three loops and spills the
+                // SGPR pairs to VGPR lanes, ~600 v_writelane / v_readlane per row)
+                if (wave_s * (ITEMS * WAVE) + ITEMS * WAVE > n_row) {
+                    int32_t lo_b = lo;
+                    opaque(lo_b);
+#pragma unroll
+                    for (int s = 0; s < ITEMS; s++) below_l -= (wpos + s * WAVE >= n_row && (int32_t)key[s] < lo_b) ? 1u : 0u;
+                }
+            }
+            uint32_t below_w = below_l;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) below_w += (uint32_t)__shfl_xor((int)below_w, off, 64);
             if (lane == 0) stat[RR_WAVES + wave] = below_w;
             wg_barrier();
             uint32_t below = 0;
 #pragma unroll
             for (int w = 0; w < RR_WAVES; w++) below += stat[RR_WAVES + w];
-            two = below <= (uint32_t)RR_TWO_OUT;
+            two = kmax > 0 && below <= (uint32_t)RR_TWO_OUT;
             n_out = (int)below;
-            if (two && below_w != 0) {   // wave-uniform and rare: only the waves that hold such keys walk theirs (reads only -- no register is re-defined here)
+            if (two) {
                 int wpos = wpos0;
                 opaque(wpos);
+                if (below_w != 0) {   // wave-uniform and rare: only the waves that hold such keys walk theirs; the list takes CANONICAL keys
+                    int32_t lo_c = lo;
+                    opaque(lo_c);
+#pragma unroll
+                    for (int s = 0; s < ITEMS; s++)
+                        if ((int32_t)key[s] < lo_c && wpos + s * WAVE < n_row)
+                            outl[atomicAdd(&stat[2 * RR_WAVES], 1u)] = make_uint2(rr_key(key[s], false, 0u), (uint32_t)(wpos + s * WAVE));
+                }
+                // key' = clamp(raw - (lo - 1), 0, 0xFFFFFF) << 8: 0 below the window, 1 .. 2^24 - 2 inside it, 0xFFFFFF for NaN (and the padding)
 #pragma unroll
                 for (int s = 0; s < ITEMS; s++)
-                    if (key[s] < lo) outl[atomicAdd(&stat[2 * RR_WAVES], 1u)] = make_uint2(key[s], (uint32_t)(wpos + s * WAVE));
-            }
-            // key' = min(sat(key - (lo - 1)), 0xFFFFFF) << 8: 0 below the window, 1 .. 2^24 - 2 inside it, 0xFFFFFF for NaN / padding.
-            // Branch-free on purpose: a conditional re-definition of the ITEMS key registers makes hipcc copy them through scratch.
+                    key[s] = (uint32_t)rr_clamp_i32(__builtin_elementwise_sub_sat((int32_t)key[s], lo1), 0, 0xFFFFFF) << 8;
+                if (wave_s * (ITEMS * WAVE) + ITEMS * WAVE > n_row) {
 #pragma unroll
-            for (int s = 0; s < ITEMS; s++) {
-                const uint32_t t = min(__builtin_elementwise_sub_sat(key[s], lo1), 0xFFFFFFu) << 8;
-                key[s] = two ? t : key[s];
+                    for (int s = 0; s < ITEMS; s++) key[s] = (wpos + s * WAVE >= n_row) ? 0xFFFFFF00u : key[s];
+                }
+            } else {
+                RR_CANON(n_row)
             }
             // (the first barrier of pass 0 orders these LDS accesses before anything that follows)
         }
@@ -1170,25 +1204,35 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
             }
         } else {
             int32_t *o = (int32_t *)rank + row * ldr;
-            uint2 nv = *reinterpret_cast<const uint2 *>(xbuf + (wt * 4 < N ? wt * 4 : 0));
-            _Pragma("unroll 1") for (int j = wt * 4; j < N; j += RR_THREADS * 4) {
-                const uint2 v = nv;
-                const int jn = j + RR_THREADS * 4;
-                nv = *reinterpret_cast<const uint2 *>(xbuf + (jn < N ? jn : 0));
-                const int e0 = v.x & 0xFFFFu, e1 = v.x >> 16, e2 = v.y & 0xFFFFu, e3 = v.y >> 16;
-                if (vec_ok && j + 3 < N) {
-                    if (SE_RR_NT) __builtin_nontemporal_store((rr_i32x4){e0, e1, e2, e3}, reinterpret_cast<rr_i32x4 *>(o + j));
-                    else *reinterpret_cast<int4 *>(o + j) = make_int4(e0, e1, e2, e3);
-                } else {
-                    o[j] = e0;
-                    if (j + 1 < N) o[j + 1] = e1;
-                    if (j + 2 < N) o[j + 2] = e2;
-                    if (j + 3 < N) o[j + 3] = e3;
+            // RR_WO steps per trip: their LDS reads are in flight together, then the stores (with one step per trip and one read ahead, as the
+            // int64 path does, the loop paid an LDS round trip per 16-byte store: ~12k of a row's ~100k cycles)
+            constexpr int RR_WO = SE_RR_WO;
+            _Pragma("unroll 1") for (int j0 = wt * 4; j0 < N; j0 += RR_THREADS * 4 * RR_WO) {
+                uint2 v[RR_WO];
+#pragma unroll
+                for (int u = 0; u < RR_WO; u++) {
+                    const int j = j0 + u * RR_THREADS * 4;
+                    v[u] = *reinterpret_cast<const uint2 *>(xbuf + (j < N ? j : 0));
+                }
+#pragma unroll
+                for (int u = 0; u < RR_WO; u++) {
+                    const int j = j0 + u * RR_THREADS * 4;
+                    if (j >= N) break;
+                    const int e0 = v[u].x & 0xFFFFu, e1 = v[u].x >> 16, e2 = v[u].y & 0xFFFFu, e3 = v[u].y >> 16;
+                    if (vec_ok && j + 3 < N) {
+                        if (SE_RR_NT) __builtin_nontemporal_store((rr_i32x4){e0, e1, e2, e3}, reinterpret_cast<rr_i32x4 *>(o + j));
+                        else *reinterpret_cast<int4 *>(o + j) = make_int4(e0, e1, e2, e3);
+                    } else {
+                        o[j] = e0;
+                        if (j + 1 < N) o[j + 1] = e1;
+                        if (j + 2 < N) o[j + 2] = e2;
+                        if (j + 3 < N) o[j + 3] = e3;
+                    }
                 }
             }
         }
         RR_T(7)
-        if constexpr (!IMG) RR_CANON(n_next)
+        if constexpr (!RAWKEYS) RR_CANON(n_next)
         if constexpr (PROF) {   // keep the canonicalisation (and with it the wait for the loads) inside the 'load' interval of the phase profile
             _Pragma("unroll") for (int s = 0; s < ITEMS; s++) opaque(key[s]);
         }

@@ -311,7 +311,7 @@ def test_sqdist_loss_kernels_vs_reference_lines_and_fp64_gradient(sehip, path, d
     xb = xd.float().clone().requires_grad_(True)
     la = host_utils.SquaredDistanceLoss(Ed)(yd, xa)
     lb = host_utils.squared_distance(Ed[yd], xb)
-    assert float((la - lb).abs().max()) <= tol
+    assert float((la.detach() - lb.detach()).abs().max()) <= tol
     (la * dev(w)).sum().backward()
     (lb * dev(w)).sum().backward()
     assert float((xa.grad - xb.grad).abs().max()) <= 1e-5 * max(1.0, float(xb.grad.abs().max()))

@@ -330,6 +330,12 @@ def test_bench_dry_run_with_8_ranks_completes_every_leg():
     assert rec["sharded_gallery"] == {"parts": 8, "matches_unsharded": True}
     assert rec["retrieval"]["query_shards"] == 8 and rec["retrieval"]["rows_ranked"] == 64 * 8 and rec["retrieval"]["matches_unsharded"] is True
     assert rec["train"]["ranks"] == 8 and rec["train"]["replicas_identical"] is True and rec["train"]["loss_finite"] is True
+    # the preflight ran first (communicator, 4-byte all-reduce, packed [2, 8, 251] all-gather, rank -> device map, gradient all-reduce
+    # timings flat / bucketed) and its record travels with the line
+    pre = rec["preflight"]
+    assert pre["world"] == 8 and sorted(r["rank"] for r in pre["ranks"]) == list(range(8))
+    assert all(set(v) >= {"flat_ms", "buckets_25MB_ms", "bytes"} for v in pre["grad_allreduce"].values())
+    assert "[bench.py preflight] 8 ranks, backend gloo" in out.stderr
 
 
 def test_bench_refuses_more_gpus_than_visible():
