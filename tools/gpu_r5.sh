@@ -57,6 +57,47 @@ two)
   timeout 300 python tools/fuzz_rank.py --seconds 100 --seed 11 >> $log 2>&1
   timeout 300 python tools/dev_img.py time >> $log 2>&1
   ;;
+evidence)
+  # end-of-round evidence: bench line (both branches), kernel microbenchmarks, rocprofv3 kernel stats of the bench command,
+  # phase profile of the image path.  Output: gpurun_out/r5ev/
+  unset SEHIP_LIB
+  OUT=gpurun_out/r5ev; mkdir -p $OUT; export TMPDIR=/tmp
+  ( timeout 1500 python bench.py --steps 20 --warmup 5 ) > $OUT/bench.json 2> $OUT/bench.err; head -c 300 $OUT/bench.json >> $log; echo >> $log
+  ( timeout 900 python bench.py --steps 20 --warmup 5 --metric euclid --no-train --no-sharded --no-cpu-baseline ) > $OUT/bench_euclid.json 2>> $OUT/bench.err
+  for what in pdist rank fused shard hprec rownorm; do timeout 400 python tools/bench_kernels.py $what 2>&1 | grep -v amdgpu.ids; done > $OUT/kernels.log 2>&1
+  ( SEHIP_LIB=$PWD/semantic-embeddings_amd/sehip/libsehip_tuning.so SE_RANK_PEEL=3 SE_RR_PROFILE=1 timeout 300 python tools/dev_img.py time --reps 1 ) 2>&1 | grep -v amdgpu.ids > $OUT/rank_phase_profile.txt
+  ( SEHIP_LIB=$PWD/semantic-embeddings_amd/sehip/libsehip_tuning.so SE_RANK_PEEL=2 SE_RR_PROFILE=1 timeout 300 python tools/dev_img.py time --reps 1 ) 2>&1 | grep -v amdgpu.ids >> $OUT/rank_phase_profile.txt
+  ( timeout 600 python tools/topk_skew.py; timeout 600 python tools/topk_skew.py --n 160146 --q 20000 --d 1000 --classes 125 ) 2>&1 | grep -v amdgpu.ids > $OUT/topk_skew.txt
+  cd /tmp
+  rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$OUT/prof -o r5 -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-train > $GRAFT_REPO_ROOT/$OUT/prof.log 2>&1
+  cd $GRAFT_REPO_ROOT
+  DB=$(find $OUT/prof -name "*.db" | head -1)
+  [ -n "$DB" ] && python tools/rocprof_summary.py $DB "python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-train" > $OUT/prof_summary.txt
+  rm -rf $OUT/prof
+  cat $OUT/kernels.log >> $log
+  ;;
+pmc)
+  # PMC counter passes, each in its own rocprofv3 run with no tracing flags (MI355X_MICROARCH.md): the headline kernels
+  unset SEHIP_LIB
+  OUT=gpurun_out/r5pmc; mkdir -p $OUT; export TMPDIR=/tmp
+  run_pmc () { # name counters cmd...
+    local name=$1; local ctr=$2; shift 2
+    timeout 600 rocprofv3 --pmc $ctr --output-format csv -d $OUT/pmc_$name -o $name -- "$@" > $OUT/pmc_$name.log 2>&1
+    find $OUT/pmc_$name -name "*counter_collection.csv" | head -1 | xargs -I{} python tools/pmc_summary.py {} > $OUT/pmc_$name.txt 2>&1
+    rm -rf $OUT/pmc_$name
+  }
+  RK="python tools/dev_img.py time --reps 2"
+  PD="python tools/bench_kernels.py pdist --reps 2"
+  run_pmc rk_fetch "FETCH_SIZE GRBM_GUI_ACTIVE" $RK
+  run_pmc rk_write "WRITE_SIZE" $RK
+  run_pmc rk_sq "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS" $RK
+  run_pmc rk_sq2 "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_ADDR_CONFLICT" $RK
+  run_pmc pd_fetch "FETCH_SIZE GRBM_GUI_ACTIVE" $PD
+  run_pmc pd_write "WRITE_SIZE" $PD
+  run_pmc pd_sq "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA" $PD
+  run_pmc pd_sq2 "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU" $PD
+  for f in $OUT/pmc_*.txt; do echo "== $f" >> $log; cat $f >> $log; done
+  ;;
 alltests)
   unset SEHIP_LIB
   timeout 3400 python -m pytest tests -x -q -m gpu >> $log 2>&1
