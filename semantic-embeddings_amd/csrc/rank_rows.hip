@@ -626,8 +626,9 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
             key[s] = rr_key(key[s], pos >= (NN), pk_ + (ITEMS <= 88 ? (uint32_t)((((s >> 3) & 7) << 17) | ((s & 7) << 6)) : 0u)); /* pos >= N: padding */ \
         }                                                                                                             \
     }
-#define RR_PREFETCH_NEXT_ROW() \
-    if (end >= 32 && more) { \
+#define RR_PREFETCH_NEXT_ROW() RR_PREFETCH_NEXT_ROW_IF(end >= 32 && more)
+#define RR_PREFETCH_NEXT_ROW_IF(COND) \
+    if (COND) { \
                 const char *nrow = (const char *)row_ptr(row + gridDim.x); \
                 const uint32_t row_bytes = (uint32_t)row_len(row + gridDim.x) * 4u; \
                 for (uint32_t off = (uint32_t)tid * 128u; off < row_bytes; off += RR_THREADS * 128u) \
@@ -922,7 +923,9 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
             // L2 prefetch of this workgroup's NEXT row (one workgroup per CU: nothing else hides its 200 KB of HBM latency): one dword
             // per 128-byte line, all into one sink register that stays reserved until the loads after the pass loop have been waited for.
             // SE_RR_PF (build-time tuning aid): 0 = no prefetch, 1 = before the destination phase of the last pass (default), 2 = after it, 3 = before its scan
-            if (SE_RR_PF == 1) { RR_PREFETCH_NEXT_ROW() }
+            // (image path: the row's scan + repair follow the last pass -- its prefetch is issued in front of the scan instead: lines brought
+            // in this early were evicted again before the loads, 19 % of the row bytes fetched twice)
+            if (SE_RR_PF == 1 && !(IMG && two)) { RR_PREFETCH_NEXT_ROW() }
             // ---- X: destinations, then the 2-byte exchanges ----
             if (wave_live) {
 #pragma unroll
@@ -1027,6 +1030,7 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
                 // the worklist (bit 8 b + 4 h of a group's word: position 4 h + b); ONE returning add per thread reserves its slots and
                 // only the (rare) set bits are walked -- nothing in this phase waits for LDS inside a divergent loop.  Pairs that reach
                 // into the padding become empty entries.
+                if (SE_RR_PF == 1) { RR_PREFETCH_NEXT_ROW_IF(more) }
                 constexpr int NS = RR_THREADS * ITEMS;
                 constexpr int NG = (NS / 8 + RR_THREADS - 1) / RR_THREADS;   // groups per thread
                 uint32_t S[NG];
@@ -1110,11 +1114,19 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
                             ic[k] = xbuf[p + 2 < (uint32_t)NS ? p + 2 : p]; id[k] = xbuf[p + 3 < (uint32_t)NS ? p + 3 : p];
                         }
 #pragma unroll
+                        for (int k = 0; k < GB; k++) { tm[k] = tagb[im[k]]; t0[k] = tagb[ia[k]]; t2[k] = tagb[ic[k]]; t3[k] = tagb[id[k]]; }
+                        // the gathers (64-byte fabric requests for 4 bytes each: only the ones the run needs -- nothing for a pair whose run
+                        // another thread owns, the third key only for a run of three)
+#pragma unroll
                         for (int k = 0; k < GB; k++) {
-                            tm[k] = tagb[im[k]]; t0[k] = tagb[ia[k]]; t2[k] = tagb[ic[k]]; t3[k] = tagb[id[k]];
-                            ka[k] = __float_as_uint(drow_cur[ia[k]]);
-                            kb[k] = __float_as_uint(drow_cur[ib[k]]);
-                            kc[k] = __float_as_uint(drow_cur[ic[k] < (uint32_t)n_row ? ic[k] : 0u]);   // (position p + 2 may be padding)
+                            const bool mine = pp[k] != 0xFFFFFFFFu && !(pp[k] != 0u && tm[k] == t0[k]);
+                            const bool three = mine && (int)pp[k] + 2 < n_row && t2[k] == t0[k];
+                            ka[k] = kb[k] = kc[k] = 0u;
+                            if (mine) {
+                                ka[k] = __float_as_uint(drow_cur[ia[k]]);
+                                kb[k] = __float_as_uint(drow_cur[ib[k]]);
+                            }
+                            if (three) kc[k] = __float_as_uint(drow_cur[ic[k]]);
                         }
 #pragma unroll
                         for (int k = 0; k < GB; k++) {

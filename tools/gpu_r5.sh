@@ -76,6 +76,17 @@ evidence)
   rm -rf $OUT/prof
   cat $OUT/kernels.log >> $log
   ;;
+pmcrk)
+  # FETCH / WRITE of the ranking kernels only (dev library)
+  OUT=gpurun_out/r5pmc2; mkdir -p $OUT; export TMPDIR=/tmp
+  for c in FETCH_SIZE WRITE_SIZE; do
+    timeout 600 rocprofv3 --pmc $c --output-format csv -d $OUT/p_$c -o x -- python tools/dev_img.py time --reps 2 > $OUT/p_$c.log 2>&1
+    find $OUT/p_$c -name "*counter_collection.csv" | head -1 | xargs -I{} python tools/pmc_summary.py {} 2>&1 | grep -A2 "rank_rows_reg_kernel<98, false, true, [23]" >> $log
+    rm -rf $OUT/p_$c
+  done
+  timeout 300 python tools/dev_img.py time >> $log 2>&1
+  SE_RANK_PEEL=3 timeout 300 python tools/dev_img.py check 2>&1 | tail -1 >> $log
+  ;;
 pmc)
   # PMC counter passes, each in its own rocprofv3 run with no tracing flags (MI355X_MICROARCH.md): the headline kernels
   unset SEHIP_LIB
