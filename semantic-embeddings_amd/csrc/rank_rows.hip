@@ -441,7 +441,10 @@ constexpr int RR_TWO_OUT = 256;
 // 1 / 256 of the other neighbours are false positives, which the repair leaves in place because their keys are in order), the runs
 // go to a worklist, and one thread per run gathers the true keys from the row (L2 / Infinity Cache) and puts the run into canonical
 // order.  A row with a run above RR_IMG_RUN entries, a full worklist, or keys the image cannot take (NaN, infinities, all zero) is
-// sorted again with the three passes by the same workgroup (and the workgroup backs off from the image path for a while).
+// sorted again by the same workgroup one LEVEL further down: level 0 = the tight image (c half as large: the bulk of a cosine row
+// spreads over twice as many most significant digits -- fewer lanes of a wave step on one counter, fewer 2-byte scatters into the
+// same dword -- and half as many keys share an image; the keys beyond its range saturate at the ends: 8.0 -> 7.75 ms), level 1 = the
+// image that holds every key, level 2 = the three passes; the workgroup backs off from a level it had to give up for a while.
 constexpr int RR_IMG_RUN = 8;          // longest run the repair sorts (entries)
 constexpr int RR_IMG_WL = 3072;        // worklist entries (run start | length << 16)
 constexpr int RR_IMG_MAX_ITEMS = 98;   // instantiations above this have no room for tags + worklist next to the exchange buffer
@@ -654,10 +657,14 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
     }
     uint32_t pf_sink = 0;
     [[maybe_unused]] int rr_pass = -1;   // profile build: pass index for the per-pass phase times
-    // image path, all wave-uniform: `img_redo` = this row's image sort was given up, sort it again with the three passes; after a
-    // give-up the workgroup takes the three passes directly for the next 1, 2, 4 ... 32 rows before it tries the image again
-    [[maybe_unused]] bool img_redo = false;
-    [[maybe_unused]] int img_skip = 0, img_penalty = 0;
+    // image path, all wave-uniform.  A row is tried at LEVEL 0 = the tight image (c one power of two smaller: the row's bulk spreads over twice
+    // as many most significant digits and half as many keys share an image; the few keys beyond its range -- a cosine row's own
+    // distance of -1 -- saturate at the ends and are put right by the repair like any other run), given up -> the same row again at
+    // level 1 = the image that holds every key, given up -> level 2 = the three passes.  After a give-up at a level the workgroup
+    // starts its next 1, 2, 4 ... 32 rows one level further down before it tries that level again.
+    [[maybe_unused]] int img_level = 0;                       // level of the row in hand
+    [[maybe_unused]] bool img_again = false;                  // the row in hand is a retry (its level was set by the give-up)
+    [[maybe_unused]] int img_skip0 = 0, img_pen0 = 0, img_skip1 = 0, img_pen1 = 0;   // per level: rows still to skip it, length of its last back-off
     for (int64_t row = blockIdx.x; row < Q;) {
         const bool more = row + gridDim.x < Q;
         [[maybe_unused]] const int n_next = row_len(more ? row + gridDim.x : row);
@@ -671,8 +678,12 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
         [[maybe_unused]] int n_out = 0;
         if constexpr (IMG) {
             const int n_row = row_len(row);
-            bool attempt = !img_redo && img_skip == 0;
-            if (!img_redo && img_skip > 0) img_skip--;
+            if (!img_again) {                                   // a new row: the first level nothing has been given up at lately
+                if (img_skip1 > 0) { img_level = 2; img_skip1--; }
+                else if (img_skip0 > 0) { img_level = 1; img_skip0--; }
+                else img_level = 0;
+            }
+            bool attempt = img_level < 2;
             uint32_t cbits = 0, base = 0;
             if (attempt) {
                 // largest magnitude of the row as an integer maximum (NaN and infinities come out on top and disqualify the row)
@@ -689,7 +700,7 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
                 for (int w = 0; w < RR_WAVES; w++) mb = max(mb, wave_tot[w]);
                 mb = (uint32_t)__builtin_amdgcn_readfirstlane((int)mb);
                 // c = 2^(e + 1) with 2^e * 1.5 >= max |v|: every |v| <= 0.75 c.  Finite, not tiny (2^-100 <= max |v| < 2^126).
-                const uint32_t e = (mb >> 23) + ((mb & 0x7FFFFFu) > 0x400000u ? 1u : 0u);
+                const uint32_t e = (mb >> 23) + ((mb & 0x7FFFFFu) > 0x400000u ? 1u : 0u) - (img_level == 0 ? 1u : 0u);
                 two = mb >= 0x0D800000u && mb < 0x7E800000u;
                 cbits = (e + 1u) << 23;
                 base = e << 23;
@@ -704,7 +715,8 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
 #pragma unroll
                 for (int s = 0; s < ITEMS; s++) {
                     const uint32_t t = __float_as_uint(__uint_as_float(key[s]) + c);
-                    const uint32_t q = __builtin_elementwise_sub_sat(t, base);        // 0 .. 0xE00000
+                    // (signed arithmetic: at the tight level fl(v + c) can be negative or reach 2 c -- both ends saturate, the map stays monotone)
+                    const uint32_t q = (uint32_t)rr_clamp_i32(__builtin_elementwise_sub_sat((int32_t)t, (int32_t)base), 0, 0xFEFFFF);
                     // tag of column (wpos + 64 s) = the low 8 image bits, written IN COLUMN ORDER: consecutive lanes, consecutive bytes
                     asm volatile("ds_write_b8 %0, %1 offset:%2" ::"v"(tb), "v"(q), "n"(s * WAVE) : "memory");
                     key[s] = q << 8;
@@ -1253,12 +1265,14 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
         // (the next row's pass-0 barriers order these reads before its first exchange write)
         if constexpr (IMG) {
             if (img_fail) {
-                img_redo = true;
-                img_penalty = img_penalty ? (img_penalty < 16 ? 2 * img_penalty : 32) : 1;
-                img_skip = img_penalty;
+                // (img_fail implies an image attempt: level 0 or 1)
+                if (img_level == 0) { img_pen0 = img_pen0 ? (img_pen0 < 16 ? 2 * img_pen0 : 32) : 1; img_skip0 = img_pen0; }
+                else { img_pen1 = img_pen1 ? (img_pen1 < 16 ? 2 * img_pen1 : 32) : 1; img_skip1 = img_pen1; }
+                img_level++;
+                img_again = true;
             } else {
-                if (two) img_penalty = 0;
-                img_redo = false;
+                if (two) { if (img_level == 0) img_pen0 = 0; else img_pen1 = 0; }
+                img_again = false;
                 row += gridDim.x;
             }
         } else row += gridDim.x;

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--q", type=int, default=None)
     ap.add_argument("--reps", type=int, default=5)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--rows", default="cosine", choices=["cosine", "uniform"], help="time: -dot of normalised gaussian features, or uniform(-1, 1) keys")
     args = ap.parse_args()
     import torch
     import sehip
@@ -60,6 +61,8 @@ def main():
     x = torch.from_numpy(rng.standard_normal((n, 100)).astype(np.float32)).cuda()
     sehip.normalize_rows_(x)
     pd = sehip.pairwise_dist(x[:q], x, metric=sehip.METRIC_COSINE)
+    if args.rows == "uniform":
+        pd.uniform_(-1.0, 1.0)
     rk = torch.empty((q, n), dtype=torch.int32, device="cuda")
 
     def timeit(fn):
