@@ -416,6 +416,9 @@ constexpr int RR_WIDE_WORDS = 2048;   // counter words per wave of the 12-bit pa
 #ifndef SE_RR_TWO
 #define SE_RR_TWO 1                   // build parameter: 0 = never take the two-pass path below
 #endif
+#ifndef SE_RR_SCAN_DEPTH
+#define SE_RR_SCAN_DEPTH 1            // build parameter: groups of the image path's tag scan whose random reads are in flight ahead of the arithmetic
+#endif
 #ifndef SE_RR_WO
 #define SE_RR_WO 4                    // build parameter: steps of the int32 write-out loop whose LDS reads are in flight together
 #endif
@@ -1058,7 +1061,8 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
                     xg[g] = *reinterpret_cast<const uint4 *>(xbuf + bs);
                     nxg[g] = xbuf[bs + 8 < NS ? bs + 8 : bs];
                 }
-                uint32_t t[2][9];
+                constexpr int TD = SE_RR_SCAN_DEPTH;   // groups whose tag reads are in flight ahead of the arithmetic
+                uint32_t t[TD + 1][9];
                 auto tag_reads = [&](int g, uint32_t (&tt)[9]) {
                     const uint32_t xi[4] = {xg[g].x, xg[g].y, xg[g].z, xg[g].w};
 #pragma unroll
@@ -1068,11 +1072,12 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
                     }
                     tt[8] = tagb[nxg[g]];
                 };
-                tag_reads(0, t[0]);
+#pragma unroll
+                for (int g = 0; g < TD && g < NG; g++) tag_reads(g, t[g % (TD + 1)]);
 #pragma unroll
                 for (int g = 0; g < NG; g++) {
-                    if (g + 1 < NG) tag_reads(g + 1, t[(g + 1) & 1]);
-                    const uint32_t (&tc)[9] = t[g & 1];
+                    if (g + TD < NG) tag_reads(g + TD, t[(g + TD) % (TD + 1)]);
+                    const uint32_t (&tc)[9] = t[g % (TD + 1)];
                     const bool live = (tsc + RR_THREADS * g) * 8 < n_row - 1;
                     const uint32_t A = tc[0] | (tc[1] << 8) | (tc[2] << 16) | (tc[3] << 24), B = tc[4] | (tc[5] << 8) | (tc[6] << 16) | (tc[7] << 24);
                     const uint32_t zA = A ^ __builtin_amdgcn_alignbyte(B, A, 1), zB = B ^ __builtin_amdgcn_alignbyte(tc[8], B, 1);   // byte i: tag(i) ^ tag(i + 1)
