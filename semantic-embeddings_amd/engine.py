@@ -59,8 +59,7 @@ class FlatState(object):
     Every slice starts on a 256-byte boundary (``align`` elements; the padding words stay zero in all four buffers, so the
     whole-buffer update, clip norm and all-reduce see zeros there).  A freshly allocated parameter tensor is 256-byte aligned
     in PyTorch and vendor kernels may assume so; packing 16-64-element bias vectors back to back put them at arbitrary 4-byte
-    offsets -- the one difference between this trainer's captured step and a plain capture of the same network
-    (DESIGN.md section 7.1)."""
+    offsets (round 4 excluded this as the cause of the bf16 replay fault, round 5 found the cause elsewhere: DESIGN.md section 7.1)."""
 
     def __init__(self, model, l2_of=None, align=None):
         params = [p for p in model.parameters() if p.requires_grad]
@@ -277,9 +276,11 @@ class Trainer(object):
         if not X.is_cuda:
             return False
         if self.autocast_dtype is not None and not allow_autocast:
-            # bf16-autocast replays of these backbones return non-finite conv-bias gradients inside this trainer's flat-buffer layout
-            # (root cause not found) and would save nothing (the bf16 ResNet-50 step is GPU-bound in eager mode):
-            # the mode is not offered.
+            # bf16 replays of these backbones return wrong conv-bias gradients -- not because of this trainer (a bare torch.cuda.graph of
+            # the network fails the same way): one aten::convolution_backward on bf16 channels_last tensors (MIOpen's split-K weight
+            # gradient) depends on memory outside the graph's pool when replayed: its result changes with what the allocator recycled in
+            # between (tools/graph_wrw_bf16_repro.py).  The mode is not offered; it would save nothing either
+            # (the bf16 ResNet-50 step is GPU-bound in eager mode, bf16 is slower than fp32 replay for the CIFAR nets).
             print('[engine] HIP-graph replay is offered for fp32 steps only; staying eager', flush=True)
             return False
         ys = y if isinstance(y, (tuple, list)) else (y,)
