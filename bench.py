@@ -857,6 +857,19 @@ def main(argv=None):
             leg("train_bf16", lambda: bench_train(args, rank, world, dtype="bf16", scaling=sc))
             if "error" not in out["train"] and "error" not in out["train_bf16"]:
                 out["train"]["bf16_images_per_sec"] = out["train_bf16"]["value"]
+            if "error" not in out["train"] and sc == "weak":
+                # per-GPU batch sweep beside the stated batch: shows how far configs[1] sits inside the launch-bound regime
+                sweep = {str(args.batch): {"images_per_sec": out["train"]["value"], "ms_per_step": out["train"]["ms_per_step"]}}
+                for bsz in (256, 512):
+                    if bsz == args.batch:
+                        continue
+                    try:
+                        r = bench_train(argparse.Namespace(**dict(vars(args), batch=bsz, steps=min(args.steps, 10), warmup=min(args.warmup, 3))), rank, world, scaling=sc)
+                        sweep[str(bsz)] = {"images_per_sec": r["value"], "ms_per_step": r["ms_per_step"]}
+                    except Exception as e:
+                        sweep[str(bsz)] = {"error": "%s: %s" % (type(e).__name__, e)}
+                    torch.cuda.empty_cache()
+                out["train"]["batch_sweep_per_gpu"] = sweep
             r50 = argparse.Namespace(**dict(vars(args), arch="resnet-50", batch=64))
             leg("train_r50", lambda: bench_train(r50, rank, world, scaling=sc))                            # configs[3]: CUB, 200 classes
             leg("train_r50_ilsvrc", lambda: bench_train(r50, rank, world, classes=1000, scaling=sc))    # configs[4]: C = D = 1000
