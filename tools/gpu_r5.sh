@@ -133,6 +133,14 @@ pdvar)
     timeout 900 python -m pytest tests/test_gpu_retrieval.py -x -q -m gpu -k "pairwise or golden" 2>&1 | tail -3 >> $log
   done
   ;;
+quad)
+  unset SEHIP_LIB
+  timeout 1800 python -m pytest tests/test_gpu_topk.py -x -q -m gpu 2>&1 | tail -3 >> $log
+  timeout 900 python -m pytest tests/test_gpu_retrieval.py tests/test_gpu_dropin.py -x -q -m gpu -k "topk or larger or sharded or retrieve" 2>&1 | tail -3 >> $log
+  timeout 300 python tools/fuzz_topk.py --seconds 90 2>&1 | tail -2 >> $log
+  timeout 600 python tools/bench_kernels.py fused 2>&1 | grep -v amdgpu.ids >> $log
+  SEHIP_LIB=$PWD/semantic-embeddings_amd/sehip/libsehip_tuning.so SE_TOPK_VERBOSE=1 timeout 300 python tools/bench_kernels.py fused --reps 2 2>&1 | grep "refine_kernel profile" | head -3 >> $log
+  ;;
 tests)
   unset SEHIP_LIB
   timeout 3400 python -m pytest tests -x -q -m gpu >> $log 2>&1
@@ -167,6 +175,14 @@ pdvar)
     export SEHIP_LIB=$PWD/semantic-embeddings_amd/sehip/variants/libsehip_$v.so
     timeout 900 python -m pytest tests/test_gpu_retrieval.py -x -q -m gpu -k "pairwise or golden" 2>&1 | tail -3 >> $log
   done
+  ;;
+quad)
+  unset SEHIP_LIB
+  timeout 1800 python -m pytest tests/test_gpu_topk.py -x -q -m gpu 2>&1 | tail -3 >> $log
+  timeout 900 python -m pytest tests/test_gpu_retrieval.py tests/test_gpu_dropin.py -x -q -m gpu -k "topk or larger or sharded or retrieve" 2>&1 | tail -3 >> $log
+  timeout 300 python tools/fuzz_topk.py --seconds 90 2>&1 | tail -2 >> $log
+  timeout 600 python tools/bench_kernels.py fused 2>&1 | grep -v amdgpu.ids >> $log
+  SEHIP_LIB=$PWD/semantic-embeddings_amd/sehip/libsehip_tuning.so SE_TOPK_VERBOSE=1 timeout 300 python tools/bench_kernels.py fused --reps 2 2>&1 | grep "refine_kernel profile" | head -3 >> $log
   ;;
 tests)
   unset SEHIP_LIB
