@@ -109,39 +109,7 @@ pmc)
   run_pmc pd_sq2 "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU" $PD
   for f in $OUT/pmc_*.txt; do echo "== $f" >> $log; cat $f >> $log; done
   ;;
-allrefprof)
-  # phase profile of pf_refine_kernel at the all-pairs size and at the shard size (tuning library)
-  export SEHIP_LIB=$PWD/semantic-embeddings_amd/sehip/libsehip_tuning.so
-  SE_TOPK_VERBOSE=1 timeout 300 python tools/bench_kernels.py fused --reps 3 2>&1 | grep -v amdgpu.ids | sort | uniq -c >> $log
-  SE_TOPK_VERBOSE=1 timeout 300 python tools/bench_kernels.py shard --reps 2 2>&1 | grep -v amdgpu.ids | sort | uniq -c >> $log
-  ;;
-pdprof)
-  export SEHIP_LIB=$PWD/semantic-embeddings_amd/sehip/libsehip_tuning.so
-  SE_PD_PROFILE=1 timeout 300 python tools/bench_kernels.py pdist --reps 2 2>&1 | grep -v amdgpu.ids | sort | uniq -c | sort -rn | head -40 >> $log
-  for a in 1 2 4; do echo "== SE_PD_ABLATE=$a" >> $log; SE_PD_ABLATE=$a timeout 300 python tools/bench_kernels.py pdist --reps 5 2>&1 | grep -v amdgpu.ids >> $log; done
-  ;;
-pdvar)
-  for v in dev pd1 pd2; do
-    export SEHIP_LIB=$PWD/semantic-embeddings_amd/sehip/variants/libsehip_$v.so
-    echo "== variant $v" >> $log
-    timeout 300 python tools/bench_kernels.py pdist --reps 7 2>&1 | grep -v amdgpu.ids >> $log
-    echo "== variant $v, plain stores" >> $log
-    SE_PD_PLAIN_ST=1 timeout 300 python tools/bench_kernels.py pdist --reps 7 2>&1 | grep -v amdgpu.ids | head -3 >> $log
-  done
-  for v in pd1 pd2; do
-    export SEHIP_LIB=$PWD/semantic-embeddings_amd/sehip/variants/libsehip_$v.so
-    timeout 900 python -m pytest tests/test_gpu_retrieval.py -x -q -m gpu -k "pairwise or golden" 2>&1 | tail -3 >> $log
-  done
-  ;;
-quad)
-  unset SEHIP_LIB
-  timeout 1800 python -m pytest tests/test_gpu_topk.py -x -q -m gpu 2>&1 | tail -3 >> $log
-  timeout 900 python -m pytest tests/test_gpu_retrieval.py tests/test_gpu_dropin.py -x -q -m gpu -k "topk or larger or sharded or retrieve" 2>&1 | tail -3 >> $log
-  timeout 300 python tools/fuzz_topk.py --seconds 90 2>&1 | tail -2 >> $log
-  timeout 600 python tools/bench_kernels.py fused 2>&1 | grep -v amdgpu.ids >> $log
-  SEHIP_LIB=$PWD/semantic-embeddings_amd/sehip/libsehip_tuning.so SE_TOPK_VERBOSE=1 timeout 300 python tools/bench_kernels.py fused --reps 2 2>&1 | grep "refine_kernel profile" | head -3 >> $log
-  ;;
-tests)
+alltests)
   unset SEHIP_LIB
   timeout 3400 python -m pytest tests -x -q -m gpu >> $log 2>&1
   ;;
@@ -162,27 +130,6 @@ pdprof)
   export SEHIP_LIB=$PWD/semantic-embeddings_amd/sehip/libsehip_tuning.so
   SE_PD_PROFILE=1 timeout 300 python tools/bench_kernels.py pdist --reps 2 2>&1 | grep -v amdgpu.ids | sort | uniq -c | sort -rn | head -40 >> $log
   for a in 1 2 4; do echo "== SE_PD_ABLATE=$a" >> $log; SE_PD_ABLATE=$a timeout 300 python tools/bench_kernels.py pdist --reps 5 2>&1 | grep -v amdgpu.ids >> $log; done
-  ;;
-pdvar)
-  for v in dev pd1 pd2; do
-    export SEHIP_LIB=$PWD/semantic-embeddings_amd/sehip/variants/libsehip_$v.so
-    echo "== variant $v" >> $log
-    timeout 300 python tools/bench_kernels.py pdist --reps 7 2>&1 | grep -v amdgpu.ids >> $log
-    echo "== variant $v, plain stores" >> $log
-    SE_PD_PLAIN_ST=1 timeout 300 python tools/bench_kernels.py pdist --reps 7 2>&1 | grep -v amdgpu.ids | head -3 >> $log
-  done
-  for v in pd1 pd2; do
-    export SEHIP_LIB=$PWD/semantic-embeddings_amd/sehip/variants/libsehip_$v.so
-    timeout 900 python -m pytest tests/test_gpu_retrieval.py -x -q -m gpu -k "pairwise or golden" 2>&1 | tail -3 >> $log
-  done
-  ;;
-quad)
-  unset SEHIP_LIB
-  timeout 1800 python -m pytest tests/test_gpu_topk.py -x -q -m gpu 2>&1 | tail -3 >> $log
-  timeout 900 python -m pytest tests/test_gpu_retrieval.py tests/test_gpu_dropin.py -x -q -m gpu -k "topk or larger or sharded or retrieve" 2>&1 | tail -3 >> $log
-  timeout 300 python tools/fuzz_topk.py --seconds 90 2>&1 | tail -2 >> $log
-  timeout 600 python tools/bench_kernels.py fused 2>&1 | grep -v amdgpu.ids >> $log
-  SEHIP_LIB=$PWD/semantic-embeddings_amd/sehip/libsehip_tuning.so SE_TOPK_VERBOSE=1 timeout 300 python tools/bench_kernels.py fused --reps 2 2>&1 | grep "refine_kernel profile" | head -3 >> $log
   ;;
 tests)
   unset SEHIP_LIB
