@@ -54,6 +54,10 @@ constexpr int PF_PITCH = PF_ROWB + 16;                      // LDS row pitch in 
 constexpr int PF_PPR = PF_ROWB / 16;                        // 16-byte pieces per row (16)
 constexpr int PF_NLOAD_A = PF_BM * PF_PPR / PF_THREADS;     // pieces per thread: gallery operand (8)
 constexpr int PF_NLOAD_B = PF_BN * PF_PPR / PF_THREADS;     // query operand (4)
+// The filter epilogue's accumulator dump (36 dwords per thread) lives in the gallery operand's LDS plus this gap in front of the query
+// operand: the query panel of a one-chunk job (padded width 128) stays in LDS for all tiles of the job and must not be overwritten.
+constexpr int PF_DUMP_BYTES = SE_PF_BM * 2 * 36 * 4;
+constexpr int PF_GAP = PF_DUMP_BYTES > PF_BM * PF_PITCH ? PF_DUMP_BYTES - PF_BM * PF_PITCH : 0;
 #ifndef SE_PF_WGS
 #define SE_PF_WGS (256 / SE_PF_BM)
 #endif
@@ -318,12 +322,12 @@ __global__ __launch_bounds__(PF_THREADS, PF_WGS_PER_CU) void pf_tile_kernel(
     const unsigned *__restrict__ ctl_a, const unsigned *__restrict__ ctl_b, PfArgs fa)
 {
     extern __shared__ __attribute__((aligned(16))) char pf_smem[];
-    char *sA = pf_smem, *sB = pf_smem + PF_BM * PF_PITCH;
+    char *sA = pf_smem, *sB = pf_smem + PF_BM * PF_PITCH + PF_GAP;
     // side arrays.  Per job (query columns): tCmpCol = the constant the raw accumulator is compared with, tSqCol = |q|^2, jobCnt = slot counters;
     // per tile (gallery rows): tSqRow = |g|^2, tCmpRow = its share of the Euclidean compare constant
-    float *tCmpCol = (float *)(pf_smem + (PF_BM + PF_BN) * PF_PITCH), *tSqCol = tCmpCol + PF_BN, *tSqRow = tSqCol + PF_BN, *tCmpRow = tSqRow + PF_BM;
+    float *tCmpCol = (float *)(pf_smem + (PF_BM + PF_BN) * PF_PITCH + PF_GAP), *tSqCol = tCmpCol + PF_BN, *tSqRow = tSqCol + PF_BN, *tCmpRow = tSqRow + PF_BM;
     unsigned *jobCnt = (unsigned *)(tCmpRow + PF_BM);
-    static_assert(PF_THREADS * 36 * 4 <= (PF_BM + PF_BN) * PF_PITCH, "the epilogue's half dump must fit the operand LDS");
+    static_assert(PF_THREADS * 36 * 4 <= PF_BM * PF_PITCH + PF_GAP, "the epilogue's half dump must fit in front of the query operand");
     static_assert(PF_BN + PF_BM <= PF_THREADS, "side arrays are filled by one thread per entry");
 
     const int xcd = blockIdx.x & 7, slot_in_xcd = blockIdx.x >> 3;
@@ -411,9 +415,12 @@ __global__ __launch_bounds__(PF_THREADS, PF_WGS_PER_CU) void pf_tile_kernel(
 #ifndef SE_PF_SPREAD
 #define SE_PF_SPREAD 0
 #endif
+        // one-chunk jobs (padded width 128, e.g. D = 100): the job's query panel is already in LDS and stays there -- every tile of the
+        // job used to fetch and stage it again (a third of the operand traffic and LDS writes of the 391 tiles of a 50k x 50k job)
+        const bool keep_b = nchunks == 1 && !job_ends;
         if (have_next && !SE_PF_SPREAD) {
             pf_load<PF_NLOAD_A>(ra, A, lda, (int64_t)nx.t * PF_BM, NA, nc * PF_BK);
-            pf_load<PF_NLOAD_B>(rb, B, ldb, (int64_t)nx.tn * PF_BN, NB, nc * PF_BK);
+            if (!keep_b) pf_load<PF_NLOAD_B>(rb, B, ldb, (int64_t)nx.tn * PF_BN, NB, nc * PF_BK);
         }
         PF_T(1)
         // ---- MFMA over the chunk in LDS: 8 steps of k = 16 ----
@@ -599,7 +606,7 @@ __global__ __launch_bounds__(PF_THREADS, PF_WGS_PER_CU) void pf_tile_kernel(
         }
         if (have_next) {
             pf_stage(sA, ra);
-            pf_stage(sB, rb);
+            if (!keep_b) pf_stage(sB, rb);
             if (last_chunk) {
                 if (job_ends) { PF_JOB_SIDE(nx.tn) }
                 PF_TILE_SIDE(nx.t)
@@ -1030,7 +1037,7 @@ static int pf_launch3(const uint16_t *a, int64_t lda, const uint16_t *b, int64_t
         return fail(SE_ERR_UNSUPPORTED, "se_retrieve_topk: %lld pre-filter tiles exceed the 32-bit tile counter", (long long)(tiles_m * tiles_n));
     if (lda * 2 * PF_BM >= ((int64_t)1 << 32) || ldb * 2 * PF_BN >= ((int64_t)1 << 32))
         return fail(SE_ERR_UNSUPPORTED, "se_retrieve_topk: pre-filter row pitch too large for 32-bit tile offsets");
-    const size_t lds = (size_t)(PF_BM + PF_BN) * PF_PITCH + (size_t)(2 * PF_BM + 3 * PF_BN) * sizeof(float);
+    const size_t lds = (size_t)(PF_BM + PF_BN) * PF_PITCH + PF_GAP + (size_t)(2 * PF_BM + 3 * PF_BN) * sizeof(float);
     const int64_t grid = (int64_t)8 * g.gi * g.gj;
     auto kern = pf_tile_kernel<METRIC, EPI>;
     SE_HIP_CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
