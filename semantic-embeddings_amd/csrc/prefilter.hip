@@ -58,6 +58,9 @@ constexpr int PF_NLOAD_B = PF_BN * PF_PPR / PF_THREADS;     // query operand (4)
 // operand: the query panel of a one-chunk job (padded width 128) stays in LDS for all tiles of the job and must not be overwritten.
 constexpr int PF_DUMP_BYTES = SE_PF_BM * 2 * 36 * 4;
 constexpr int PF_GAP = PF_DUMP_BYTES > PF_BM * PF_PITCH ? PF_DUMP_BYTES - PF_BM * PF_PITCH : 0;
+#ifndef SE_PF_CB
+#define SE_PF_CB 3        // candidates per lane, query and tile taken in straight-line code by the filter epilogue (0: the loop only)
+#endif
 #ifndef SE_PF_WGS
 #define SE_PF_WGS (256 / SE_PF_BM)
 #endif
@@ -575,15 +578,33 @@ __global__ __launch_bounds__(PF_THREADS, PF_WGS_PER_CU) void pf_tile_kernel(
                     const int lc = wn * 64 + j * 32 + col;
                     uint2 *lst = fa.lists + ((cur_n0 + lc) * (int64_t)nsub + (cur.p * gj + gj_j)) * fa.cap;
                     const float sbq = METRIC == SE_METRIC_EUCLID ? tSqCol[lc] : 0.f;
-                    while (m) {
-                        const int i = __builtin_clz(m);                                   // value index: mi = i >> 4, r = i & 15
-                        m &= ~(0x80000000u >> i);
+                    auto emit = [&](int i, float a) {
                         const int lr = lr0 + (i >> 4) * 32 + (i & 3) + 8 * ((i >> 2) & 3);
-                        const float a = mine[i];
                         const float v = pf_finish<METRIC>(a * unscale, METRIC == SE_METRIC_EUCLID ? tSqRow[lr] : 0.f, sbq);
                         if (__builtin_expect(slot < (unsigned)fa.cap, 1)) lst[slot] = make_uint2(__float_as_uint(v), (uint32_t)(cur_m0 + lr));
                         else pf_spill_append(fa, cur_n0 + lc, nsub, make_uint2(__float_as_uint(v), (uint32_t)(cur_m0 + lr)));
                         slot++;
+                    };
+                    // the first PF_CB candidates of every lane in straight-line code: their LDS reads are in flight together (a lane holds
+                    // 0.5 candidates per query and tile on average, the busiest lane of a wave ~3: the divergent loop below paid one LDS
+                    // round trip per iteration); the loop takes what is left
+                    constexpr int PF_CB = SE_PF_CB;
+                    int ci[PF_CB > 0 ? PF_CB : 1];
+                    float ca[PF_CB > 0 ? PF_CB : 1];
+#pragma unroll
+                    for (int t = 0; t < PF_CB; t++) {
+                        const int i = m ? __builtin_clz(m) : -1;                          // value index: mi = i >> 4, r = i & 15
+                        m = m ? (m & ~(0x80000000u >> i)) : 0u;
+                        ci[t] = i;
+                        ca[t] = mine[i >= 0 ? i : 0];
+                    }
+#pragma unroll
+                    for (int t = 0; t < PF_CB; t++)
+                        if (ci[t] >= 0) emit(ci[t], ca[t]);
+                    while (m) {
+                        const int i = __builtin_clz(m);
+                        m &= ~(0x80000000u >> i);
+                        emit(i, mine[i]);
                     }
                 }
                 PF_T(6)
