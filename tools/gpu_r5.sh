@@ -1,5 +1,7 @@
 #!/bin/bash
 # round-5 GPU session runner: tools/gpu_r5.sh <stage> ; logs under gpurun_out/r5_<stage>.log
+# stages img / two / pmcrk use the fast-to-build development library (three instantiations of the ranking kernel):
+#   make -C semantic-embeddings_amd/csrc variant NAME=dev VFLAGS=-DSE_RR_DEV
 stage=${1:-img}
 mkdir -p gpurun_out
 export SEHIP_LIB=${SEHIP_LIB:-$PWD/semantic-embeddings_amd/sehip/variants/libsehip_dev.so}
