@@ -244,7 +244,9 @@ __global__ __launch_bounds__(RK_THREADS) void rank_rows_kernel(const float *__re
 #endif
 constexpr int RR_THREADS = SE_RR_THREADS;
 // instantiations (keys per thread) of the 512-thread build; -DSE_RR_DEV: a quick-to-compile subset for kernel work (NOT a product build)
-#ifdef SE_RR_DEV
+#ifdef SE_RR_DEV98
+#define SE_RR_CASES_512 SE_RR_CASE(98)
+#elif defined(SE_RR_DEV)
 #define SE_RR_CASES_512 SE_RR_CASE(8) SE_RR_CASE(72) SE_RR_CASE(98)
 #else
 #define SE_RR_CASES_512 SE_RR_CASE(2) SE_RR_CASE(8) SE_RR_CASE(12) SE_RR_CASE(20) SE_RR_CASE(30) SE_RR_CASE(40) SE_RR_CASE(46) SE_RR_CASE(52) SE_RR_CASE(58) SE_RR_CASE(64) SE_RR_CASE(72) SE_RR_CASE(80) SE_RR_CASE(88) SE_RR_CASE(98) SE_RR_CASE(104)
@@ -400,7 +402,7 @@ struct RRRank {
 // same property has been re-verified on the device at first use (se_rank_rows: probe kernel) and can be
 // switched off with SE_RANK_SAFE=1.  ~5 VALU per key and pass instead of ~41.
 #ifndef SE_RR_NT
-#define SE_RR_NT 0   // 1: nontemporal rank stores (build-time tuning aid)
+#define SE_RR_NT 1   // 1: nontemporal rank stores (round 6: -2 % on the image path once the next row is loaded straight from HBM; neutral elsewhere)
 #endif
 typedef int rr_i32x4 __attribute__((ext_vector_type(4)));
 typedef long long rr_i64x2 __attribute__((ext_vector_type(2)));
@@ -415,6 +417,9 @@ constexpr int RR_HW_BITS = 11;   // digit width of the hardware-ordered variant:
 constexpr int RR_WIDE_WORDS = 2048;   // counter words per wave of the 12-bit pass (4096 packed 16-bit counters)
 #ifndef SE_RR_TWO
 #define SE_RR_TWO 1                   // build parameter: 0 = never take the two-pass path below
+#endif
+#ifndef SE_RR_EARLY
+#define SE_RR_EARLY 1                 // build parameter: image path -- next row's loads issued behind the last pass, waited for before the rank stores
 #endif
 #ifndef SE_RR_SCAN_DEPTH
 #define SE_RR_SCAN_DEPTH 1            // build parameter: groups of the image path's tag scan whose random reads are in flight ahead of the arithmetic
@@ -612,15 +617,25 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
     // the loads first -- and canonicalised after the write-out, which covers most of their latency.  (With the loads issued after
     // the stores, as in the first version, every row first waited for HBM to absorb its 200-400 KB: 29 % of the kernel.)
     uint32_t key[ITEMS], ir[ITEMS];   // ir = (index << 16) | (within-wave rank, then destination)
+    __amdgpu_buffer_rsrc_t ld_rsrc;
+    uint32_t ld_voff = 0;
     uint32_t ring[RR_RING];
+    // One BUFFER load per key: the row is its own buffer resource (base = first distance, extent = its length), the lane's byte offset
+    // is one register per 16 steps (4,096 bytes: what the instruction's immediate offset spans) and positions behind the row's end read
+    // as ZERO by the hardware's range check (the padding is applied in RR_CANON / by the two-pass paths) -- 8 bytes of code per key.
+    // (round 6: the global-load form -- clamped index, 64-bit address arithmetic, 32 bytes of code per key and load site -- put the
+    // 98-key kernels 2-4 KB above the 64 KB instruction cache; an unlucky placement of the code object then cost 4-10 % of the kernel.
+    // The range check covers voffset + immediate only, so nothing goes into the scalar offset.)
 #define RR_LOAD_ONE(DROW, WPOS, S, NN)                                                                               \
     {                                                                                                                 \
-        /* unconditional load (clamped index; the padding is applied in RR_CANON): a branch around a load makes      \
-           hipcc wait for each load before issuing the next */                                                        \
-        const int pos = (WPOS) + (S) * WAVE;                                                                          \
-        uint32_t gi = (uint32_t)(pos < (NN) ? pos : (NN) - 1);   /* unsigned: scalar base + 32-bit lane offset addressing */ \
-        opaque(gi);                                                                                                   \
-        key[S] = __float_as_uint((DROW)[gi]);                                                                         \
+        if ((S) % 16 == 0) {                                                                                          \
+            if ((S) == 0) {                                                                                           \
+                ld_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(DROW), 0, (NN) * 4, 0x00020000);     \
+                ld_voff = (uint32_t)(WPOS) * 4u;                                                                      \
+            } else ld_voff += 4096u;                                                                                  \
+            opaque(ld_voff);                                                                                          \
+        }                                                                                                             \
+        key[S] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(ld_rsrc, (int)ld_voff + ((S) % 16) * 256, 0, 0);      \
     }
 #define RR_CANON(NN)                                                                                                  \
     {                                                                                                                 \
@@ -697,8 +712,10 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
 #pragma unroll
                 for (int off = 32; off > 0; off >>= 1) mb = max(mb, (uint32_t)__shfl_xor((int)mb, off, 64));
                 if (lane == 0) wave_tot[wave] = mb;
-                if (tid == 0) { ictl[0] = 0; ictl[1] = 0; }
                 wg_barrier();
+                // (behind the barrier: every wave has read the previous row's worklist cursor / give-up flag by now; the next use of either
+                // word lies behind the barriers of the passes)
+                if (tid == 0) { ictl[0] = 0; ictl[1] = 0; }
 #pragma unroll
                 for (int w = 0; w < RR_WAVES; w++) mb = max(mb, wave_tot[w]);
                 mb = (uint32_t)__builtin_amdgcn_readfirstlane((int)mb);
@@ -737,17 +754,23 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
             // (round 5: the keys are still RAW float bits here -- the row is canonicalised only if it does not qualify.  For the rows this
             // path is for -- non-negative distances with a handful of keys below the window -- the order of the raw bits as SIGNED integers
             // is the canonical order above zero: negative values (the query's own distance can round to -1e-7) are negative integers, i.e.
-            // "below the window" like every other small key, NaN bit patterns exceed +inf's and end up on the top code next to the padding.
+            // "below the window" like every other small key; a row that holds a NaN of either sign does not qualify (see `umx` below).
             // 1.5 + 2 + 3 VALU per key instead of the 6 of the canonicalisation + 9: ~7k of a row's ~97k cycles.)
             uint32_t *stat = wave_tot;                                  // [0, 8): per-wave maxima, [8, 16): per-wave counts below the window
             uint2 *outl = reinterpret_cast<uint2 *>(wcnt);              // (key, position) of the keys below the window (the dedicated counters are idle on this path)
             const int n_row = row_len(row);
             // largest key, NaN read as +inf (a window anchored at +inf holds nothing else: the row falls back), negatives as 0
             int32_t mxi = 0;
+            uint32_t umx = 0;   // largest raw key as an UNSIGNED integer: above -inf's 0xFF800000 only for a NaN with the sign bit set
 #pragma unroll
-            for (int s = 0; s + 1 < ITEMS; s += 2)
+            for (int s = 0; s + 1 < ITEMS; s += 2) {
                 mxi = max(max(mxi, rr_clamp_i32((int32_t)key[s], 0, 0x7F800000)), rr_clamp_i32((int32_t)key[s + 1], 0, 0x7F800000));
-            if constexpr (ITEMS & 1) mxi = max(mxi, rr_clamp_i32((int32_t)key[ITEMS - 1], 0, 0x7F800000));
+                umx = max(max(umx, key[s]), key[s + 1]);   // v_max3_u32
+            }
+            if constexpr (ITEMS & 1) { mxi = max(mxi, rr_clamp_i32((int32_t)key[ITEMS - 1], 0, 0x7F800000)); umx = max(umx, key[ITEMS - 1]); }
+            // a negative NaN (0xFFC00000: what 0 / 0 gives on x86) is a negative integer: it would count as "below the window" and be ranked
+            // FIRST.  Read it as +inf like the positive ones: the window then holds nothing else and the row takes the canonical three passes.
+            mxi = umx > 0xFF800000u ? 0x7F800000 : mxi;
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) mxi = max(mxi, __shfl_xor(mxi, off, 64));
             if (lane == 0) stat[wave] = (uint32_t)mxi;
@@ -1030,6 +1053,16 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
         }
         // ---- image path: the exchange buffer is sorted by (image, index); put the runs of equal tags into (key, index) order ----
         [[maybe_unused]] bool img_fail = false;
+        if constexpr (IMG && SE_RR_EARLY) {
+            // The NEXT row's loads are issued here, straight from HBM (no L2 prefetch): the key registers are dead behind the last pass, and
+            // the scan + repair (~20k cycles) cover the latency.  They are waited for BEFORE this row's rank stores are issued, so that
+            // nothing has to wait for the stores to drain: the next row's maximum / image phase (VALU only) runs under them.
+            const float *drow = row_ptr(more ? row + gridDim.x : row);
+            int wpos = wpos0;
+            opaque(wpos);
+#pragma unroll
+            for (int s = 0; s < ITEMS; s++) RR_LOAD_ONE(drow, wpos, s, n_next)
+        }
         if constexpr (IMG) {
             if (two) {
                 // (per-row opaque copies: otherwise hipcc hoists every row-invariant mask / offset of this block out of the row loop and
@@ -1045,7 +1078,7 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
                 // the worklist (bit 8 b + 4 h of a group's word: position 4 h + b); ONE returning add per thread reserves its slots and
                 // only the (rare) set bits are walked -- nothing in this phase waits for LDS inside a divergent loop.  Pairs that reach
                 // into the padding become empty entries.
-                if (SE_RR_PF == 1) { RR_PREFETCH_NEXT_ROW_IF(more) }
+                if (SE_RR_PF == 1 && !SE_RR_EARLY) { RR_PREFETCH_NEXT_ROW_IF(more) }
                 constexpr int NS = RR_THREADS * ITEMS;
                 constexpr int NG = (NS / 8 + RR_THREADS - 1) / RR_THREADS;   // groups per thread
                 uint32_t S[NG];
@@ -1193,12 +1226,18 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
         // hipcc copy all ITEMS index registers there, and a separate straight-line instance of the last pass -- measured, DESIGN.md 5.2 --
         // pushes the 98-key build into scratch; the row was prefetched into L2 during the last pass.  They are issued BEFORE the rank
         // stores and waited for after them: the memory pipeline serves them first and the write-out covers most of their latency.)
-        {
+        if (!(IMG && SE_RR_EARLY) || img_fail) {
             const float *drow = row_ptr((IMG && img_fail) ? row : (more ? row + gridDim.x : row));   // (image path given up: the same row again)
             int wpos = wpos0;
             opaque(wpos);   // per-row opaque: otherwise hipcc hoists ITEMS row-invariant clamps out of the row loop and keeps them live
 #pragma unroll
             for (int s = 0; s < ITEMS; s++) RR_LOAD_ONE(drow, wpos, s, n_next)
+        }
+        if constexpr (IMG && SE_RR_EARLY) {
+            // the next row's keys have landed (and the prefetch dwords of a row that took the three passes): nothing is outstanding when the stores start
+#pragma unroll
+            for (int s = 0; s < ITEMS; s++) opaque(key[s]);
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf_sink) : : "memory");
         }
         int wt = tid;
         opaque(wt);   // per-row opaque: the write-out offsets are recomputed here instead of living (spilled) across the whole row loop
@@ -1265,7 +1304,8 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
         if constexpr (PROF) {   // keep the canonicalisation (and with it the wait for the loads) inside the 'load' interval of the phase profile
             _Pragma("unroll") for (int s = 0; s < ITEMS; s++) opaque(key[s]);
         }
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf_sink) : : "memory");   // prefetch dwords landed too: the sink register is free again, nothing is outstanding
+        if constexpr (!(IMG && SE_RR_EARLY))
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf_sink) : : "memory");   // prefetch dwords landed too: the sink register is free again, nothing is outstanding
         RR_T(0)
         // (the next row's pass-0 barriers order these reads before its first exchange write)
         if constexpr (IMG) {

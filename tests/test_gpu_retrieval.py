@@ -190,7 +190,7 @@ def test_rank_rows_two_pass_path(sehip, n):
     wide.  Also exact ties inside the window, keys exactly on the window's lower edge, +inf (window anchored at inf: everything else
     is 'below'), NaN and padding-like all-ones."""
     rng = np.random.default_rng(n)
-    q = 11
+    q = 13
     pd = (200.0 + 25.0 * rng.standard_normal((q, n))).astype(np.float32).clip(120.0, 300.0)
     free = np.setdiff1d(np.arange(n), (np.arange(1024) * n) // 1024)         # columns the detector's 1024-column sample skips
     pd[0, 0] = 0.0                                                           # the query's own distance (sampled: one below per row is allowed)
@@ -205,6 +205,14 @@ def test_rank_rows_two_pass_path(sehip, n):
     pd[7, free[3:9]] = np.nan                                                # NaN keys sort last on either path
     pd[8] = (1e-3 * np.abs(rng.standard_normal(n)) + 1e-6).astype(np.float32)   # positive but 2^30 codes wide: three passes
     pd[9, free[:20]] = -np.abs(rng.standard_normal(20)).astype(np.float32)   # 20 distinct negatives below the window
+    # NaNs with the SIGN BIT set (0xFFC00000 is what 0 / 0 gives on x86, FMA chains propagate it): negative as raw integers, yet they
+    # sort last like every NaN (round-5 advisor finding: the raw-key window test ranked them first)
+    neg_nan = np.array([0xFFC00000, 0xFFFFFFFF, 0xFF800001], dtype=np.uint32).view(np.float32)
+    pd[10, free[40:43]] = neg_nan
+    pd[11, free[5]] = neg_nan[0]
+    pd[11, free[6]] = np.nan
+    pd[11, 0] = 0.0
+    pd[12, free[:300:2]] = neg_nan[0]                                        # 150 of them: more than a few, fewer than the outlier cap
     got = sehip.rank_rows(dev(pd)).cpu().numpy()
     want = ro.canon_rank_rows(pd)
     for r in range(q):

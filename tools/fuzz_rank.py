@@ -49,7 +49,8 @@ def make_rows(rng, q, n):
                 low = (rng.standard_normal(m) * 1e-2).astype(np.float32)
             pd[r, cols] = low
         if rng.random() < 0.2:
-            pd[r, rng.choice(n, size=int(rng.integers(1, 5)), replace=False)] = rng.choice(np.array([np.nan, np.inf], dtype=np.float32))
+            pd[r, rng.choice(n, size=int(rng.integers(1, 5)), replace=False)] = rng.choice(
+                np.concatenate([np.array([np.nan, np.inf], dtype=np.float32), np.array([0xFFC00000, 0xFF800001], dtype=np.uint32).view(np.float32)]))   # NaNs of both signs
         if rng.random() < 0.2:
             pd[r, ::int(rng.integers(2, 9))] = pd[r, 0]
     return np.ascontiguousarray(pd, dtype=np.float32)
