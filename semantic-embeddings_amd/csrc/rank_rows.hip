@@ -418,6 +418,9 @@ constexpr int RR_WIDE_WORDS = 2048;   // counter words per wave of the 12-bit pa
 #ifndef SE_RR_TWO
 #define SE_RR_TWO 1                   // build parameter: 0 = never take the two-pass path below
 #endif
+#ifndef SE_RR_PROF_BARRIER
+#define SE_RR_PROF_BARRIER 0          // profile build: 1 = a barrier in front of every timestamp (phase times include the skew between the waves)
+#endif
 #ifndef SE_RR_EARLY
 #define SE_RR_EARLY 1                 // build parameter: image path -- next row's loads issued behind the last pass, waited for before the rank stores
 #endif
@@ -609,8 +612,11 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
         } else return N;
     };
     // tuning aid (SE_RR_PROFILE=1): shader-clock cycles per phase, summed over every workgroup's wave 0
-    uint64_t t_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_pp[24] = {}, t_last = PROF ? __builtin_amdgcn_s_memtime() : 0;
-#define RR_T(i) if constexpr (PROF) { lds_wait(); wg_barrier(); /* phase times are workgroup-wide: include the skew between the waves */ const uint64_t now = __builtin_amdgcn_s_memtime(); t_acc[i] += now - t_last; if (rr_pass >= 0) t_pp[(i) * 3 + rr_pass] += now - t_last; t_last = now; } else { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
+    // (round 6: twelve 32-bit counters and no barrier of their own in front of the timestamps -- every phase but the rank phase and the
+    // key read-back ends in one anyway.  The round-5 form -- 36 64-bit counters with a run-time index, a barrier per timestamp -- was
+    // 74 KB of code with 208 B of scratch: above the 64 KB instruction cache, it overstated every phase.)
+    uint32_t t_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_last = PROF ? (uint32_t)__builtin_amdgcn_s_memtime() : 0;
+#define RR_T(i) if constexpr (PROF) { if (SE_RR_PROF_BARRIER) { lds_wait(); wg_barrier(); } const uint32_t now = (uint32_t)__builtin_amdgcn_s_memtime(); t_acc[i] += now - t_last; t_last = now; } else { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
 
     // The row loop is software-pipelined over HBM: the NEXT row is prefetched into L2 during the last pass (one dword per 128-byte
     // line), loaded into the key registers right after it -- BEFORE this row's rank stores are issued, so the memory pipeline serves
@@ -674,7 +680,6 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
         if constexpr (!RAWKEYS) RR_CANON(n0)   // (image / window paths: the keys stay raw until the row has chosen between its two-pass key and the canonical key)
     }
     uint32_t pf_sink = 0;
-    [[maybe_unused]] int rr_pass = -1;   // profile build: pass index for the per-pass phase times
     // image path, all wave-uniform.  A row is tried at LEVEL 0 = the tight image (c one power of two smaller: the row's bulk spreads over twice
     // as many most significant digits and half as many keys share an image; the few keys beyond its range -- a cosine row's own
     // distance of -1 -- saturate at the ends and are put right by the repair like any other run), given up -> the same row again at
@@ -841,7 +846,6 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
 #pragma unroll 1
         for (int p = 0; p < NPASS; p++) {
             const int shift = two ? 8 + 12 * p : (WIDE ? p * 10 : p * BITS);
-            rr_pass = p;
             const int end = two ? (p == 1 ? 32 : 20)                        // bits [0, end) are sorted after this pass
                                 : (WIDE ? (p == 2 ? 32 : shift + 10) : ((shift + BITS < 32) ? shift + BITS : 32));
             const bool wide = WIDE && (two || p == 2);                      // 12-bit digit, counters aliased onto the exchange buffer
@@ -1035,7 +1039,6 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
             // (the next pass's barriers order these reads before its first exchange write)
         }
 #undef RR_DST
-        rr_pass = -1;
         if constexpr (WIDE && VAR == 2) {
             if (two && n_out > 1) {   // the keys below the window hold the first n_out places in index order: order them by (key, index)
                 const uint2 *outl = reinterpret_cast<const uint2 *>(wcnt);
@@ -1325,7 +1328,6 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
     if (PROF && tid == 0)
     {
         for (int i = 0; i < 12; i++) atomicAdd(&prof[i], (unsigned long long)t_acc[i]);
-        for (int i = 0; i < 24; i++) atomicAdd(&prof[12 + i], (unsigned long long)t_pp[i]);
     }
 #undef RR_T
 }
@@ -1447,8 +1449,7 @@ static int launch_rank_reg_variant(const float *pdist, int64_t ldp, int64_t q, i
         if (tot > 0) {
             fprintf(stderr, "[se_rank_rows profile] ITEMS=%d hw=%d peel=%d grid=%lld:", ITEMS, (int)HW, VAR, (long long)grid);
             for (int i = 0; i < 11; i++) fprintf(stderr, " %s %.1f%%", names[i], 100.0 * (double)h[i] / tot);
-            fprintf(stderr, "  (%.0f cycles per row)\n[se_rank_rows profile] cycles per row by phase and pass:", tot / (double)q);
-            for (int i = 1; i < 7; i++) fprintf(stderr, " %s %.0f/%.0f/%.0f", names[i], (double)h[12 + 3 * i] / (double)q, (double)h[13 + 3 * i] / (double)q, (double)h[14 + 3 * i] / (double)q);
+            fprintf(stderr, "  (%.0f cycles per row; wave 0 of every workgroup, timestamps behind the phases' own barriers)", tot / (double)q);
             fprintf(stderr, "\n");
         }
     }

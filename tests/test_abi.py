@@ -133,3 +133,25 @@ def test_every_work_group_barrier_drains_the_lds_queue_first():
         if name.endswith(".hip"):
             src = re.sub(r"//.*", "", open(os.path.join(csrc, name)).read())
             assert not re.search(r"__syncthreads\s*\(\s*\)|__builtin_amdgcn_s_barrier", src), name
+
+
+def test_ranking_kernels_fit_the_instruction_cache():
+    """Round 6: the 98-key instantiations of the register-resident ranking kernel were 66.8 / 68.6 KB of code against a 64 KB
+    instruction cache; whether the per-row loop thrashed it depended on where the code object placed the kernel (identical code:
+    7.2 or 8.0 ms, profiles/r06_b_rank_icache.txt).  The hardware-ordered instantiations the benchmark shapes take (up to 98 keys
+    per thread, every variant) must stay below 63 KB in the SHIPPED library."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import isa_barrier_audit
+    import sehip
+    sizes = isa_barrier_audit.kernel_code_bytes(sehip.LIB_PATH)
+    rank = {k: v for k, v in sizes.items() if "rank_rows_reg_kernel" in k}
+    assert len(rank) >= 40, len(rank)
+    seen = 0
+    for name, size in rank.items():
+        m = re.search(r"rank_rows_reg_kernelILi(\d+)ELb0ELb1ELi(\d)ELb0", name)      # <ITEMS, PROF = false, HWORD = true, VAR, SEG = false>
+        if m and int(m.group(1)) <= 98:
+            seen += 1
+            assert size < 63 * 1024, (name, size)
+    assert seen >= 30, seen
+

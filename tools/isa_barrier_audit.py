@@ -32,6 +32,21 @@ def code_objects(path):
     return out
 
 
+def kernel_code_bytes(path):
+    """{demangled-or-mangled kernel name: code bytes} of every function symbol in the gfx950 code objects of `path` (round 6: the
+    per-row loop of the ranking kernels must stay inside the 64 KB instruction cache, profiles/r06_b_rank_icache.txt)."""
+    sizes = {}
+    for triple, image in code_objects(path):
+        with tempfile.NamedTemporaryFile(suffix=".co") as f:
+            f.write(image); f.flush()
+            text = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "-sW", f.name], check=True, capture_output=True, text=True).stdout
+        for ln in text.split("\n"):
+            fld = ln.split()
+            if len(fld) >= 8 and fld[3] == "FUNC" and fld[2].isdigit():
+                sizes[fld[7]] = max(sizes.get(fld[7], 0), int(fld[2]))
+    return sizes
+
+
 def audit(path):
     """-> (kernels, barriers, bare) with bare = [(kernel, address, reason)].
 
