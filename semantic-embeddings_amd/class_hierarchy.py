@@ -318,20 +318,26 @@ class ClassHierarchy(object):
         pos = {c: i for i, c in enumerate(class_list)}
         cls_h = np.array([pos[c] for c in lab], dtype=np.int32)
         wup_t, lcs_t = self.similarity_tables(class_list)
-        # best-possible cumulative similarity per query class: descending-sorted similarities of the whole gallery
+        # best-possible cumulative similarity per query class: descending-sorted similarities of the whole gallery.  The C x N float64
+        # curves are built ON THE DEVICE (round 6: 180 host cumsums of 50,000 entries + 80 MB of host-to-device copies were 25 of the 56 ms
+        # of a 50,000-item evaluation): per class the C similarity values in descending order, each repeated by its class count,
+        # then one float64 prefix sum per row.
         counts = np.bincount(cls_h, minlength=len(class_list))
-        best_w = np.empty((len(class_list), n))
-        best_l = np.empty((len(class_list), n))
-        for c in range(len(class_list)):
-            for table, best in ((wup_t, best_w), (lcs_t, best_l)):
-                vals = table[c]
-                order = np.argsort(-vals, kind='stable')
-                best[c] = np.cumsum(np.repeat(vals[order], counts[order]))
+        dev = kernels.get('device') or torch.device('cuda', torch.cuda.current_device())
+
+        def best_curves(table):
+            table = np.asarray(table, dtype=np.float64)
+            order = np.argsort(-table, axis=1, kind='stable')
+            vals = torch.from_numpy(np.take_along_axis(table, order, axis=1)).to(dev)
+            reps = torch.from_numpy(counts[order].astype(np.int64)).to(dev)
+            flat = torch.repeat_interleave(vals.reshape(-1), reps.reshape(-1), output_size=len(class_list) * n)
+            return flat.view(len(class_list), n).cumsum(dim=1)
+
+        best_w, best_l = best_curves(wup_t), best_curves(lcs_t)
 
         import torch.distributed as dist
         world = dist.get_world_size(group) if (distributed and dist.is_initialized()) else 1
         rank = dist.get_rank(group) if world > 1 else 0
-        dev = kernels.get('device') or torch.device('cuda', torch.cuda.current_device())
         if torch.is_tensor(features):    # features straight from the network (learn_image_embeddings feature extraction): stay on the device
             feats = features.detach().to(device=dev, dtype=torch.float32).contiguous().clone()
         else:
@@ -355,8 +361,7 @@ class ClassHierarchy(object):
             # ---- top-L lists are enough for every requested metric: fused distance + top-L (the N x N matrix is never written),
             #      over this rank's shard of the gallery when there are several ranks ----
             L = min(n, max(ks + [ahp_clip or 0]) + 1)
-            best_w, best_l = best_w[:, :L + 1], best_l[:, :L + 1]
-            args_d = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (wup_t, lcs_t, best_w, best_l)]
+            args_d = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (wup_t, lcs_t)] + [best_w[:, :L + 1].contiguous(), best_l[:, :L + 1].contiguous()]
             g0, g1 = shard_bounds(n, world)[rank]
             if 'local_topk' not in kernels:
                 import sehip
@@ -374,7 +379,7 @@ class ClassHierarchy(object):
                                                              qidx_d[q0:q1].contiguous(), *args_d, ks_d, ahp_len=ahp_len, want_ap=False,
                                                              **curves(args_d)))
         else:
-            args_d = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (wup_t, lcs_t, best_w, best_l)]
+            args_d = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (wup_t, lcs_t)] + [best_w, best_l]
             extra = curves(args_d)      # once per gallery, shared by every tile
             for r0, tile in kernels['ranking_tiles'](feats, normalize, tile_rows=tile_rows, queries=(q0, q1), kblocks=kblocks):
                 rows = tile.shape[0]

@@ -97,20 +97,56 @@ def _resolve_kblocks(kblocks, d, warn=True):
     return kblocks if len(kblocks) > 1 else None
 
 
-def ranking_tiles(features, normalize=False, tile_rows=None, idx64=False, queries=None, kblocks=None, whole_if_fits=False,
+_tile_cache = {}   # device index -> {'pd': flat uint8 tensor, 'rk': flat uint8 tensor}: grow-only distance / rank buffers of ranking_tiles
+
+
+def release_tile_cache(device=None):
+    """Drop the cached distance / rank buffers of ``ranking_tiles`` (one device, default: all).  They are grow-only and live for the
+    process: 2 x 10 GB after a 50,000-item all-pairs evaluation."""
+    if device is None:
+        _tile_cache.clear()
+    else:
+        import torch
+        dev = torch.device(device)
+        _tile_cache.pop(dev.index if dev.index is not None else torch.cuda.current_device(), None)
+
+
+def _cached_rows(kind, rows, n, dtype, device):
+    """``[rows, n]`` view (row pitch a multiple of 16 bytes, like ``sehip.empty_rows``) of the device's grow-only cached buffer
+    ``kind``: a second evaluation in the same process -- the CLI loops over its --feat files -- pays no 10 GB allocation."""
+    import torch
+    esz = torch.empty((), dtype=dtype).element_size()
+    per16 = 16 // esz
+    pitch = (n + per16 - 1) // per16 * per16
+    need = rows * pitch * esz
+    key = device.index if device.index is not None else torch.cuda.current_device()
+    slot = _tile_cache.setdefault(key, {})
+    buf = slot.get(kind)
+    if buf is None or buf.numel() < need:
+        slot.pop(kind, None)
+        buf = None                        # free the old buffer before the larger one is allocated
+        buf = torch.empty((max(need, 16),), dtype=torch.uint8, device=device)
+        slot[kind] = buf
+    mat = buf[:need].view(dtype).view(rows, pitch)
+    return mat if pitch == n else mat[:, :n]
+
+
+def ranking_tiles(features, normalize=False, tile_rows=None, idx64=False, queries=None, kblocks=None, whole_if_fits=True,
                   prenormalized=False):
     """Generator over ``(first_row, rank_tile)`` with ``rank_tile`` an int32 (int64 if ``idx64``)
     DEVICE tensor ``[rows, N]``: the canonical ranking of queries ``first_row .. first_row+rows``.
+    **A tile is valid until the next one is drawn**: distances and ranks live in grow-only per-device buffers that every tile and
+    every later call reuses (``release_tile_cache`` frees them).
 
     ``features`` must already be a float32 device tensor ``[N, D]``; it is normalised in place when
     ``normalize`` is set (like the reference mutates its input, evaluate_retrieval.py:58).
     (``prenormalized``: the caller already did that -- normalising twice would change bits.)
     ``queries`` optionally restricts the query rows to ``range(*queries)``; ``kblocks`` (None | 'openblas' | list) makes
     the FMA chain restart per K block like the host BLAS the reference ran on (see ``host_blas_kblocks``).
-    ``whole_if_fits``: rank all queries as ONE tile when distances + ranks (8 N^2 bytes) fit into a third of the free device
-    memory -- all-pairs then takes the symmetric distance kernel (3.4 instead of 5.4 ms at 50k x 50k).  Off by default: a one-shot
-    evaluation pays more for the two fresh 10 GB allocations (0.24 s measured) than the kernels save; callers that reuse their
-    buffers (bench.py) call the kernels directly."""
+    ``whole_if_fits`` (default since round 6): rank all queries as ONE tile when distances + ranks (8 N^2 bytes) fit into a third of
+    the device memory that is free or already held by the tile cache -- all-pairs then takes the symmetric distance kernel
+    (3.2 instead of 5.4 ms at 50k x 50k), i.e. the kernels bench.py times.  The first call on a device pays for the two
+    allocations once (0.24 s for 2 x 10 GB); with the cache later evaluations do not."""
     import torch
     import sehip
 
@@ -129,14 +165,23 @@ def ranking_tiles(features, normalize=False, tile_rows=None, idx64=False, querie
             # distances + ranks of all queries, plus what the ranking will ask of the (grow-only) workspace cache on top of what that
             # cache already holds -- up to ~3 GB for rows above 53,248 columns
             extra_ws = max(0, sehip.rank_rows_workspace_bytes(q1 - q0, n) - sehip.workspace_bytes(features.device))
-            if 8 * n * (q1 - q0) + extra_ws <= torch.cuda.mem_get_info(features.device)[0] // 3:
+            key = features.device.index if features.device.index is not None else torch.cuda.current_device()
+            held = sum(int(b.numel()) for b in _tile_cache.get(key, {}).values())
+            need = (4 + (8 if idx64 else 4)) * n * (q1 - q0)
+            if need + extra_ws <= (torch.cuda.mem_get_info(features.device)[0] + held) // 3:
                 tile_rows = max(tile_rows, q1 - q0)
-    pd = sehip.empty_rows(min(tile_rows, max(q1 - q0, 1)), n, torch.float32, features.device)   # row pitch: a multiple of 16 bytes
+    rows_max = min(tile_rows, max(q1 - q0, 1))
+    if features.is_cuda:
+        pd = _cached_rows('pd', rows_max, n, torch.float32, features.device)
+        rk = _cached_rows('rk', rows_max, n, torch.int64 if idx64 else torch.int32, features.device)
+    else:   # (CPU stand-ins of the tests never get here: the kernels need a device)
+        pd = sehip.empty_rows(rows_max, n, torch.float32, features.device)
+        rk = None
     for r0 in range(q0, q1, tile_rows):
         rows = min(tile_rows, q1 - r0)
         sehip.pairwise_dist(features[r0:r0 + rows], features, metric=metric,
                             sqa=None if sq is None else sq[r0:r0 + rows], sqb=sq, kblocks=kblocks, out=pd[:rows])
-        yield r0, sehip.rank_rows(pd[:rows], idx64=idx64)
+        yield r0, sehip.rank_rows(pd[:rows], idx64=idx64, out=None if rk is None else rk[:rows])
 
 
 def pairwise_retrieval(features, normalize=False, return_generator=True, kblocks=None):

@@ -8,6 +8,24 @@ export SEHIP_LIB=${SEHIP_LIB:-$PWD/semantic-embeddings_amd/sehip/variants/libseh
 log=gpurun_out/r6_$stage.log
 : > $log
 case $stage in
+pdab)
+  # A/B of distance-kernel variants: tools/gpu_r6.sh pdab name...   ("prod" = the product library)
+  shift
+  for v in "$@"; do
+    echo "== $v" >> $log
+    if [ $v = prod ]; then unset SEHIP_LIB; else export SEHIP_LIB=$PWD/semantic-embeddings_amd/sehip/variants/libsehip_$v.so; fi
+    timeout 600 python tools/bench_kernels.py pdist --reps 7 2>&1 | grep -v amdgpu.ids >> $log
+    timeout 900 python -m pytest tests/test_gpu_retrieval.py -x -q -m gpu -k "pairwise or golden or benchmarked or full_size" 2>&1 | tail -2 >> $log
+  done
+  ;;
+e2e)
+  # end-to-end evaluation (what evaluate_retrieval.py's main does per --feat file), both branches, three calls each
+  unset SEHIP_LIB
+  timeout 600 python tools/eval_e2e.py 2>&1 | grep -v amdgpu.ids >> $log
+  timeout 600 python tools/eval_e2e.py --euclid 2>&1 | grep -v amdgpu.ids >> $log
+  timeout 600 python tools/eval_e2e.py --profile --reps 2 2>&1 | grep -v amdgpu.ids | head -40 >> $log
+  timeout 1200 python -m pytest tests/test_gpu_dropin.py -x -q -m gpu 2>&1 | tail -3 >> $log
+  ;;
 ranktests)
   # product library: ranking tests + fuzz + kernel microbench
   unset SEHIP_LIB
