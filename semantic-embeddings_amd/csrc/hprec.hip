@@ -35,8 +35,11 @@ namespace se {
 
 #ifndef SE_HP_THREADS           // geometry of a chunk: threads x consecutive ranks per thread, and the occupancy the registers are
 #define SE_HP_THREADS 256       // bounded for (waves per SIMD); tools/experiments/README.md has the measured alternatives
-#define SE_HP_ITEMS 16
+#define SE_HP_ITEMS 8          // (round 6: 8 ranks per thread and chunk -- two queries of a class share a pass, their state doubles)
 #define SE_HP_WAVES_PER_SIMD 2
+#endif
+#ifndef SE_HP_PAIR
+#define SE_HP_PAIR 1            // two queries of one class per workgroup pass (0: one, the round-5 kernel)
 #endif
 #ifndef SE_HP_PF
 #define SE_HP_PF 1              // chunks of rank look-ahead
@@ -127,7 +130,7 @@ __global__ __launch_bounds__(HP_THREADS) void hprec_rcp_kernel(const double *__r
 
 // Counting sort of the queries by class (any order inside a class) + the per-XCD cursors of hprec_kernel.
 __global__ __launch_bounds__(HP_ORDER_THREADS) void hprec_order_kernel(const int32_t *__restrict__ qcls, const int32_t *__restrict__ qidx, int64_t Q, int C,
-                                                                       int32_t *__restrict__ ws)
+                                                                       const int32_t *__restrict__ rank, int64_t ldr, int32_t *__restrict__ ws)
 {
     extern __shared__ int hp_hist[];            // [C] class counts -> cursors, then [16] wave totals
     int *s_wt = hp_hist + C;
@@ -150,7 +153,10 @@ __global__ __launch_bounds__(HP_ORDER_THREADS) void hprec_order_kernel(const int
     int4 *ent = reinterpret_cast<int4 *>(ws + HP_WS_HEAD);      // everything a workgroup needs to start a query, in one 16-byte load
     for (int64_t i = tid; i < Q; i += HP_ORDER_THREADS) {
         const int c = qcls[i];
-        ent[atomicAdd(&hp_hist[c], 1)] = make_int4((int)i, c, qidx ? qidx[i] : -1, 0);
+        // flag: 1 = the query is the first entry of its own ranking (normally: its own nearest neighbour), 2 = it is not a gallery item,
+        // 0 = its position has to be looked for -- queries of one class with equal non-zero flags are processed two per pass
+        const int self = qidx ? qidx[i] : -1;
+        ent[atomicAdd(&hp_hist[c], 1)] = make_int4((int)i, c, self, self < 0 ? 2 : (rank[i * ldr] == self ? 1 : 0));
     }
 }
 
@@ -169,14 +175,14 @@ __global__ __launch_bounds__(HP_THREADS, SE_HP_WAVES_PER_SIMD) void hprec_kernel
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char hp_raw[];
     double2 *s_sim = reinterpret_cast<double2 *>(hp_raw);          // [C] (wup, lcs) similarity of the query class to every class
-    double *s_part = reinterpret_cast<double *>(s_sim + C);        // [2][HP_WAVES][3] wave totals of the scans, double-buffered
-    double *s_fin = s_part + 2 * HP_WAVES * 3;                     // [HP_WAVES][3] end-of-query reduction, then [4] trapezoid end points
-    double *s_ends = s_fin + HP_WAVES * 3;
-    int *s_ks = reinterpret_cast<int *>(s_ends + 4);               // [nk] the cut-offs, ascending
+    double *s_part = reinterpret_cast<double *>(s_sim + C);        // [2][2][HP_WAVES][3] wave totals of the scans (two queries), double-buffered
+    double *s_fin = s_part + 2 * 2 * HP_WAVES * 3;                 // [2][HP_WAVES][3] end-of-query reduction, then [2][4] trapezoid end points
+    double *s_ends = s_fin + 2 * HP_WAVES * 3;
+    int *s_ks = reinterpret_cast<int *>(s_ends + 8);               // [nk] the cut-offs, ascending
     int *s_perm = s_ks + nk;                                       // [nk] their slots in the output row
     int *s_qpos = s_perm + nk;
-    int *s_next = s_qpos + 1;
-    unsigned char *s_cls8 = reinterpret_cast<unsigned char *>(s_qpos + 4);   // [gallery] class of every gallery item (CLSW 1 / 2)
+    int *s_next = s_qpos + 1;                                      // [9]: number of queries drawn, then (query, class, own index, flag) x 2
+    unsigned char *s_cls8 = reinterpret_cast<unsigned char *>(s_qpos + 12);   // [gallery] class of every gallery item (CLSW 1 / 2)
     unsigned short *s_cls16 = reinterpret_cast<unsigned short *>(s_cls8);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
@@ -237,243 +243,307 @@ __global__ __launch_bounds__(HP_THREADS, SE_HP_WAVES_PER_SIMD) void hprec_kernel
     const int xcd = blockIdx.x & 7;
     const int64_t seg_len = (Q + 7) / 8;
     int seg = 0, ticket = 0;                                       // thread 0: the segment it draws from and its next draw
-    if (order_ws && tid == 0) ticket = atomicAdd(&order_ws[xcd], 1);
+    if (order_ws && tid == 0) ticket = atomicAdd(&order_ws[xcd], 2);   // (two consecutive entries per draw)
     int64_t q_static = blockIdx.x;
     const int Li = (int)L;                                         // positions are int32 (list_len < 2^31 - 8192 is checked at the entry point)
     // upper bound of the positions a query can need, known before its own position in the list is: the first ranks are requested
     // together with everything else a query starts with (one memory latency instead of four in a row)
     const int lp_bound = (want_ap || ahp_len == 0) ? Li : min(Li, max(kmax, ahp_len > 0 ? (int)ahp_len : 0) + 1);
     for (;;) {
-        int64_t q;
+        // ---- draw: up to TWO queries -- consecutive entries of the class order, i.e. mostly of one class ----
+        int nq_drawn = 1;
+        int64_t qv[2] = {0, 0};
+        int qcv[2] = {0, 0}, flagv[2] = {0, 0};
+        int32_t selfv[2] = {-1, -1};
         if (order_ws) {
-            if (tid == 0) {   // resolve the draw made while the previous query was being processed
-                int got = -1;
+            if (tid == 0) {   // resolve the draw made while the previous queries were being processed
+                int n_got = 0;
                 for (;;) {
                     const int xs = (xcd + seg) & 7;
                     const int64_t lo = xs * seg_len, hi = (lo + seg_len < Q) ? lo + seg_len : Q;
                     if (lo + ticket < hi) {
-                        const int4 e = reinterpret_cast<const int4 *>(order_ws + HP_WS_HEAD)[lo + ticket];
-                        got = e.x; s_next[1] = e.y; s_next[2] = e.z;
+                        const int4 *ent = reinterpret_cast<const int4 *>(order_ws + HP_WS_HEAD);
+                        const int4 e = ent[lo + ticket];
+                        s_next[1] = e.x; s_next[2] = e.y; s_next[3] = e.z; s_next[4] = e.w;
+                        n_got = 1;
+                        if (lo + ticket + 1 < hi) {
+                            const int4 f = ent[lo + ticket + 1];
+                            s_next[5] = f.x; s_next[6] = f.y; s_next[7] = f.z; s_next[8] = f.w;
+                            n_got = 2;
+                        }
                         break;
                     }
                     if (++seg == 8) break;
-                    ticket = atomicAdd(&order_ws[(xcd + seg) & 7], 1);
+                    ticket = atomicAdd(&order_ws[(xcd + seg) & 7], 2);
                 }
-                *s_next = got;
+                s_next[0] = n_got;
             }
             wg_barrier();
-            q = *s_next;
-            if (q < 0) break;
-            if (tid == 0 && seg < 8) ticket = atomicAdd(&order_ws[(xcd + seg) & 7], 1);   // the next draw: in flight during this query
+            nq_drawn = s_next[0];
+            if (nq_drawn == 0) break;
+            if (tid == 0 && seg < 8) ticket = atomicAdd(&order_ws[(xcd + seg) & 7], 2);   // the next draw: in flight during these queries
+#pragma unroll
+            for (int u = 0; u < 2; u++) { qv[u] = s_next[1 + 4 * u]; qcv[u] = s_next[2 + 4 * u]; selfv[u] = s_next[3 + 4 * u]; flagv[u] = s_next[4 + 4 * u]; }
         } else {
-            q = q_static;
-            if (q >= Q) break;
+            if (q_static >= Q) break;
+            qv[0] = q_static; qcv[0] = qcls[q_static]; selfv[0] = qidx ? qidx[q_static] : -1;
             q_static += gridDim.x;
         }
-        const int32_t *rrow = rank + q * ldr;
-        const int qc = order_ws ? s_next[1] : qcls[q];
-        const int32_t self = order_ws ? s_next[2] : (qidx ? qidx[q] : -1);
-        const double2 *rc = rcp + (int64_t)qc * ldc;
-        double *orow = out + q * ldo;
-        // The ranks a thread owns in a chunk are requested HP_PF chunks ahead (HP_PF register sets, refilled right after the barrier of
-        // the chunk that consumed them).
-        int r[HP_PF][HP_ITEMS];
-        auto load_ranks = [&](int (&dst)[HP_ITEMS], int at, int bound) {
-            if (vec_ok && at + HP_ITEMS <= bound) {
+        // One pass over the ranks of NQ queries of ONE class whose own positions in their rankings agree (normally: both are their own
+        // nearest neighbour): the 16 bytes of best curve per rank -- 4x the ranking's own bytes, what the kernel waits for -- are loaded
+        // once and used for both.  Everything per query (ranks, sums, accumulators, end points, output row) is an array over u.
+        auto run = [&](auto nq_c, const int64_t (&qq)[2], const int32_t (&selfq)[2], const int qc, const int qpos_known) {
+            constexpr int NQ = decltype(nq_c)::value;
+            const int32_t *rrow[NQ];
+            double *orow[NQ];
 #pragma unroll
-                for (int v = 0; v < HP_ITEMS / 4; v++) {
-                    const int4 a = *reinterpret_cast<const int4 *>(rrow + at + 4 * v);
-                    dst[4 * v] = a.x; dst[4 * v + 1] = a.y; dst[4 * v + 2] = a.z; dst[4 * v + 3] = a.w;
-                }
-            } else {
+            for (int u = 0; u < NQ; u++) { rrow[u] = rank + qq[u] * ldr; orow[u] = out + qq[u] * ldo; }
+            const double2 *rc = rcp + (int64_t)qc * ldc;
+            // The ranks a thread owns in a chunk are requested HP_PF chunks ahead (HP_PF register sets, refilled right after the barrier of
+            // the chunk that consumed them).
+            int r[NQ][HP_PF][HP_ITEMS];
+            auto load_ranks = [&](int (&dst)[HP_ITEMS], const int32_t *row, int at, int bound) {
+                if (vec_ok && at + HP_ITEMS <= bound) {
 #pragma unroll
-                for (int e = 0; e < HP_ITEMS; e++) dst[e] = (at + e < bound) ? rrow[at + e] : 0;
-            }
-        };
-#pragma unroll
-        for (int u = 0; u < HP_PF; u++) load_ranks(r[u], tid * HP_ITEMS + u * HP_CHUNK, lp_bound);
-        const int32_t first = rrow[0];
-        for (int c = tid; c < C; c += HP_THREADS) s_sim[c] = make_double2(wup[(int64_t)qc * C + c], lcs[(int64_t)qc * C + c]);
-        if (tid == 0) *s_qpos = (self >= 0 && first == self) ? 0 : 0x7FFFFFFF;
-        if (tid < 4) s_ends[tid] = 0.0;
-        wg_barrier();
-        // ---- position of the query in its own ranking (first hit; L if absent): normally it is its own nearest neighbour (rank 0) ----
-        if (self >= 0 && first != self) {   // otherwise chunk by chunk with a uniform early exit
-            for (int64_t b0 = 0; b0 < L; b0 += 4 * HP_THREADS) {
-#pragma unroll
-                for (int e = 0; e < 4; e++) {
-                    const int64_t i = b0 + e * HP_THREADS + tid;
-                    if (i < L && rrow[i] == self) atomicMin(s_qpos, (int)i);
-                }
-                wg_barrier();
-                const int found = *s_qpos;      // read into a register BEFORE the second barrier: a fast wave must not start the next
-                wg_barrier();                // chunk's atomicMin while a slow wave has yet to read the flag (the waves would take
-                if (found != 0x7FFFFFFF) break; // different exits and pair their barriers out of order)
-            }
-        }
-        const int qpos = (*s_qpos == 0x7FFFFFFF) ? Li : *s_qpos;
-        const int eff_len = (qpos < Li) ? Li - 1 : Li;                          // len(wup) after `del wup[qid_ind]`
-        const int alen = (ahp_len > 0) ? (ahp_len < eff_len ? (int)ahp_len : eff_len) : eff_len;   // AHP window (effective ranks)
-        // effective rank j -> original position: j if j < qpos else j + 1.  AHP / AP need positions up to:
-        int need = kmax;
-        if (ahp_len >= 0) need = (alen > need) ? alen : need;
-        if (want_ap) need = eff_len;
-        const int last_pos = (need < Li) ? need + 1 : Li;                       // original positions [0, last_pos) cover `need` effective ranks
-
-        const int64_t half = ldc / 2;
-        // whole-list AHP: its last end point is (all similarities) / best at the last rank that is not the query -- the divisor is
-        // requested here, by the thread that will need it in the finish step
-        double2 t_last = make_double2(0.0, 0.0);
-        if (tid == 0 && ahp_len == 0 && eff_len > 0) {
-            const int i_last = (eff_len - 1 < qpos) ? eff_len - 1 : eff_len;
-            t_last = rc[hp_slot(i_last) + (i_last < qpos ? half : 0)];
-        }
-        HP_T(1)
-        double car_w = 0.0, car_l = 0.0;      // running similarity sums up to the current chunk (the same value in every thread)
-        int car_r = 0;                        // relevant items so far
-        double acc_w = 0.0, acc_l = 0.0, acc_ap = 0.0;                          // this thread's share of sum(cum / best) and of the AP terms
-        int par = 0;
-        const double2 *rct = rc;            // uniform: the chunk's table rows, indexed e * HP_THREADS + tid
-        int base = 0;
-        // 1 / (best - 1) of a thread's positions in a chunk: contiguous across the wave for every e (1 / best for the ranks ahead of
-        // the query: the second half of the class row)
-        auto load_curve = [&](auto behind_c, double2 (&dst)[HP_ITEMS], const double2 *rows, int at) {
-            constexpr bool BEHIND = decltype(behind_c)::value;       // every position is known to lie behind the query
-#pragma unroll
-            for (int e = 0; e < HP_ITEMS; e++) dst[e] = rows[e * HP_THREADS + tid + ((!BEHIND && at + e < qpos) ? half : 0)];
-        };
-        auto step = [&](int (&rr)[HP_ITEMS]) {
-            const int i0 = base + tid * HP_ITEMS;
-            const bool cuts = (nk > 0) && (base <= kmax);               // uniform: a cut-off may fall into this chunk
-            // One chunk, in one of three forms (uniform tests below).  FAST: an interior chunk -- every position is live, behind the
-            // query, inside the AHP window and away from its end points and from the cut-offs: nothing to mask or test per rank.
-            // TAIL: the same except that the list ends inside the chunk (whole-list AHP: its last end point is taken in the finish
-            // step): positions are masked, nothing else.  Otherwise the general form.
-            auto chunk = [&](auto mode_c) {
-                constexpr int MODE = decltype(mode_c)::value;
-                constexpr bool FAST = MODE == 1, TAIL = MODE == 2;
-                double2 t[HP_ITEMS];              // 1 / (best - 1) of these positions: contiguous across the wave for every e
-                load_curve(std::integral_constant<bool, FAST || TAIL>{}, t, rct, i0);
-                double2 sv[HP_ITEMS];             // rank -> class -> similarity pair, summed up inside the thread
-                unsigned rel = 0;                 // bit e: position e is of the query's class
-                double tw = 0.0, tl = 0.0;
-#pragma unroll
-                for (int e = 0; e < HP_ITEMS; e++) {
-                    const int i = i0 + e;
-                    const bool live = FAST || ((i < last_pos) && (TAIL || i != qpos));
-                    int c = 0;
-                    if (CLSW == 1) c = s_cls8[rr[e]];
-                    else if (CLSW == 2) c = s_cls16[rr[e]];
-                    else if (live) c = cls[rr[e]];
-                    double2 v = s_sim[c];
-                    if (!FAST) { v.x = live ? v.x : 0.0; v.y = live ? v.y : 0.0; }
-                    rel |= (live && c == qc) ? (1u << e) : 0u;
-                    tw += v.x; tl += v.y;
-                    sv[e] = make_double2(tw, tl);      // inclusive prefix inside the thread: the walk below adds the thread's base to each,
-                }                                      // 16 independent additions instead of a second dependent chain
-                const int tr = __popc(rel);
-                if (FAST) HP_T(2)
-                // ---- workgroup exclusive scan of the thread totals: DPP inside the wave, wave totals through LDS ----
-                const double iw = wave_incl_scan_f64(tw), il = wave_incl_scan_f64(tl);
-                const int ir = wave_incl_scan_i32(tr);
-                if (FAST) HP_T(3)
-                double *part = s_part + par * (HP_WAVES * 3);
-                if (lane == 63) { part[wave * 3 + 0] = iw; part[wave * 3 + 1] = il; part[wave * 3 + 2] = (double)ir; }
-                wg_barrier();   // the only barrier of a chunk: the other half of s_part is written next time
-                if (FAST) HP_T(4)
-                load_ranks(rr, i0 + HP_PF * HP_CHUNK, last_pos);
-                double cw = car_w + (iw - tw), cl = car_l + (il - tl);     // sums BEFORE this thread's first element
-                int cr = car_r + (ir - tr);
-#pragma unroll
-                for (int w = 0; w < HP_WAVES; w++) {
-                    const double pw = part[w * 3 + 0], pl = part[w * 3 + 1];
-                    const int pr = (int)part[w * 3 + 2];
-                    if (w < wave) { cw += pw; cl += pl; cr += pr; }
-                    car_w += pw; car_l += pl; car_r += pr;
-                }
-                if (FAST) HP_T(5)
-                // ---- walk the 16 positions: cumulative sums, cum / best, trapezoid terms, the cut-offs ----
-                int kat = 0, knext = 0x7FFFFFFF;
-                if (MODE == 0 && cuts && !ks_iota) {   // lower bound of this thread's first effective rank + 1 among the sorted cut-offs
-                    const int k0 = (i0 <= qpos) ? i0 + 1 : i0;
-                    int hi = nk;
-                    while (kat < hi) {
-                        const int mid = (kat + hi) >> 1;
-                        if (s_ks[mid] < k0) kat = mid + 1; else hi = mid;
+                    for (int v = 0; v < HP_ITEMS / 4; v++) {
+                        const int4 a = *reinterpret_cast<const int4 *>(row + at + 4 * v);
+                        dst[4 * v] = a.x; dst[4 * v + 1] = a.y; dst[4 * v + 2] = a.z; dst[4 * v + 3] = a.w;
                     }
-                    if (kat < nk) knext = s_ks[kat];
-                }
-                double odd_w = 0.0, odd_l = 0.0;       // second accumulator pair of the interior path (shorter FMA chains)
+                } else {
 #pragma unroll
-                for (int e = 0; e < HP_ITEMS; e++) {
-                    const int i = i0 + e;
-                    const double cwe = cw + sv[e].x, cle = cl + sv[e].y;      // cumulative similarity up to and including this rank
-                    if (FAST) {
-                        if (e & 1) { odd_w = fma(cwe, t[e].x, odd_w); odd_l = fma(cle, t[e].y, odd_l); }
-                        else { acc_w = fma(cwe, t[e].x, acc_w); acc_l = fma(cle, t[e].y, acc_l); }
-                    } else if (TAIL) {
-                        if (i < last_pos) { acc_w = fma(cwe, t[e].x, acc_w); acc_l = fma(cle, t[e].y, acc_l); }
-                    } else if (i < last_pos && i != qpos) {
-                        const double yw = cwe * t[e].x, yl = cle * t[e].y;
-                        const int j = (i < qpos) ? i : i - 1;                   // effective rank
-                        if (ahp_len >= 0 && j < alen) {
-                            acc_w += yw; acc_l += yl;
-                            if (j == 0) { s_ends[0] = yw; s_ends[1] = yl; }
-                            if (ahp_len > 0 && j == alen - 1) { s_ends[2] = yw; s_ends[3] = yl; }   // whole list: taken in the finish step
-                        }
-                        if (cuts && ks_iota) {
-                            if (j < nk) { orow[j] = yw; orow[nk + j] = yl; }
-                        } else if (cuts && j < kmax) {   // hierarchical precision at k = j + 1, if that is a cut-off: the thread's ranks are
-                            while (knext < j + 1) knext = (++kat < nk) ? s_ks[kat] : 0x7FFFFFFF;   // consecutive, so it merges them with
-                            while (knext == j + 1) {                                            // the sorted cut-offs from its lower bound
-                                orow[s_perm[kat]] = yw; orow[nk + s_perm[kat]] = yl;
-                                knext = (++kat < nk) ? s_ks[kat] : 0x7FFFFFFF;
-                            }
-                        }
-                    }
-                }
-                if (FAST) { acc_w += odd_w; acc_l += odd_l; }
-                if (FAST) HP_T(6)
-                // ---- AP: precision at the relevant ranks (about one in C ranks: a loop over the set bits, not a test per rank) ----
-                if (want_ap) {
-                    for (unsigned m = rel; m; m &= m - 1) {
-                        const int e = __ffs(m) - 1, i = i0 + e;
-                        const int j1 = (i < qpos) ? i + 1 : i;                  // effective rank + 1
-                        acc_ap += (double)(cr + __popc(rel & ((2u << e) - 1u))) * fast_rcp_f64((double)j1);
-                    }
+                    for (int e = 0; e < HP_ITEMS; e++) dst[e] = (at + e < bound) ? row[at + e] : 0;
                 }
             };
-            const bool interior = vec_ok && ahp_len >= 0 && !cuts && base > qpos && base + HP_CHUNK <= last_pos && base + HP_CHUNK - 2 < alen - 1;
-            const bool tail = ahp_len == 0 && !cuts && base > qpos;
-            if (interior) { chunk(std::integral_constant<int, 1>{}); HP_T(7) }
-            else if (tail) { chunk(std::integral_constant<int, 2>{}); HP_T(8) }
-            else { chunk(std::integral_constant<int, 0>{}); HP_T(8) }
-            base += HP_CHUNK; par ^= 1; rct += HP_CHUNK;
-        };
-        while (base < last_pos) {
 #pragma unroll
-            for (int u = 0; u < HP_PF; u++)
-                if (base < last_pos) step(r[u]);
-        }
-        // ---- finish: trapezoid and AP (the end points were left in LDS by whichever thread owned ranks 0 and alen - 1) ----
-        {
-            const double f0 = wave_incl_scan_f64(acc_w), f1 = wave_incl_scan_f64(acc_l), f2 = wave_incl_scan_f64(acc_ap);   // lane 63: the wave's sums
-            if (lane == 63) { s_fin[wave * 3 + 0] = f0; s_fin[wave * 3 + 1] = f1; s_fin[wave * 3 + 2] = f2; }
+            for (int u = 0; u < NQ; u++)
+#pragma unroll
+                for (int p = 0; p < HP_PF; p++) load_ranks(r[u][p], rrow[u], tid * HP_ITEMS + p * HP_CHUNK, lp_bound);
+            const int32_t self = selfq[0];
+            int32_t first = 0;
+            if (NQ == 1 && qpos_known < 0) first = rrow[0][0];
+            for (int c = tid; c < C; c += HP_THREADS) s_sim[c] = make_double2(wup[(int64_t)qc * C + c], lcs[(int64_t)qc * C + c]);
+            if (tid == 0) *s_qpos = (qpos_known >= 0) ? qpos_known : ((self >= 0 && first == self) ? 0 : 0x7FFFFFFF);
+            if (tid < 4 * NQ) s_ends[tid] = 0.0;
             wg_barrier();
-            if (tid == 0) {
-                double g0 = 0.0, g1 = 0.0, g2 = 0.0;
-                for (int w = 0; w < HP_WAVES; w++) { g0 += s_fin[w * 3 + 0]; g1 += s_fin[w * 3 + 1]; g2 += s_fin[w * 3 + 2]; }
-                if (ahp_len == 0 && eff_len > 0) { s_ends[2] = car_w * t_last.x; s_ends[3] = car_l * t_last.y; }   // whole list: y[-1]
-                if (ahp_len >= 0) {
-                    // np.trapz(y, dx) = dx * (sum(y) - (y[0] + y[-1]) / 2), dx = 1 / len(wup) (whole list) or 1 / clip
-                    const double dx = 1.0 / (double)((ahp_len > 0) ? ahp_len : eff_len);
-                    orow[2 * nk] = dx * (g0 - 0.5 * (s_ends[0] + s_ends[2]));
-                    orow[2 * nk + 1] = dx * (g1 - 0.5 * (s_ends[1] + s_ends[3]));
+            // ---- position of the query in its own ranking (first hit; L if absent): normally it is its own nearest neighbour (rank 0) ----
+            if (NQ == 1 && qpos_known < 0 && self >= 0 && first != self) {   // otherwise chunk by chunk with a uniform early exit
+                for (int64_t b0 = 0; b0 < L; b0 += 4 * HP_THREADS) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        const int64_t i = b0 + e * HP_THREADS + tid;
+                        if (i < L && rrow[0][i] == self) atomicMin(s_qpos, (int)i);
+                    }
+                    wg_barrier();
+                    const int found = *s_qpos;      // read into a register BEFORE the second barrier: a fast wave must not start the next
+                    wg_barrier();                // chunk's atomicMin while a slow wave has yet to read the flag (the waves would take
+                    if (found != 0x7FFFFFFF) break; // different exits and pair their barriers out of order)
                 }
-                if (want_ap) orow[2 * nk + 2] = car_r > 0 ? g2 / (double)car_r : 0.0;
+            }
+            const int qpos = (*s_qpos == 0x7FFFFFFF) ? Li : *s_qpos;
+            const int eff_len = (qpos < Li) ? Li - 1 : Li;                          // len(wup) after `del wup[qid_ind]`
+            const int alen = (ahp_len > 0) ? (ahp_len < eff_len ? (int)ahp_len : eff_len) : eff_len;   // AHP window (effective ranks)
+            // effective rank j -> original position: j if j < qpos else j + 1.  AHP / AP need positions up to:
+            int need = kmax;
+            if (ahp_len >= 0) need = (alen > need) ? alen : need;
+            if (want_ap) need = eff_len;
+            const int last_pos = (need < Li) ? need + 1 : Li;                       // original positions [0, last_pos) cover `need` effective ranks
+
+            const int64_t half = ldc / 2;
+            // whole-list AHP: its last end point is (all similarities) / best at the last rank that is not the query -- the divisor is
+            // requested here, by the thread that will need it in the finish step
+            double2 t_last = make_double2(0.0, 0.0);
+            if (tid == 0 && ahp_len == 0 && eff_len > 0) {
+                const int i_last = (eff_len - 1 < qpos) ? eff_len - 1 : eff_len;
+                t_last = rc[hp_slot(i_last) + (i_last < qpos ? half : 0)];
+            }
+            HP_T(1)
+            double car_w[NQ], car_l[NQ];          // running similarity sums up to the current chunk (the same value in every thread)
+            int car_r[NQ];                        // relevant items so far
+            double acc_w[NQ], acc_l[NQ], acc_ap[NQ];                                // this thread's share of sum(cum / best) and of the AP terms
+#pragma unroll
+            for (int u = 0; u < NQ; u++) { car_w[u] = car_l[u] = 0.0; car_r[u] = 0; acc_w[u] = acc_l[u] = acc_ap[u] = 0.0; }
+            int par = 0;
+            const double2 *rct = rc;            // uniform: the chunk's table rows, indexed e * HP_THREADS + tid
+            int base = 0;
+            // 1 / (best - 1) of a thread's positions in a chunk: contiguous across the wave for every e (1 / best for the ranks ahead of
+            // the query: the second half of the class row)
+            auto load_curve = [&](auto behind_c, double2 (&dst)[HP_ITEMS], const double2 *rows, int at) {
+                constexpr bool BEHIND = decltype(behind_c)::value;       // every position is known to lie behind the query
+#pragma unroll
+                for (int e = 0; e < HP_ITEMS; e++) dst[e] = rows[e * HP_THREADS + tid + ((!BEHIND && at + e < qpos) ? half : 0)];
+            };
+            auto step = [&](auto slot_c) {
+                constexpr int SLOT = decltype(slot_c)::value;
+                const int i0 = base + tid * HP_ITEMS;
+                const bool cuts = (nk > 0) && (base <= kmax);               // uniform: a cut-off may fall into this chunk
+                // One chunk, in one of three forms (uniform tests below).  FAST: an interior chunk -- every position is live, behind the
+                // query, inside the AHP window and away from its end points and from the cut-offs: nothing to mask or test per rank.
+                // TAIL: the same except that the list ends inside the chunk (whole-list AHP: its last end point is taken in the finish
+                // step): positions are masked, nothing else.  Otherwise the general form.
+                auto chunk = [&](auto mode_c) {
+                    constexpr int MODE = decltype(mode_c)::value;
+                    constexpr bool FAST = MODE == 1, TAIL = MODE == 2;
+                    double2 t[HP_ITEMS];              // 1 / (best - 1) of these positions: contiguous across the wave for every e -- ONE load for all NQ queries
+                    load_curve(std::integral_constant<bool, FAST || TAIL>{}, t, rct, i0);
+                    double2 sv[NQ][HP_ITEMS];         // rank -> class -> similarity pair, summed up inside the thread
+                    unsigned rel[NQ];                 // bit e: position e is of the query's class
+                    double tw[NQ], tl[NQ];
+                    int tr[NQ];
+#pragma unroll
+                    for (int u = 0; u < NQ; u++) {
+                        rel[u] = 0; tw[u] = 0.0; tl[u] = 0.0;
+#pragma unroll
+                        for (int e = 0; e < HP_ITEMS; e++) {
+                            const int i = i0 + e;
+                            const bool live = FAST || ((i < last_pos) && (TAIL || i != qpos));
+                            int c = 0;
+                            if (CLSW == 1) c = s_cls8[r[u][SLOT][e]];
+                            else if (CLSW == 2) c = s_cls16[r[u][SLOT][e]];
+                            else if (live) c = cls[r[u][SLOT][e]];
+                            double2 v = s_sim[c];
+                            if (!FAST) { v.x = live ? v.x : 0.0; v.y = live ? v.y : 0.0; }
+                            rel[u] |= (live && c == qc) ? (1u << e) : 0u;
+                            tw[u] += v.x; tl[u] += v.y;
+                            sv[u][e] = make_double2(tw[u], tl[u]);   // inclusive prefix inside the thread: the walk below adds the thread's base to each,
+                        }                                            // independent additions instead of a second dependent chain
+                        tr[u] = __popc(rel[u]);
+                    }
+                    if (FAST) HP_T(2)
+                    // ---- workgroup exclusive scan of the thread totals: DPP inside the wave, wave totals through LDS ----
+                    double iw[NQ], il[NQ];
+                    int ir[NQ];
+                    double *part = s_part + par * (2 * HP_WAVES * 3);
+#pragma unroll
+                    for (int u = 0; u < NQ; u++) {
+                        iw[u] = wave_incl_scan_f64(tw[u]); il[u] = wave_incl_scan_f64(tl[u]);
+                        ir[u] = wave_incl_scan_i32(tr[u]);
+                        if (lane == 63) { part[(u * HP_WAVES + wave) * 3 + 0] = iw[u]; part[(u * HP_WAVES + wave) * 3 + 1] = il[u]; part[(u * HP_WAVES + wave) * 3 + 2] = (double)ir[u]; }
+                    }
+                    if (FAST) HP_T(3)
+                    wg_barrier();   // the only barrier of a chunk (of all NQ queries): the other half of s_part is written next time
+                    if (FAST) HP_T(4)
+                    double cw[NQ], cl[NQ];
+                    int cr[NQ];
+#pragma unroll
+                    for (int u = 0; u < NQ; u++) {
+                        load_ranks(r[u][SLOT], rrow[u], i0 + HP_PF * HP_CHUNK, last_pos);
+                        cw[u] = car_w[u] + (iw[u] - tw[u]); cl[u] = car_l[u] + (il[u] - tl[u]);     // sums BEFORE this thread's first element
+                        cr[u] = car_r[u] + (ir[u] - tr[u]);
+#pragma unroll
+                        for (int w = 0; w < HP_WAVES; w++) {
+                            const double pw = part[(u * HP_WAVES + w) * 3 + 0], pl = part[(u * HP_WAVES + w) * 3 + 1];
+                            const int pr = (int)part[(u * HP_WAVES + w) * 3 + 2];
+                            if (w < wave) { cw[u] += pw; cl[u] += pl; cr[u] += pr; }
+                            car_w[u] += pw; car_l[u] += pl; car_r[u] += pr;
+                        }
+                    }
+                    if (FAST) HP_T(5)
+                    // ---- walk the positions: cumulative sums, cum / best, trapezoid terms, the cut-offs ----
+                    int kat0 = 0, knext0 = 0x7FFFFFFF;
+                    if (MODE == 0 && cuts && !ks_iota) {   // lower bound of this thread's first effective rank + 1 among the sorted cut-offs
+                        const int k0 = (i0 <= qpos) ? i0 + 1 : i0;
+                        int hi = nk;
+                        while (kat0 < hi) {
+                            const int mid = (kat0 + hi) >> 1;
+                            if (s_ks[mid] < k0) kat0 = mid + 1; else hi = mid;
+                        }
+                        if (kat0 < nk) knext0 = s_ks[kat0];
+                    }
+#pragma unroll
+                    for (int u = 0; u < NQ; u++) {
+                        int kat = kat0, knext = knext0;
+                        double odd_w = 0.0, odd_l = 0.0;       // second accumulator pair of the interior path (shorter FMA chains)
+#pragma unroll
+                        for (int e = 0; e < HP_ITEMS; e++) {
+                            const int i = i0 + e;
+                            const double cwe = cw[u] + sv[u][e].x, cle = cl[u] + sv[u][e].y;      // cumulative similarity up to and including this rank
+                            if (FAST) {
+                                if (e & 1) { odd_w = fma(cwe, t[e].x, odd_w); odd_l = fma(cle, t[e].y, odd_l); }
+                                else { acc_w[u] = fma(cwe, t[e].x, acc_w[u]); acc_l[u] = fma(cle, t[e].y, acc_l[u]); }
+                            } else if (TAIL) {
+                                if (i < last_pos) { acc_w[u] = fma(cwe, t[e].x, acc_w[u]); acc_l[u] = fma(cle, t[e].y, acc_l[u]); }
+                            } else if (i < last_pos && i != qpos) {
+                                const double yw = cwe * t[e].x, yl = cle * t[e].y;
+                                const int j = (i < qpos) ? i : i - 1;                   // effective rank
+                                if (ahp_len >= 0 && j < alen) {
+                                    acc_w[u] += yw; acc_l[u] += yl;
+                                    if (j == 0) { s_ends[4 * u + 0] = yw; s_ends[4 * u + 1] = yl; }
+                                    if (ahp_len > 0 && j == alen - 1) { s_ends[4 * u + 2] = yw; s_ends[4 * u + 3] = yl; }   // whole list: taken in the finish step
+                                }
+                                if (cuts && ks_iota) {
+                                    if (j < nk) { orow[u][j] = yw; orow[u][nk + j] = yl; }
+                                } else if (cuts && j < kmax) {   // hierarchical precision at k = j + 1, if that is a cut-off: the thread's ranks are
+                                    while (knext < j + 1) knext = (++kat < nk) ? s_ks[kat] : 0x7FFFFFFF;   // consecutive, so it merges them with
+                                    while (knext == j + 1) {                                            // the sorted cut-offs from its lower bound
+                                        orow[u][s_perm[kat]] = yw; orow[u][nk + s_perm[kat]] = yl;
+                                        knext = (++kat < nk) ? s_ks[kat] : 0x7FFFFFFF;
+                                    }
+                                }
+                            }
+                        }
+                        if (FAST) { acc_w[u] += odd_w; acc_l[u] += odd_l; }
+                    }
+                    if (FAST) HP_T(6)
+                    // ---- AP: precision at the relevant ranks (about one in C ranks: a loop over the set bits, not a test per rank) ----
+                    if (want_ap) {
+#pragma unroll
+                        for (int u = 0; u < NQ; u++)
+                            for (unsigned m = rel[u]; m; m &= m - 1) {
+                                const int e = __ffs(m) - 1, i = i0 + e;
+                                const int j1 = (i < qpos) ? i + 1 : i;                  // effective rank + 1
+                                acc_ap[u] += (double)(cr[u] + __popc(rel[u] & ((2u << e) - 1u))) * fast_rcp_f64((double)j1);
+                            }
+                    }
+                };
+                const bool interior = vec_ok && ahp_len >= 0 && !cuts && base > qpos && base + HP_CHUNK <= last_pos && base + HP_CHUNK - 2 < alen - 1;
+                const bool tail = ahp_len == 0 && !cuts && base > qpos;
+                if (interior) { chunk(std::integral_constant<int, 1>{}); HP_T(7) }
+                else if (tail) { chunk(std::integral_constant<int, 2>{}); HP_T(8) }
+                else { chunk(std::integral_constant<int, 0>{}); HP_T(8) }
+                base += HP_CHUNK; par ^= 1; rct += HP_CHUNK;
+            };
+            while (base < last_pos) {
+                static_assert(HP_PF >= 1 && HP_PF <= 2, "rank look-ahead: one or two chunks");
+                if (base < last_pos) step(std::integral_constant<int, 0>{});
+                if (HP_PF > 1 && base < last_pos) step(std::integral_constant<int, HP_PF - 1>{});
+            }
+            // ---- finish: trapezoid and AP (the end points were left in LDS by whichever thread owned ranks 0 and alen - 1) ----
+            {
+#pragma unroll
+                for (int u = 0; u < NQ; u++) {
+                    const double f0 = wave_incl_scan_f64(acc_w[u]), f1 = wave_incl_scan_f64(acc_l[u]), f2 = wave_incl_scan_f64(acc_ap[u]);   // lane 63: the wave's sums
+                    if (lane == 63) { s_fin[(u * HP_WAVES + wave) * 3 + 0] = f0; s_fin[(u * HP_WAVES + wave) * 3 + 1] = f1; s_fin[(u * HP_WAVES + wave) * 3 + 2] = f2; }
+                }
+                wg_barrier();
+                if (tid == 0) {
+#pragma unroll
+                    for (int u = 0; u < NQ; u++) {
+                        double g0 = 0.0, g1 = 0.0, g2 = 0.0;
+                        for (int w = 0; w < HP_WAVES; w++) { g0 += s_fin[(u * HP_WAVES + w) * 3 + 0]; g1 += s_fin[(u * HP_WAVES + w) * 3 + 1]; g2 += s_fin[(u * HP_WAVES + w) * 3 + 2]; }
+                        if (ahp_len == 0 && eff_len > 0) { s_ends[4 * u + 2] = car_w[u] * t_last.x; s_ends[4 * u + 3] = car_l[u] * t_last.y; }   // whole list: y[-1]
+                        if (ahp_len >= 0) {
+                            // np.trapz(y, dx) = dx * (sum(y) - (y[0] + y[-1]) / 2), dx = 1 / len(wup) (whole list) or 1 / clip
+                            const double dx = 1.0 / (double)((ahp_len > 0) ? ahp_len : eff_len);
+                            orow[u][2 * nk] = dx * (g0 - 0.5 * (s_ends[4 * u + 0] + s_ends[4 * u + 2]));
+                            orow[u][2 * nk + 1] = dx * (g1 - 0.5 * (s_ends[4 * u + 1] + s_ends[4 * u + 3]));
+                        }
+                        if (want_ap) orow[u][2 * nk + 2] = car_r[u] > 0 ? g2 / (double)car_r[u] : 0.0;
+                    }
+                }
+            }
+            HP_T(9)
+        };
+        // flags of the order kernel: 1 = the query is the first entry of its own ranking, 2 = it is not in the gallery, 0 = look for it
+        const bool pair = SE_HP_PAIR && order_ws && nq_drawn == 2 && qcv[0] == qcv[1] && flagv[0] == flagv[1] && flagv[0] != 0;
+        if (pair) {
+            run(std::integral_constant<int, 2>{}, qv, selfv, qcv[0], flagv[0] == 1 ? 0 : 0x7FFFFFFF);
+        } else {
+            for (int u = 0; u < nq_drawn; u++) {
+                const int64_t q1[2] = {qv[u], 0};
+                const int32_t s1[2] = {selfv[u], -1};
+                run(std::integral_constant<int, 1>{}, q1, s1, qcv[u], (order_ws && flagv[u] != 0) ? (flagv[u] == 1 ? 0 : 0x7FFFFFFF) : -1);
             }
         }
-        HP_T(9)
     }
 #if SE_HP_PROFILE
     if (tid == 0)
@@ -533,7 +603,7 @@ extern "C" int se_hierarchical_precision(const int32_t *rank, int64_t ldr, int64
         return fail(SE_ERR_INVALID, "se_hierarchical_precision: null pointer");
     if (ldr < list_len || ldo < 2 * nk + 3) return fail(SE_ERR_INVALID, "se_hierarchical_precision: leading dimension too small");
     if (rcp_len < list_len) return fail(SE_ERR_INVALID, "se_hierarchical_precision: the reciprocal curves cover %lld positions, the rankings have %lld", (long long)rcp_len, (long long)list_len);
-    const size_t fixed = (size_t)num_classes * sizeof(double2) + (size_t)(2 * HP_WAVES * 3 + HP_WAVES * 3 + 4) * sizeof(double) + (size_t)(2 * nk + 4) * sizeof(int);
+    const size_t fixed = (size_t)num_classes * sizeof(double2) + (size_t)(2 * 2 * HP_WAVES * 3 + 2 * HP_WAVES * 3 + 8) * sizeof(double) + (size_t)(2 * nk + 12) * sizeof(int);
     const size_t cap = 160 * 1024;
     if (fixed > cap) return fail(SE_ERR_UNSUPPORTED, "se_hierarchical_precision: %d classes exceed the LDS similarity rows", num_classes);
     // the gallery's classes as bytes / shorts in LDS when they fit (two workgroups per CU preferred for the byte table), else gathered
@@ -554,7 +624,7 @@ extern "C" int se_hierarchical_precision(const int32_t *rank, int64_t ldr, int64
     if (ws) {
         SE_HIP_CHECK(hipFuncSetAttribute((const void *)hprec_order_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)order_lds));
         if (reinterpret_cast<uintptr_t>(ws) % 16 != 0) return fail(SE_ERR_INVALID, "se_hierarchical_precision: order_ws must be 16-byte aligned");
-        hipLaunchKernelGGL(hprec_order_kernel, dim3(1), dim3(HP_ORDER_THREADS), order_lds, s, qcls, qidx, q, num_classes, ws);
+        hipLaunchKernelGGL(hprec_order_kernel, dim3(1), dim3(HP_ORDER_THREADS), order_lds, s, qcls, qidx, q, num_classes, rank, ldr, ws);
         SE_LAUNCH_CHECK();
     }
     // persistent workgroups (the class table is loaded once each): as many as are resident at once

@@ -89,7 +89,7 @@ def main():
         counts = np.bincount(cls.cpu().numpy(), minlength=C)
         best = np.stack([np.cumsum(np.repeat(tab[c][np.argsort(-tab[c], kind="stable")], counts[np.argsort(-tab[c], kind="stable")])) for c in range(C)])
         tab_d, best_d = torch.from_numpy(tab).cuda(), torch.from_numpy(best).cuda()
-        qq = min(q, 8192)
+        qq = min(q, 8192) if args.q is None else q          # (--q given: that many queries, e.g. the full 50,000)
         pd = sehip.pairwise_dist(x[:qq], x, metric=sehip.METRIC_COSINE)
         rk = sehip.rank_rows(pd)
         ks = torch.arange(1, 251, dtype=torch.int32, device="cuda")
