@@ -76,6 +76,7 @@ struct PfArgs {
     int64_t sqa_stride;                // Euclidean epilogue: |a|^2 of gallery row r is sqa[r * sqa_stride]
     float *out; int64_t ldo;           // PF_STORE
     unsigned long long *prof;          // tuning build: phase cycle counters (SE_PF_PROFILE=1)
+    int last_steps;                    // k = 16 MFMA steps of a tile's LAST chunk that hold any data (the rest of the padded width is zero: D = 100 -> 7 of 8)
 };
 
 // ---- conversion ---------------------------------------------------------------------------------------------------------------
@@ -427,8 +428,12 @@ __global__ __launch_bounds__(PF_THREADS, PF_WGS_PER_CU) void pf_tile_kernel(
         }
         PF_T(1)
         // ---- MFMA over the chunk in LDS: 8 steps of k = 16 ----
+        // (round 6: the steps behind the last column with data multiply zeros -- C + 0 = C bit for bit, the accumulators are never -0 --
+        // and are skipped: D = 100 padded to 128 runs seven steps, not eight)
+        const int nsteps = last_chunk ? fa.last_steps : PF_BK / 16;
 #pragma unroll
         for (int s = 0; s < PF_BK / 16; s++) {
+            if (s >= nsteps) break;
 #if SE_PF_SPREAD
             // experiment: the next chunk's loads dealt over the MFMA steps instead of one burst in front of them
             if (have_next) {
@@ -1122,6 +1127,10 @@ int pf_pass(int epi, const PfGeom *geom, int metric, const uint16_t *gallery, in
     PfArgs fa;
     fa.gm = pa.gm; fa.gm_ld = pa.gm_ld; fa.thr = pa.thr; fa.rowcnt = pa.rowcnt; fa.lists = pa.lists; fa.cap = pa.cap;
     fa.sqa_stride = pa.sqa_stride; fa.out = pa.out; fa.ldo = pa.ldo; fa.prof = nullptr; fa.spill = pa.spill; fa.spill_lists = pa.spill_lists; fa.spill_cnt = pa.spill_cnt;
+    {
+        const int in_last = pa.d_valid > 0 ? pa.d_valid - (kp / PF_BK - 1) * PF_BK : PF_BK;     // columns with data in the last chunk
+        fa.last_steps = (in_last <= 0 || in_last >= PF_BK) ? PF_BK / 16 : (in_last + 15) / 16;
+    }
     const PfGeom g = geom ? *geom : pf_geometry(n_a, n_q, 1, 0);
     if (g.big) {
         if (epi != PF_FILTER) return fail(SE_ERR_INVALID, "pre-filter pass: the 256 x 256 kernel only filters");

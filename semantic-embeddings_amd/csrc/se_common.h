@@ -131,6 +131,7 @@ struct PfPassArgs {
     int spill; uint2 *spill_lists; unsigned *spill_cnt;   // filter pass: sub-list slots of every query's shared spill region, [queries][spill * cap]; fill counters [queries]
     int64_t sqa_stride;
     float *out; int64_t ldo;           // PF_EPI_STORE (tuning build): d~ matrix [gallery rows, queries]
+    int d_valid;                       // columns that are not zero padding (0: all kp): the 128 x 128 kernel skips the all-zero k = 16 steps of its last chunk
 };
 int pf_padded_dim(int64_t d);
 // fp32 rows -> scaled fp16 rows [n, pf_padded_dim(d)] + per-row norm of the image / of the rounding residual (upper bounds; NaN for

@@ -1517,7 +1517,7 @@ static int retrieve_topk_prefilter(const float *queries, int64_t ldq, const floa
         unsigned *nflag = rowcnt + rows * L.parts;                     // [1] queries handed to the exact kernel; [2..3] statistics (tuning)
         unsigned *spill_cnt = nflag + 4;                               // [rows] entries in every query's spill region
         SE_HIP_CHECK(hipMemsetAsync(rowcnt, 0, (size_t)rows * L.parts * 4 + 16 + (size_t)rows * 4, s));
-        PfPassArgs pa = {gm, p.G, thr, rowcnt, lists, L.cap, L.spill, spill_lists, spill_cnt, p.step, nullptr, 0};
+        PfPassArgs pa = {gm, p.G, thr, rowcnt, lists, L.cap, L.spill, spill_lists, spill_cnt, p.step, nullptr, 0, (int)d};
         int rc = pf_pass(PF_EPI_GROUPMIN, nullptr, metric, gimg, p.step * (int64_t)kp, qi, kp, sqg, sq, p.S, rows, kp, ctl, qc, pa, s);
         if (rc != SE_OK) return rc;
         phase_mark("sample", s);
@@ -1707,7 +1707,7 @@ extern "C" int se_tuning_prefilter_probe(const float *queries, int64_t ldq, cons
     SE_HIP_CHECK(hipMemsetAsync(gm, 0, (size_t)q * 4, s));
     if (const int rc = pf_convert(gallery, ldg, n, d, gimg, gnrm, gres, ctl, s)) return rc;
     if (const int rc = pf_convert(queries, ldq, q, d, qimg, qnrm, qres, ctl + 8, s)) return rc;
-    PfPassArgs pa = {nullptr, 0, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, 1, out_dt, ldo};
+    PfPassArgs pa = {nullptr, 0, nullptr, nullptr, nullptr, 0, 0, nullptr, nullptr, 1, out_dt, ldo, 0};
     if (const int rc = pf_pass(PF_EPI_STORE, nullptr, metric, gimg, kp, qimg, kp, sqg, sqq, n, q, kp, ctl, ctl + 8, pa, s)) return rc;
     hipLaunchKernelGGL(pf_thr_kernel, dim3((unsigned)((q + 3) / 4)), dim3(256), 0, s, gm, (int64_t)1, q, 1, 1, qnrm, qres, ctl, metric, (int)d, kp, nkb, thr, out_eps);
     SE_LAUNCH_CHECK();

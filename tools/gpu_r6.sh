@@ -8,6 +8,12 @@ export SEHIP_LIB=${SEHIP_LIB:-$PWD/semantic-embeddings_amd/sehip/variants/libseh
 log=gpurun_out/r6_$stage.log
 : > $log
 case $stage in
+topk6)
+  unset SEHIP_LIB
+  timeout 1800 python -m pytest tests/test_gpu_topk.py -x -q -m gpu 2>&1 | tail -3 >> $log
+  timeout 300 python tools/fuzz_topk.py --seconds 90 2>&1 | tail -2 >> $log
+  timeout 600 python tools/bench_kernels.py fused 2>&1 | grep -v amdgpu.ids >> $log
+  ;;
 hprec)
   unset SEHIP_LIB
   timeout 1200 python -m pytest tests/test_gpu_dropin.py -x -q -m gpu 2>&1 | tail -3 >> $log
