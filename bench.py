@@ -55,6 +55,9 @@ RANK_LDS_FLOOR_CYCLES_PER_KEY_TWO_PASS = 43300.0 / 50000.0
 RANK_LDS_FLOOR_CYCLES_PER_KEY_IMAGE = (43300.0 + 784 * 3.5 + 784 * 5.9 + 196 * 3.5) / 50000.0
 MFMA_F16_PEAK_TFLOPS = 2500.0   # dense fp16 = bf16 peak (MI355X_MICROARCH.md)
 SHADER_CLOCK_GHZ = 2.4
+# what the chip SUSTAINS under the retrieval kernels (GRBM_GUI_ACTIVE / duration, profiles/r05_pmc_rank_pdist.txt: 1.9 - 2.13 GHz): the LDS
+# floor of the ranking kernel is reported at both clocks -- at 2.4 GHz it is a floor the chip cannot reach
+SUSTAINED_CLOCK_GHZ = 2.1
 N_CUS = 256
 
 
@@ -395,6 +398,9 @@ def bench_retrieval(args, rank, world):
                           "frac_of_floor": pd_floor / pms},
         "rank_rows": {"ms": rms, "algorithmic_GB": rk_bytes / 1e9, "GBps": rk_bytes / 1e6 / rms, "frac_hbm": rk_bytes / 1e6 / rms / HBM_PEAK_GBS,
                       "lds_floor_ms": rk_lds_floor_ms, "frac_of_lds_floor": rk_lds_floor_ms / rms,
+                      "lds_floor_ms_sustained_clock": rk_lds_floor_ms * SHADER_CLOCK_GHZ / SUSTAINED_CLOCK_GHZ,
+                      "frac_of_lds_floor_sustained_clock": rk_lds_floor_ms * SHADER_CLOCK_GHZ / SUSTAINED_CLOCK_GHZ / rms,
+                      "sustained_clock_GHz": SUSTAINED_CLOCK_GHZ,
                       "variant": "two lossless passes (window)" if two_pass else ("image path: two passes on a 24-bit image + tag scan + repair" if image else "three passes"),
                       "lds_floor": ("2-pass LSD radix on 24 significant key bits, 10" if two_pass else
                                     ("2-pass LSD radix on a 24-bit image + tag write / read + scan, 12.25" if image else "3-pass LSD radix, 17.25")) +
@@ -411,6 +417,7 @@ def bench_retrieval(args, rank, world):
     if dominant == "rank_rows":
         roofline["lds_floor_ms"] = rk_lds_floor_ms
         roofline["frac_of_lds_floor"] = rk_lds_floor_ms / rms
+        roofline["frac_of_lds_floor_sustained_clock"] = rk_lds_floor_ms * SHADER_CLOCK_GHZ / SUSTAINED_CLOCK_GHZ / rms
     else:
         roofline["floor_ms"] = pd_floor
         roofline["frac_of_floor"] = pd_floor / pms
@@ -466,6 +473,76 @@ def bench_metrics(args, rk, reps=3):
     ms = float(np.median(ts))
     return {"ms": ms, "queries": int(q), "ranks_per_query": int(n), "Mranks_per_sec": q * n / ms / 1e3, "rank_GBps": 4.0 * q * n / ms / 1e6,
             "metrics": "P@1..250 (WUP, LCS), whole-list AHP (WUP, LCS), AP; 100 classes", "finite": bool(torch.isfinite(res).all().item())}
+
+
+def bench_guaranteed_order(args, q=8192, reps=3):
+    """The headline's stable order rests on a probed hardware property (gfx950's LDS serves same-address returning adds in lane
+    order: include/sehip.h, se_rank_rows_init).  This leg times the ranking WITHOUT it -- a child process with SE_RANK_SAFE=1, the
+    ballot kernels every device can run -- on q cosine rows of the benchmark's shape, once, outside the timed region, and scales the
+    time to the step's row count."""
+    import subprocess
+    code = (
+        "import sys, json, numpy as np, torch\n"
+        "sys.path[:0] = %r\n"
+        "import sehip\n"
+        "n, d, q, reps = %d, %d, %d, %d\n"
+        "x = torch.from_numpy(np.random.default_rng(0).standard_normal((n, d)).astype(np.float32)).cuda()\n"
+        "sehip.normalize_rows_(x)\n"
+        "pd = sehip.pairwise_dist(x[:q], x, metric=sehip.METRIC_COSINE)\n"
+        "rk = torch.empty((q, n), dtype=torch.int32, device='cuda')\n"
+        "sehip.rank_rows(pd, out=rk); torch.cuda.synchronize()\n"
+        "ts = []\n"
+        "for _ in range(reps):\n"
+        "    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)\n"
+        "    a.record(); sehip.rank_rows(pd, out=rk); b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b))\n"
+        "print(json.dumps({'ms': float(np.median(ts)), 'violations': int(sehip.rank_rows_check(pd, rk))}))\n"
+    ) % ([os.path.join(ROOT, "semantic-embeddings_amd"), ROOT], args.n, args.d, min(q, args.q or args.n), reps)
+    env = dict(os.environ, SE_RANK_SAFE="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=600)
+    got = json.loads(res.stdout.strip().splitlines()[-1])
+    rows = min(q, args.q or args.n)
+    return {"rows_timed": rows, "ms_rows_timed": got["ms"], "order_guard_violations": got["violations"],
+            "ms_scaled_to_step": got["ms"] * (args.q or args.n) / rows,
+            "what": "se_rank_rows with SE_RANK_SAFE=1 (guaranteed-order ballot kernels, no reliance on the LDS lane order), child process"}
+
+
+def bench_eval_e2e(args, reps=2):
+    """What evaluate_retrieval.py's main() does per --feat file, end to end in wall time: features on the host -> device, distances,
+    full ranking, hierarchical precision (P@1..250, whole-list AHP, AP) of every query on the CIFAR-100 hierarchy of the golden
+    fixtures -> the averages back on the host.  Both branches of the CLI (--norm yes / the Euclidean default).  The reference's own
+    stages for the same input on the survey host: BASELINE.md section 2 (distance + ranking 166.5 s, metrics ~0.6 h)."""
+    from class_hierarchy import ClassHierarchy
+    import tempfile
+    g = np.load(os.path.join(ROOT, "tests", "golden", "hierarchy_cifar.npz"))
+    with tempfile.NamedTemporaryFile("w", suffix=".txt", delete=False) as f:
+        for p_, c_ in g["edges"]:
+            f.write("%d %d\n" % (p_, c_))
+    h = ClassHierarchy.from_file(f.name, id_type=int)
+    os.unlink(f.name)
+    rng = np.random.default_rng(0)
+    classes = sorted(set(g["labels"].tolist()))
+    n, d = args.n, args.d
+    labels = [classes[i] for i in rng.integers(0, len(classes), size=n)]
+    centers = rng.standard_normal((max(classes) + 1, d)).astype(np.float32)
+    feats = (centers[labels] + 0.8 * rng.standard_normal((n, d))).astype(np.float32)
+    ks = list(range(1, 251))
+    out = {"items": n, "dim": d, "metrics": "P@1..250 (WUP, LCS_HEIGHT), whole-list AHP, AP; CIFAR-100 hierarchy",
+           "reference_host_stages": "BASELINE.md section 2: distance + ranking 166.5 s, hierarchical_precision ~0.6 h (8 vCPU survey host)"}
+    for name, norm in (("cosine", True), ("euclid", False)):
+        h.hierarchical_precision_device(feats[:4096].copy(), labels[:4096], ks, compute_ahp=True, compute_ap=True, normalize=norm, per_query=False)
+        ts = []
+        for _ in range(reps + 1):        # the first full-size call allocates the whole-matrix tile cache (reported separately)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            avg, _ = h.hierarchical_precision_device(feats.copy(), labels, ks, compute_ahp=True, compute_ap=True, normalize=norm, per_query=False)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        out[name] = {"first_call_s": ts[0], "wall_s": float(np.median(ts[1:])), "AHP_WUP": float(avg["AHP (WUP)"]), "AP": float(avg["AP"])}
+    import evaluate_retrieval
+    evaluate_retrieval.release_tile_cache()
+    return out
 
 
 def bench_rank_long_rows(args, reps=3, q=8192, n=100000):
@@ -837,6 +914,10 @@ def main(argv=None):
                 out[name] = {"error": "%s: %s" % (type(e).__name__, e)}
 
         leg("hierarchical_precision", lambda: bench_metrics(args, rk))
+        if rank == 0 and world == 1 and "error" not in out and args.metric == "cosine":
+            leg("guaranteed_order", lambda: bench_guaranteed_order(args))
+            if "kernels" in out and "error" not in out.get("guaranteed_order", {"error": 1}):
+                out["kernels"]["rank_rows"]["guaranteed_order_ms"] = out["guaranteed_order"]["ms_scaled_to_step"]
         if rank == 0 and world == 1 and not args.no_cpu_baseline:      # reported baseline: rank 0 at N = 1 only, bounded sample; it also
             leg("cpu_baseline", lambda: cpu_baseline_retrieval(args, feats_h, rk))   # compares rk with the host ranks
         del rk
@@ -845,6 +926,9 @@ def main(argv=None):
         torch.cuda.empty_cache()
         leg("rank_long_rows", lambda: bench_rank_long_rows(args))
         torch.cuda.empty_cache()
+        if rank == 0 and world == 1:
+            leg("eval_e2e", lambda: bench_eval_e2e(args))
+            torch.cuda.empty_cache()
         if args.with_sharded:
             leg("sharded_gallery", lambda: bench_sharded_gallery(args, rank, world))
             torch.cuda.empty_cache()
