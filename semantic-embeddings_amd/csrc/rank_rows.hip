@@ -447,15 +447,19 @@ constexpr int RR_TWO_OUT = 256;
 // the key order; below c / 2 the subtraction saturates at 0), again in two 12-bit passes -- and then REPAIRED: keys that share an
 // image (~1.3 % of a 50,000-column cosine row: the image's ulp is c 2^-24 below c and c 2^-23 above it) sit next to each other in index
 // order after the stable sort, and only their true (key, index) order can differ.  To SEE equal images at the final positions the low 8
-// image bits travel through pass 0 and are scattered as a one-byte TAG next to the index in pass 1 (8 instead of 12 random LDS
-// operations per key); a linear scan of the tags finds the maximal runs of equal tags (every block of equal images is inside one;
-// 1 / 256 of the other neighbours are false positives, which the repair leaves in place because their keys are in order), the runs
-// go to a worklist, and one thread per run gathers the true keys from the row (L2 / Infinity Cache) and puts the run into canonical
-// order.  A row with a run above RR_IMG_RUN entries, a full worklist, or keys the image cannot take (NaN, infinities, all zero) is
+// image bits are written as a one-byte TAG per COLUMN before the passes (tag plane, column order: consecutive lanes, consecutive
+// bytes -- a linear write under the image arithmetic); after the last pass the tag of final position i is tagb[xbuf[i]]: a scan reads
+// the indices in 16-byte groups, gathers their tags (one random byte read per key: 8 instead of 12 random LDS operations per key in
+// all) and finds the neighbours with equal tags (every block of equal images is inside such a run; 1 / 256 of the other neighbours
+// are false positives, which the repair leaves in place because their keys are in order); the pairs go to a worklist, and the owner
+// of a run's first pair gathers the true keys from the row (L2 / Infinity Cache) and puts the run into canonical order.  (Tags
+// scattered to the FINAL positions instead -- through a third exchange in round 5, from a bucket-start bitmap in round 6 -- were
+// built twice and lost both times: tools/experiments/README.md.)  A row with a run above RR_IMG_RUN entries, a full worklist, or keys the image cannot take (NaN, infinities, all zero) is
 // sorted again by the same workgroup one LEVEL further down: level 0 = the tight image (c half as large: the bulk of a cosine row
 // spreads over twice as many most significant digits -- fewer lanes of a wave step on one counter, fewer 2-byte scatters into the
 // same dword -- and half as many keys share an image; the keys beyond its range saturate at the ends: 8.0 -> 7.75 ms), level 1 = the
-// image that holds every key, level 2 = the three passes; the workgroup backs off from a level it had to give up for a while.
+// image whose range holds every key of the row (keys below -c / 2 still saturate at image 0 and are repaired like any run: time, not
+// correctness), level 2 = the three passes; the workgroup backs off from a level it had to give up for a while.
 constexpr int RR_IMG_RUN = 8;          // longest run the repair sorts (entries)
 constexpr int RR_IMG_WL = 3072;        // worklist entries (run start | length << 16)
 constexpr int RR_IMG_MAX_ITEMS = 98;   // instantiations above this have no room for tags + worklist next to the exchange buffer

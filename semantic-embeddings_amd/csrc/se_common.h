@@ -18,7 +18,7 @@ int fail(int code, const char *fmt, ...);
 // event on their stream behind each phase.  Off (the default): one relaxed atomic load per mark.
 void phase_mark(const char *name, hipStream_t s);
 bool phase_timing_on();
-void phase_note_counters(const unsigned *dev_counters, long long rows);   // se_retrieve_topk: where its 4 statistics words live
+void phase_note_counters(const unsigned *dev_counters, long long rows, hipStream_t s);   // se_retrieve_topk: its 4 statistics words, copied on stream s into a library-owned pinned buffer
 
 #define SE_HIP_CHECK(expr)                                                                     \
     do {                                                                                       \

@@ -13,7 +13,9 @@ static int pt_n = 0;
 static hipEvent_t pt_ev[PT_CAP];
 static bool pt_ev_made[PT_CAP];
 static const char *pt_name[PT_CAP];
-static const unsigned *pt_counters = nullptr;
+static unsigned *pt_host = nullptr;            // pinned, library-owned: the 4 statistics words of the last se_retrieve_topk, copied on ITS stream
+static hipEvent_t pt_cnt_ev;                   // ... recorded behind that copy
+static bool pt_cnt_made = false, pt_cnt_valid = false;
 static long long pt_rows = 0;
 
 bool phase_timing_on() { return pt_on.load(std::memory_order_relaxed) != 0; }
@@ -31,12 +33,23 @@ void phase_mark(const char *name, hipStream_t s)
     pt_name[pt_n++] = name;
 }
 
-void phase_note_counters(const unsigned *dev_counters, long long rows)
+// The statistics words live in the CALLER's workspace, which may be freed or reused before se_phase_timing_read runs (round-5
+// advisor finding: the read used to copy from that pointer): they are copied here, on the call's own stream, into a pinned buffer
+// the library owns.
+void phase_note_counters(const unsigned *dev_counters, long long rows, hipStream_t s)
 {
     if (!phase_timing_on()) return;
     std::lock_guard<std::mutex> lk(pt_mu);
-    pt_counters = dev_counters;
+    pt_cnt_valid = false;
+    if (!pt_host && hipHostMalloc((void **)&pt_host, 4 * sizeof(unsigned), hipHostMallocDefault) != hipSuccess) { pt_host = nullptr; return; }
+    if (!pt_cnt_made) {
+        if (hipEventCreate(&pt_cnt_ev) != hipSuccess) return;
+        pt_cnt_made = true;
+    }
+    if (hipMemcpyAsync(pt_host, dev_counters, 4 * sizeof(unsigned), hipMemcpyDeviceToHost, s) != hipSuccess) return;
+    if (hipEventRecord(pt_cnt_ev, s) != hipSuccess) return;
     pt_rows = rows;
+    pt_cnt_valid = true;
 }
 
 char *err_buf()
@@ -64,7 +77,7 @@ extern "C" int se_phase_timing(int on)
 {
     std::lock_guard<std::mutex> lk(se::pt_mu);
     se::pt_n = 0;
-    se::pt_counters = nullptr;
+    se::pt_cnt_valid = false;
     se::pt_on.store(on ? 1 : 0, std::memory_order_relaxed);
     return SE_OK;
 }
@@ -72,6 +85,7 @@ extern "C" int se_phase_timing(int on)
 extern "C" int se_phase_timing_read(const char **names_host, float *ms_host, int cap, int64_t *counters_host)
 {
     std::lock_guard<std::mutex> lk(se::pt_mu);
+    struct Reset { ~Reset() { se::pt_n = 0; se::pt_cnt_valid = false; } } reset_on_every_exit;   // (also when a HIP call below fails)
     int out = 0;
     if (se::pt_n > 0) SE_HIP_CHECK(hipEventSynchronize(se::pt_ev[se::pt_n - 1]));
     for (int i = 1; i < se::pt_n && out < cap; i++) {
@@ -83,13 +97,11 @@ extern "C" int se_phase_timing_read(const char **names_host, float *ms_host, int
     }
     if (counters_host) {
         counters_host[0] = counters_host[1] = counters_host[2] = counters_host[3] = counters_host[4] = -1;
-        if (se::pt_counters) {
-            unsigned h[4];
-            SE_HIP_CHECK(hipMemcpy(h, se::pt_counters, sizeof(h), hipMemcpyDeviceToHost));
-            for (int i = 0; i < 4; i++) counters_host[i] = (int64_t)h[i];
+        if (se::pt_cnt_valid) {
+            SE_HIP_CHECK(hipEventSynchronize(se::pt_cnt_ev));
+            for (int i = 0; i < 4; i++) counters_host[i] = (int64_t)se::pt_host[i];
             counters_host[4] = (int64_t)se::pt_rows;
         }
     }
-    se::pt_n = 0;
     return out;
 }

@@ -1532,7 +1532,6 @@ static int retrieve_topk_prefilter(const float *queries, int64_t ldq, const floa
         phase_mark("filter", s);
         const bool verbose = kTuning && tuning_env("SE_TOPK_VERBOSE");
         const bool count = verbose || phase_timing_on();               // [2..3] of nflag: entries recomputed exactly / candidates, summed over the queries
-        phase_note_counters(nflag, rows);
 
         const int64_t rgrid = (rows + RF_WAVES - 1) / RF_WAVES < 8192 ? (rows + RF_WAVES - 1) / RF_WAVES : 8192;
 #define SE_RF_LAUNCH(M, V, LR) hipLaunchKernelGGL((pf_refine_kernel<M, V, LR>), dim3((unsigned)rgrid), dim3(RF_WAVES * 64), 0, s, lists, spill_lists, L.nsub, rowcnt, L.cap, L.parts, rows, thr, eps, qs, ldq, \
@@ -1578,6 +1577,7 @@ static int retrieve_topk_prefilter(const float *queries, int64_t ldq, const floa
                                rows, (int)n, (int)d, kbs, col_offset, k, P, (int)((lds_sel + 15) & ~(size_t)15), scratch, out_d + q0 * k, out_i + q0 * k, nflag);
         SE_LAUNCH_CHECK();
         phase_mark("fallback", s);
+        phase_note_counters(nflag, rows, s);      // final by now (refinement + exact fallback have been enqueued): copied on this stream
     }
     return SE_OK;
 }

@@ -5,6 +5,7 @@ PyTorch only provides device memory, streams and autograd plumbing.  Reference c
 the cvjena/semantic-embeddings checkout.
 """
 import ctypes
+import os
 
 import torch
 
@@ -79,12 +80,26 @@ def cosine_loss_backward(x, labels, embedding, grad_loss_i=None, grad_scale=1.0,
     return dx
 
 
+def _check_loss_inputs(labels, embedding, what):
+    """The loss kernels gather ``embedding[label]`` with the label CLAMPED to [0, C - 1] (a device kernel cannot raise the IndexError
+    the reference's ``embedding[y]`` gather would), and they return no gradient for the class-embedding table (it is a precomputed
+    constant in the reference: learn_image_embeddings.py:48-50).  ``SEHIP_CHECK_LABELS=1`` validates the labels on the host
+    (one synchronising min / max per call: a debugging aid); a table that asks for a gradient is refused always."""
+    if embedding.requires_grad:
+        raise SehipError("%s: the class-embedding table is a constant of this loss (no gradient is computed for it); detach() it" % what)
+    if os.environ.get("SEHIP_CHECK_LABELS"):
+        lo, hi = int(labels.min()), int(labels.max())
+        if lo < 0 or hi >= embedding.shape[0]:
+            raise IndexError("%s: labels span [%d, %d] but the embedding table has %d rows" % (what, lo, hi, embedding.shape[0]))
+
+
 class _CosineEmbeddingLoss(torch.autograd.Function):
     """Per-sample loss_i = 1 - <l2norm(x_i), E[y_i]> with the HIP forward/backward; also returns
     the normalised features the forward kernel produces anyway (non-differentiable by-product)."""
 
     @staticmethod
     def forward(ctx, x, labels, embedding, want_xhat):
+        _check_loss_inputs(labels, embedding, "cosine_embedding_loss")
         x = x if x.stride(-1) == 1 else x.contiguous()
         xhat, _, loss_i, _ = cosine_loss_forward(x, labels, embedding, want_xhat=want_xhat)
         ctx.save_for_backward(x, labels, embedding)
@@ -151,6 +166,7 @@ def sqdist_loss_backward(x, labels, embedding, grad_loss_i=None, grad_scale=1.0,
 class _SquaredDistanceLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, labels, embedding):
+        _check_loss_inputs(labels, embedding, "squared_distance_loss")
         x = x if x.stride(-1) == 1 else x.contiguous()
         loss_i, _, _ = sqdist_loss_forward(x, labels, embedding)
         ctx.save_for_backward(x, labels, embedding)

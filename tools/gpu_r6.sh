@@ -189,7 +189,7 @@ pmc)
   ;;
 alltests)
   unset SEHIP_LIB
-  timeout 3400 python -m pytest tests -x -q -m gpu >> $log 2>&1
+  timeout 3400 python -m pytest tests -x -q -m gpu 2>&1 | tail -5 >> $log
   ;;
 fuzz)
   unset SEHIP_LIB
