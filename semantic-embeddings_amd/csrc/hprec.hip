@@ -408,6 +408,10 @@ __global__ __launch_bounds__(HP_THREADS, SE_HP_WAVES_PER_SIMD) void hprec_kernel
                         }                                            // independent additions instead of a second dependent chain
                         tr[u] = __popc(rel[u]);
                     }
+                    // the rank registers are free again: the NEXT chunk's ranks are requested here, in front of the scans and the barrier
+                    // (behind the barrier, as in round 5, they had half a chunk to arrive in and the look-ups waited for HBM)
+#pragma unroll
+                    for (int u = 0; u < NQ; u++) load_ranks(r[u][SLOT], rrow[u], i0 + HP_PF * HP_CHUNK, last_pos);
                     if (FAST) HP_T(2)
                     // ---- workgroup exclusive scan of the thread totals: DPP inside the wave, wave totals through LDS ----
                     double iw[NQ], il[NQ];
@@ -426,7 +430,6 @@ __global__ __launch_bounds__(HP_THREADS, SE_HP_WAVES_PER_SIMD) void hprec_kernel
                     int cr[NQ];
 #pragma unroll
                     for (int u = 0; u < NQ; u++) {
-                        load_ranks(r[u][SLOT], rrow[u], i0 + HP_PF * HP_CHUNK, last_pos);
                         cw[u] = car_w[u] + (iw[u] - tw[u]); cl[u] = car_l[u] + (il[u] - tl[u]);     // sums BEFORE this thread's first element
                         cr[u] = car_r[u] + (ir[u] - tr[u]);
 #pragma unroll
