@@ -236,7 +236,9 @@ int se_pairwise_dist(const float *a, int64_t lda, const float *b, int64_t ldb, c
  * under the canonical order (distance ascending, index ascending; NaN last; -0 == +0).
  * Replaces: `ranking = np.argsort(pdist, axis = -1)`              evaluate_retrieval.py:67
  * (the reference's sort is unstable: ties are returned in canonical order here).
- *   rank: int32 [q, n] when idx64 == 0, int64 [q, n] (NumPy's dtype) otherwise.
+ *   rank: int32 [q, n] when idx64 == 0, int64 [q, n] (NumPy's dtype) when idx64 == 1, uint16 [q, n] when idx64 == 2 (rows of at
+ *   most 53,248 columns only -- SE_ERR_UNSUPPORTED otherwise: the width the register-resident kernel holds its ranks in; half the
+ *   bytes for se_hierarchical_precision_r16 to read).  ldr in elements of that type.
  *   workspace: se_rank_rows_workspace_bytes(q, n) bytes of device memory, 16-byte aligned.  n <= 53,248: one workgroup sorts a row in registers
  *   (4.4 KB of workspace: probe / guard words); 53,248 < n <= 425,984: 2, 4 or 8 segments of a row are sorted the same way into
  *   runs and merged pairwise (merge tree; up to 3 GB of run planes / level buffers for a chunk of rows at a time); longer rows:
@@ -361,6 +363,14 @@ int se_hierarchical_precision(const int32_t *rank, int64_t ldr, int64_t q, int64
                               const double *rcp, int64_t rcp_len,
                               const int32_t *ks, int nk, int64_t ahp_len, int want_ap, double *out,
                               int64_t ldo, void *order_ws, se_stream_t stream);
+/* The same for rankings of uint16 gallery indices (se_rank_rows with idx64 == 2; gallery <= 65,536): identical results, half the
+ * ranking bytes to read.  Replaces the same lines of class_hierarchy.py:211-316. */
+int se_hierarchical_precision_r16(const uint16_t *rank, int64_t ldr, int64_t q, int64_t list_len,
+                                  const int32_t *cls, int64_t gallery, const int32_t *qcls, const int32_t *qidx,
+                                  const double *wup, const double *lcs, int num_classes,
+                                  const double *rcp, int64_t rcp_len,
+                                  const int32_t *ks, int nk, int64_t ahp_len, int want_ap, double *out,
+                                  int64_t ldo, void *order_ws, se_stream_t stream);
 
 /*
  * The best-possible curves of se_hierarchical_precision, pre-divided and laid out for its loads.

@@ -14,6 +14,8 @@ imported reference).
 """
 import types
 
+import os
+
 import numpy as np
 
 _trapz = getattr(np, "trapezoid", None) or np.trapz
@@ -303,6 +305,7 @@ class ClassHierarchy(object):
         from sharded_retrieval import shard_bounds, sharded_topk
         kernels = dict(kernels or {})
         native_metrics = 'hierarchical_precision' not in kernels
+        native_ranking = 'ranking_tiles' not in kernels
         if 'ranking_tiles' not in kernels or 'hierarchical_precision' not in kernels:
             import sehip
             from evaluate_retrieval import ranking_tiles
@@ -381,7 +384,11 @@ class ClassHierarchy(object):
         else:
             args_d = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (wup_t, lcs_t)] + [best_w, best_l]
             extra = curves(args_d)      # once per gallery, shared by every tile
-            for r0, tile in kernels['ranking_tiles'](feats, normalize, tile_rows=tile_rows, queries=(q0, q1), kblocks=kblocks):
+            # (16-bit ranks between the two kernels -- ranking_tiles(idx16=True), se_hierarchical_precision_r16 -- give the same results
+            # from half the bytes, but measured at 50k x 50k the ranking gains 0.24 ms and the metric kernel, which is not bound by its
+            # rank stream, loses 0.41 ms to the unpacking: int32 stays the default; SE_EVAL_IDX16=1 switches)
+            tiles_kw = {'idx16': True} if (native_metrics and native_ranking and n <= 53248 and os.environ.get('SE_EVAL_IDX16')) else {}
+            for r0, tile in kernels['ranking_tiles'](feats, normalize, tile_rows=tile_rows, queries=(q0, q1), kblocks=kblocks, **tiles_kw):
                 rows = tile.shape[0]
                 outs.append(kernels['hierarchical_precision'](tile, cls_d, cls_d[r0:r0 + rows].contiguous(), qidx_d[r0:r0 + rows].contiguous(),
                                                              *args_d, ks_d, ahp_len=ahp_len, want_ap=compute_ap, **extra))

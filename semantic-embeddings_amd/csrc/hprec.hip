@@ -129,8 +129,9 @@ __global__ __launch_bounds__(HP_THREADS) void hprec_rcp_kernel(const double *__r
 }
 
 // Counting sort of the queries by class (any order inside a class) + the per-XCD cursors of hprec_kernel.
+template <typename RT>
 __global__ __launch_bounds__(HP_ORDER_THREADS) void hprec_order_kernel(const int32_t *__restrict__ qcls, const int32_t *__restrict__ qidx, int64_t Q, int C,
-                                                                       const int32_t *__restrict__ rank, int64_t ldr, int32_t *__restrict__ ws)
+                                                                       const RT *__restrict__ rank, int64_t ldr, int32_t *__restrict__ ws)
 {
     extern __shared__ int hp_hist[];            // [C] class counts -> cursors, then [16] wave totals
     int *s_wt = hp_hist + C;
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(HP_ORDER_THREADS) void hprec_order_kernel(const int
         // flag: 1 = the query is the first entry of its own ranking (normally: its own nearest neighbour), 2 = it is not a gallery item,
         // 0 = its position has to be looked for -- queries of one class with equal non-zero flags are processed two per pass
         const int self = qidx ? qidx[i] : -1;
-        ent[atomicAdd(&hp_hist[c], 1)] = make_int4((int)i, c, self, self < 0 ? 2 : (rank[i * ldr] == self ? 1 : 0));
+        ent[atomicAdd(&hp_hist[c], 1)] = make_int4((int)i, c, self, self < 0 ? 2 : ((int)rank[i * ldr] == self ? 1 : 0));
     }
 }
 
@@ -164,8 +165,9 @@ __global__ __launch_bounds__(HP_ORDER_THREADS) void hprec_order_kernel(const int
 // CLSW: where the class of a ranked gallery item comes from -- 1 / 2: a byte / 16-bit copy of `cls` in LDS, filled once per
 // (persistent) workgroup; 0: gathered from global memory (galleries too large for LDS).  The random 4-byte gather costs a
 // 128-byte L2 -> L1 line per rank, 32x the ranking itself, and was what bounded the kernel before the LDS copy.
-template <int CLSW>
-__global__ __launch_bounds__(HP_THREADS, SE_HP_WAVES_PER_SIMD) void hprec_kernel(const int32_t *__restrict__ rank, int64_t ldr, int64_t Q, int64_t L,
+// RT: element type of the rankings -- int32_t, or uint16_t (se_rank_rows with idx64 == 2: one 16-byte load brings a thread's 8 ranks)
+template <int CLSW, typename RT>
+__global__ __launch_bounds__(HP_THREADS, SE_HP_WAVES_PER_SIMD) void hprec_kernel(const RT *__restrict__ rank, int64_t ldr, int64_t Q, int64_t L,
                                                               const int32_t *__restrict__ cls, int64_t gallery,
                                                               const int32_t *__restrict__ qcls, const int32_t *__restrict__ qidx,
                                                               const double *__restrict__ wup, const double *__restrict__ lcs, int C,
@@ -294,7 +296,7 @@ __global__ __launch_bounds__(HP_THREADS, SE_HP_WAVES_PER_SIMD) void hprec_kernel
         // once and used for both.  Everything per query (ranks, sums, accumulators, end points, output row) is an array over u.
         auto run = [&](auto nq_c, const int64_t (&qq)[2], const int32_t (&selfq)[2], const int qc, const int qpos_known) {
             constexpr int NQ = decltype(nq_c)::value;
-            const int32_t *rrow[NQ];
+            const RT *rrow[NQ];
             double *orow[NQ];
 #pragma unroll
             for (int u = 0; u < NQ; u++) { rrow[u] = rank + qq[u] * ldr; orow[u] = out + qq[u] * ldo; }
@@ -302,16 +304,26 @@ __global__ __launch_bounds__(HP_THREADS, SE_HP_WAVES_PER_SIMD) void hprec_kernel
             // The ranks a thread owns in a chunk are requested HP_PF chunks ahead (HP_PF register sets, refilled right after the barrier of
             // the chunk that consumed them).
             int r[NQ][HP_PF][HP_ITEMS];
-            auto load_ranks = [&](int (&dst)[HP_ITEMS], const int32_t *row, int at, int bound) {
+            auto load_ranks = [&](int (&dst)[HP_ITEMS], const RT *row, int at, int bound) {
                 if (vec_ok && at + HP_ITEMS <= bound) {
+                    if constexpr (sizeof(RT) == 2) {
+                        static_assert(HP_ITEMS % 8 == 0, "16-byte loads of 16-bit ranks");
+#pragma unroll
+                        for (int v = 0; v < HP_ITEMS / 8; v++) {
+                            const uint4 a = *reinterpret_cast<const uint4 *>(row + at + 8 * v);
+                            dst[8 * v] = (int)(a.x & 0xFFFFu); dst[8 * v + 1] = (int)(a.x >> 16); dst[8 * v + 2] = (int)(a.y & 0xFFFFu); dst[8 * v + 3] = (int)(a.y >> 16);
+                            dst[8 * v + 4] = (int)(a.z & 0xFFFFu); dst[8 * v + 5] = (int)(a.z >> 16); dst[8 * v + 6] = (int)(a.w & 0xFFFFu); dst[8 * v + 7] = (int)(a.w >> 16);
+                        }
+                    } else {
 #pragma unroll
                     for (int v = 0; v < HP_ITEMS / 4; v++) {
                         const int4 a = *reinterpret_cast<const int4 *>(row + at + 4 * v);
                         dst[4 * v] = a.x; dst[4 * v + 1] = a.y; dst[4 * v + 2] = a.z; dst[4 * v + 3] = a.w;
                     }
+                    }
                 } else {
 #pragma unroll
-                    for (int e = 0; e < HP_ITEMS; e++) dst[e] = (at + e < bound) ? row[at + e] : 0;
+                    for (int e = 0; e < HP_ITEMS; e++) dst[e] = (at + e < bound) ? (int)row[at + e] : 0;
                 }
             };
 #pragma unroll
@@ -320,7 +332,7 @@ __global__ __launch_bounds__(HP_THREADS, SE_HP_WAVES_PER_SIMD) void hprec_kernel
                 for (int p = 0; p < HP_PF; p++) load_ranks(r[u][p], rrow[u], tid * HP_ITEMS + p * HP_CHUNK, lp_bound);
             const int32_t self = selfq[0];
             int32_t first = 0;
-            if (NQ == 1 && qpos_known < 0) first = rrow[0][0];
+            if (NQ == 1 && qpos_known < 0) first = (int32_t)rrow[0][0];
             for (int c = tid; c < C; c += HP_THREADS) s_sim[c] = make_double2(wup[(int64_t)qc * C + c], lcs[(int64_t)qc * C + c]);
             if (tid == 0) *s_qpos = (qpos_known >= 0) ? qpos_known : ((self >= 0 && first == self) ? 0 : 0x7FFFFFFF);
             if (tid < 4 * NQ) s_ends[tid] = 0.0;
@@ -331,7 +343,7 @@ __global__ __launch_bounds__(HP_THREADS, SE_HP_WAVES_PER_SIMD) void hprec_kernel
 #pragma unroll
                     for (int e = 0; e < 4; e++) {
                         const int64_t i = b0 + e * HP_THREADS + tid;
-                        if (i < L && rrow[0][i] == self) atomicMin(s_qpos, (int)i);
+                        if (i < L && (int32_t)rrow[0][i] == self) atomicMin(s_qpos, (int)i);
                     }
                     wg_barrier();
                     const int found = *s_qpos;      // read into a register BEFORE the second barrier: a fast wave must not start the next
@@ -583,21 +595,23 @@ namespace se {
 
 struct HpLaunch { int clsw; size_t lds; int grid; };
 
-template <int CLSW>
+template <int CLSW, typename RT>
 static hipError_t hp_occupancy(size_t lds, int *blocks_per_cu)
 {
-    hipError_t e = hipFuncSetAttribute((const void *)hprec_kernel<CLSW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void *)hprec_kernel<CLSW, RT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, hprec_kernel<CLSW>, HP_THREADS, lds);
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(blocks_per_cu, hprec_kernel<CLSW, RT>, HP_THREADS, lds);
 }
 
 }  // namespace se
 
-extern "C" int se_hierarchical_precision(const int32_t *rank, int64_t ldr, int64_t q, int64_t list_len, const int32_t *cls, int64_t gallery,
-                                         const int32_t *qcls, const int32_t *qidx, const double *wup, const double *lcs,
-                                         int num_classes, const double *rcp, int64_t rcp_len, const int32_t *ks, int nk, int64_t ahp_len, int want_ap,
-                                         double *out, int64_t ldo, void *order_ws, se_stream_t stream)
+template <typename RT>
+static int hp_run(const RT *rank, int64_t ldr, int64_t q, int64_t list_len, const int32_t *cls, int64_t gallery,
+                  const int32_t *qcls, const int32_t *qidx, const double *wup, const double *lcs,
+                  int num_classes, const double *rcp, int64_t rcp_len, const int32_t *ks, int nk, int64_t ahp_len, int want_ap,
+                  double *out, int64_t ldo, void *order_ws, se_stream_t stream)
 {
+    if (sizeof(RT) == 2 && gallery > 65536) return fail(SE_ERR_INVALID, "se_hierarchical_precision_r16: a gallery of %lld items does not fit 16-bit ranks", (long long)gallery);
     if (q < 0 || list_len <= 0 || gallery <= 0 || num_classes <= 0 || nk < 0 || nk > HP_MAX_KS || q > 0x7FFFFFFF || list_len > 0x7FFFFFFF - 2 * HP_CHUNK)
         return fail(SE_ERR_INVALID, "se_hierarchical_precision: bad shape q=%lld len=%lld gallery=%lld classes=%d nk=%d", (long long)q,
                     (long long)list_len, (long long)gallery, num_classes, nk);
@@ -618,26 +632,26 @@ extern "C" int se_hierarchical_precision(const int32_t *rank, int64_t ldr, int64
     const size_t lds = fixed + (clsw == 1 ? tab8 : clsw == 2 ? tab16 : 0);
     hipStream_t s = (hipStream_t)stream;
     int per_cu = 0, dev = 0, cus = 0;
-    SE_HIP_CHECK(clsw == 1 ? hp_occupancy<1>(lds, &per_cu) : clsw == 2 ? hp_occupancy<2>(lds, &per_cu) : hp_occupancy<0>(lds, &per_cu));
+    SE_HIP_CHECK(clsw == 1 ? (hp_occupancy<1, RT>(lds, &per_cu)) : clsw == 2 ? (hp_occupancy<2, RT>(lds, &per_cu)) : (hp_occupancy<0, RT>(lds, &per_cu)));
     SE_HIP_CHECK(hipGetDevice(&dev));
     SE_HIP_CHECK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     if (per_cu < 1) per_cu = 1;
     int32_t *ws = static_cast<int32_t *>(order_ws);
     const size_t order_lds = (size_t)(num_classes + HP_ORDER_THREADS / WAVE) * sizeof(int);
     if (ws) {
-        SE_HIP_CHECK(hipFuncSetAttribute((const void *)hprec_order_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)order_lds));
+        SE_HIP_CHECK(hipFuncSetAttribute((const void *)hprec_order_kernel<RT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)order_lds));
         if (reinterpret_cast<uintptr_t>(ws) % 16 != 0) return fail(SE_ERR_INVALID, "se_hierarchical_precision: order_ws must be 16-byte aligned");
-        hipLaunchKernelGGL(hprec_order_kernel, dim3(1), dim3(HP_ORDER_THREADS), order_lds, s, qcls, qidx, q, num_classes, rank, ldr, ws);
+        hipLaunchKernelGGL(hprec_order_kernel<RT>, dim3(1), dim3(HP_ORDER_THREADS), order_lds, s, qcls, qidx, q, num_classes, rank, ldr, ws);
         SE_LAUNCH_CHECK();
     }
     // persistent workgroups (the class table is loaded once each): as many as are resident at once
     const int64_t resident = (int64_t)per_cu * cus;
     const int64_t grid = q < resident ? q : resident;
-    const int vec_ok = (ldr % 4 == 0) && (reinterpret_cast<uintptr_t>(rank) % 16 == 0);
+    const int vec_ok = ((ldr * (int64_t)sizeof(RT)) % 16 == 0) && (reinterpret_cast<uintptr_t>(rank) % 16 == 0);
     const double2 *rc = reinterpret_cast<const double2 *>(rcp);
     const int64_t ldc = 2 * se_hprec_curve_len(rcp_len);
 #define SE_HP_LAUNCH(W)                                                                                                                  \
-    hipLaunchKernelGGL(hprec_kernel<W>, dim3((unsigned)grid), dim3(HP_THREADS), lds, s, rank, ldr, q, list_len, cls, gallery, qcls, qidx, \
+    hipLaunchKernelGGL((hprec_kernel<W, RT>), dim3((unsigned)grid), dim3(HP_THREADS), lds, s, rank, ldr, q, list_len, cls, gallery, qcls, qidx, \
                        wup, lcs, num_classes, rc, ldc, ks, nk, ahp_len, want_ap, out, ldo, ws, vec_ok)
     if (clsw == 1) SE_HP_LAUNCH(1);
     else if (clsw == 2) SE_HP_LAUNCH(2);
@@ -659,4 +673,20 @@ extern "C" int se_hierarchical_precision(const int32_t *rank, int64_t ldr, int64
     }
 #endif
     return SE_OK;
+}
+
+extern "C" int se_hierarchical_precision(const int32_t *rank, int64_t ldr, int64_t q, int64_t list_len, const int32_t *cls, int64_t gallery,
+                                         const int32_t *qcls, const int32_t *qidx, const double *wup, const double *lcs,
+                                         int num_classes, const double *rcp, int64_t rcp_len, const int32_t *ks, int nk, int64_t ahp_len, int want_ap,
+                                         double *out, int64_t ldo, void *order_ws, se_stream_t stream)
+{
+    return hp_run<int32_t>(rank, ldr, q, list_len, cls, gallery, qcls, qidx, wup, lcs, num_classes, rcp, rcp_len, ks, nk, ahp_len, want_ap, out, ldo, order_ws, stream);
+}
+
+extern "C" int se_hierarchical_precision_r16(const uint16_t *rank, int64_t ldr, int64_t q, int64_t list_len, const int32_t *cls, int64_t gallery,
+                                             const int32_t *qcls, const int32_t *qidx, const double *wup, const double *lcs,
+                                             int num_classes, const double *rcp, int64_t rcp_len, const int32_t *ks, int nk, int64_t ahp_len, int want_ap,
+                                             double *out, int64_t ldo, void *order_ws, se_stream_t stream)
+{
+    return hp_run<uint16_t>(rank, ldr, q, list_len, cls, gallery, qcls, qidx, wup, lcs, num_classes, rcp, rcp_len, ks, nk, ahp_len, want_ap, out, ldo, order_ws, stream);
 }

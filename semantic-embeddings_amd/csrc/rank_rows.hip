@@ -1253,6 +1253,19 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
             RR_STREAM_PLANE(2, row)
         } else if (!write_out) {
             // image path given up: nothing to write, the row is sorted again
+        } else if (idx64 == 2) {
+            // uint16 ranks (rows of at most 65,536 columns: what the exchange buffer holds already): 16 bytes = 8 ranks per lane and step,
+            // straight from LDS -- half the bytes of the int32 form for the kernel that reads them (se_hierarchical_precision_r16)
+            uint16_t *o = (uint16_t *)rank + row * ldr;
+            _Pragma("unroll 2") for (int j = wt * 8; j < N; j += RR_THREADS * 8) {
+                if (vec_ok && j + 7 < N) {
+                    const rr_i32x4 v = *reinterpret_cast<const rr_i32x4 *>(xbuf + j);
+                    if (SE_RR_NT) __builtin_nontemporal_store(v, reinterpret_cast<rr_i32x4 *>(o + j));
+                    else *reinterpret_cast<rr_i32x4 *>(o + j) = v;
+                } else {
+                    for (int e = 0; e < 8 && j + e < N; e++) o[j + e] = xbuf[j + e];
+                }
+            }
         } else if (idx64) {
             int64_t *o = (int64_t *)rank + row * ldr;
             // (the next row's keys are live: no unrolling, the LDS read of the next step is issued before this step's stores instead)
@@ -1339,6 +1352,9 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
 }  // namespace se
 
 using namespace se;
+
+// index width code of se_rank_rows / se_rank_rows_check (`idx64`): 0 = int32, 1 = int64, 2 = uint16 (register-resident rows only)
+static size_t rank_idx_bytes(int idx) { return idx == 2 ? 2 : (idx ? 8 : 4); }
 
 static int rank_grid(int64_t q)
 {
@@ -1433,7 +1449,7 @@ static int launch_rank_reg_variant(const float *pdist, int64_t ldp, int64_t q, i
     if (res.err != hipSuccess) return fail(SE_ERR_HIP, "se_rank_rows: kernel set-up failed: %s", hipGetErrorString(res.err));
     int64_t grid = res.grid;
     if (grid > q) grid = q;
-    const size_t esz = idx64 ? 8 : 4;
+    const size_t esz = rank_idx_bytes(idx64);
     const int vec_ok = ((((uintptr_t)rank) & 15) == 0) && ((ldr * esz) % 16 == 0);
     unsigned long long *prof = nullptr;
     if (profile && ITEMS == 98) {
@@ -1872,7 +1888,7 @@ __global__ __launch_bounds__(RR_THREADS) void rank_order_probe_kernel(uint32_t *
 // violation makes the whole call fall back; under SE_RANK_CHECK=1 every row of every call is checked and only the offending
 // rows are redone; se_rank_rows_check audits any ranking in full (bench.py reports its verdict outside the timed region).
 constexpr int RC_THREADS = 512, RC_PER = 8;
-template <bool IDX64>
+template <int IDX64>   // index width code: 0 int32, 1 int64, 2 uint16
 __global__ __launch_bounds__(RC_THREADS) void rank_check_kernel(const float *__restrict__ pdist, int64_t ldp, int64_t Q, int N, const void *rank,
                                                                int64_t ldr, uint32_t *__restrict__ bad, int cap, int64_t row_stride)
 {
@@ -1888,7 +1904,8 @@ __global__ __launch_bounds__(RC_THREADS) void rank_check_kernel(const float *__r
             for (int e = 0; e <= RC_PER; e++) {            // RC_PER consecutive ranks + the first of the next thread's
                 const int r = r0 + e;
                 if (r >= N) break;
-                const int64_t iv = IDX64 ? ((const int64_t *)rank)[row * ldr + r] : (int64_t)((const int32_t *)rank)[row * ldr + r];
+                const int64_t iv = IDX64 == 2 ? (int64_t)((const uint16_t *)rank)[row * ldr + r]
+                                              : (IDX64 ? ((const int64_t *)rank)[row * ldr + r] : (int64_t)((const int32_t *)rank)[row * ldr + r]);
                 const bool in = iv >= 0 && iv < N;
                 const uint32_t i = in ? (uint32_t)iv : 0u;
                 const uint32_t k = canon_key(drow[i]);
@@ -1914,7 +1931,8 @@ __global__ void rank_inject_kernel(void *rank, int idx64, int64_t ldr, int64_t Q
     const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 7 + 3;
     if (row >= Q || N < 4) return;
     const int r = (int)((row * 37) % (N - 1));
-    if (idx64) { int64_t *p = (int64_t *)rank + row * ldr + r; const int64_t t = p[0]; p[0] = p[1]; p[1] = t; }
+    if (idx64 == 2) { uint16_t *p = (uint16_t *)rank + row * ldr + r; const uint16_t t = p[0]; p[0] = p[1]; p[1] = t; }
+    else if (idx64) { int64_t *p = (int64_t *)rank + row * ldr + r; const int64_t t = p[0]; p[0] = p[1]; p[1] = t; }
     else { int32_t *p = (int32_t *)rank + row * ldr + r; const int32_t t = p[0]; p[0] = p[1]; p[1] = t; }
 }
 
@@ -1925,8 +1943,9 @@ static int rank_check_launch(const float *pdist, int64_t ldp, int64_t q, int n, 
     SE_HIP_CHECK(hipMemsetAsync(bad, 0, 4, s));
     const int64_t nrows = (q + row_stride - 1) / row_stride;
     const int64_t grid = nrows < 2048 ? nrows : 2048;
-    if (idx64) hipLaunchKernelGGL(rank_check_kernel<true>, dim3((unsigned)grid), dim3(RC_THREADS), 0, s, pdist, ldp, q, n, rank, ldr, bad, cap, row_stride);
-    else hipLaunchKernelGGL(rank_check_kernel<false>, dim3((unsigned)grid), dim3(RC_THREADS), 0, s, pdist, ldp, q, n, rank, ldr, bad, cap, row_stride);
+    if (idx64 == 2) hipLaunchKernelGGL(rank_check_kernel<2>, dim3((unsigned)grid), dim3(RC_THREADS), 0, s, pdist, ldp, q, n, rank, ldr, bad, cap, row_stride);
+    else if (idx64) hipLaunchKernelGGL(rank_check_kernel<1>, dim3((unsigned)grid), dim3(RC_THREADS), 0, s, pdist, ldp, q, n, rank, ldr, bad, cap, row_stride);
+    else hipLaunchKernelGGL(rank_check_kernel<0>, dim3((unsigned)grid), dim3(RC_THREADS), 0, s, pdist, ldp, q, n, rank, ldr, bad, cap, row_stride);
     SE_LAUNCH_CHECK();
     return SE_OK;
 }
@@ -2091,6 +2110,9 @@ extern "C" int se_rank_rows(const float *pdist, int64_t ldp, int64_t q, int64_t 
     if (q < 0 || n < 0 || n > 0x7FFFFFFFll) return fail(SE_ERR_INVALID, "se_rank_rows: bad shape q=%lld n=%lld", (long long)q, (long long)n);
     if (q == 0 || n == 0) return SE_OK;
     if (!pdist || !rank || ldp < n || ldr < n) return fail(SE_ERR_INVALID, "se_rank_rows: bad argument");
+    if (idx64 < 0 || idx64 > 2) return fail(SE_ERR_INVALID, "se_rank_rows: index width code %d (0 int32, 1 int64, 2 uint16)", idx64);
+    if (idx64 == 2 && (n > RR_MAX_N || rank_use_tiled(n)))
+        return fail(SE_ERR_UNSUPPORTED, "se_rank_rows: uint16 ranks are written by the register-resident kernel only (rows of at most %d columns)", RR_MAX_N);
     hipStream_t s = (hipStream_t)stream;
     if (!rank_use_tiled(n)) {
         const int items = (int)((n + RR_THREADS - 1) / RR_THREADS);
@@ -2141,7 +2163,7 @@ extern "C" int se_rank_rows(const float *pdist, int64_t ldp, int64_t q, int64_t 
 #undef SE_RR_CASE
         }
         SE_HIP_CHECK(hipMemcpy(h + 1, bad + 1, nbad * sizeof(uint32_t), hipMemcpyDeviceToHost));
-        const size_t esz = idx64 ? 8 : 4;
+        const size_t esz = rank_idx_bytes(idx64);
         for (uint32_t i = 0; i < nbad; i++) {
             const int64_t row = h[1 + i];
             void *rrow = (char *)rank + (size_t)row * (size_t)ldr * esz;
@@ -2220,6 +2242,7 @@ extern "C" int se_rank_rows_check(const float *pdist, int64_t ldp, int64_t q, in
     if (bad_rows_host) *bad_rows_host = 0;
     if (q == 0 || n == 0) return SE_OK;
     if (!pdist || !rank || ldp < n || ldr < n || !bad_rows_host) return fail(SE_ERR_INVALID, "se_rank_rows_check: bad argument");
+    if (idx64 < 0 || idx64 > 2 || (idx64 == 2 && n > 65536)) return fail(SE_ERR_INVALID, "se_rank_rows_check: index width code %d for %lld columns", idx64, (long long)n);
     if (!workspace || workspace_bytes < se_rank_rows_check_workspace_bytes()) return fail(SE_ERR_WORKSPACE, "se_rank_rows_check: workspace too small");
     hipStream_t s = (hipStream_t)stream;
     uint32_t *bad = (uint32_t *)workspace;

@@ -132,7 +132,7 @@ def _cached_rows(kind, rows, n, dtype, device):
 
 
 def ranking_tiles(features, normalize=False, tile_rows=None, idx64=False, queries=None, kblocks=None, whole_if_fits=True,
-                  prenormalized=False):
+                  prenormalized=False, idx16=False):
     """Generator over ``(first_row, rank_tile)`` with ``rank_tile`` an int32 (int64 if ``idx64``)
     DEVICE tensor ``[rows, N]``: the canonical ranking of queries ``first_row .. first_row+rows``.
     **A tile is valid until the next one is drawn**: distances and ranks live in grow-only per-device buffers that every tile and
@@ -143,6 +143,8 @@ def ranking_tiles(features, normalize=False, tile_rows=None, idx64=False, querie
     (``prenormalized``: the caller already did that -- normalising twice would change bits.)
     ``queries`` optionally restricts the query rows to ``range(*queries)``; ``kblocks`` (None | 'openblas' | list) makes
     the FMA chain restart per K block like the host BLAS the reference ran on (see ``host_blas_kblocks``).
+    ``idx16``: uint16 ranks as an int16 tensor (galleries of at most 53,248 items; what ``hierarchical_precision_device`` asks
+    for: half the bytes between the ranking and the metric kernel).
     ``whole_if_fits`` (default since round 6): rank all queries as ONE tile when distances + ranks (8 N^2 bytes) fit into a third of
     the device memory that is free or already held by the tile cache -- all-pairs then takes the symmetric distance kernel
     (3.2 instead of 5.4 ms at 50k x 50k), i.e. the kernels bench.py times.  The first call on a device pays for the two
@@ -167,13 +169,13 @@ def ranking_tiles(features, normalize=False, tile_rows=None, idx64=False, querie
             extra_ws = max(0, sehip.rank_rows_workspace_bytes(q1 - q0, n) - sehip.workspace_bytes(features.device))
             key = features.device.index if features.device.index is not None else torch.cuda.current_device()
             held = sum(int(b.numel()) for b in _tile_cache.get(key, {}).values())
-            need = (4 + (8 if idx64 else 4)) * n * (q1 - q0)
+            need = (4 + (2 if idx16 else (8 if idx64 else 4))) * n * (q1 - q0)
             if need + extra_ws <= (torch.cuda.mem_get_info(features.device)[0] + held) // 3:
                 tile_rows = max(tile_rows, q1 - q0)
     rows_max = min(tile_rows, max(q1 - q0, 1))
     if features.is_cuda:
         pd = _cached_rows('pd', rows_max, n, torch.float32, features.device)
-        rk = _cached_rows('rk', rows_max, n, torch.int64 if idx64 else torch.int32, features.device)
+        rk = _cached_rows('rk', rows_max, n, torch.int16 if idx16 else (torch.int64 if idx64 else torch.int32), features.device)
     else:   # (CPU stand-ins of the tests never get here: the kernels need a device)
         pd = sehip.empty_rows(rows_max, n, torch.float32, features.device)
         rk = None
@@ -181,7 +183,7 @@ def ranking_tiles(features, normalize=False, tile_rows=None, idx64=False, querie
         rows = min(tile_rows, q1 - r0)
         sehip.pairwise_dist(features[r0:r0 + rows], features, metric=metric,
                             sqa=None if sq is None else sq[r0:r0 + rows], sqb=sq, kblocks=kblocks, out=pd[:rows])
-        yield r0, sehip.rank_rows(pd[:rows], idx64=idx64, out=None if rk is None else rk[:rows])
+        yield r0, sehip.rank_rows(pd[:rows], idx64=idx64, idx16=idx16, out=None if rk is None else rk[:rows])
 
 
 def pairwise_retrieval(features, normalize=False, return_generator=True, kblocks=None):

@@ -27,7 +27,7 @@ EXPORTS = (
     "se_row_sqnorm", "se_normalize_rows", "se_pairwise_dist",
     "se_rank_rows_workspace_bytes", "se_rank_rows", "se_rank_rows_init_workspace_bytes", "se_rank_rows_init", "se_rank_rows_check_workspace_bytes", "se_rank_rows_check",
     "se_topk_rows", "se_topk_merge", "se_topk_merge_packed",
-    "se_retrieve_topk_workspace_bytes", "se_retrieve_topk", "se_hierarchical_precision",
+    "se_retrieve_topk_workspace_bytes", "se_retrieve_topk", "se_hierarchical_precision", "se_hierarchical_precision_r16",
     "se_hprec_order_workspace_bytes", "se_hprec_curve_len", "se_hprec_reciprocal_curves",
 )
 
@@ -97,6 +97,7 @@ def lib():
                                    ctypes.POINTER(ctypes.c_int32), c_int, vp, c_i64, vp]
     L.se_hierarchical_precision.argtypes = [vp, c_i64, c_i64, c_i64, vp, c_i64, vp, vp, vp, vp, c_int, vp, c_i64, vp, c_int,
                                             c_i64, c_int, vp, c_i64, vp, vp]
+    L.se_hierarchical_precision_r16.argtypes = L.se_hierarchical_precision.argtypes
     L.se_hprec_order_workspace_bytes.argtypes = [c_i64]
     L.se_hprec_order_workspace_bytes.restype = c_i64
     L.se_hprec_curve_len.argtypes = [c_i64]

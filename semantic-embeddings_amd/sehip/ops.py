@@ -483,18 +483,35 @@ def rank_rows_workspace_bytes(q, n):
     return int(lib().se_rank_rows_workspace_bytes(int(q), int(n)))
 
 
-def rank_rows(pdist, idx64=False, out=None):
-    """Canonical ``np.argsort(pdist, axis=-1)`` (evaluate_retrieval.py:67): (distance, index) ascending."""
+RANK_U16_MAX_N = 53248     # rows the register-resident ranking kernel takes: the only ones it writes 16-bit ranks for
+
+
+def _rank_width_code(t):
+    """Index width code of se_rank_rows / se_rank_rows_check for a rank tensor: int32 -> 0, int64 -> 1, int16 (the BIT PATTERN of
+    uint16 gallery indices: torch has no full uint16) -> 2."""
+    if t.dtype == torch.int32:
+        return 0
+    if t.dtype == torch.int64:
+        return 1
+    if t.dtype == torch.int16:
+        return 2
+    raise SehipError("ranks must be int32, int64 or int16 (uint16 bit patterns), not %s" % t.dtype)
+
+
+def rank_rows(pdist, idx64=False, out=None, idx16=False):
+    """Canonical ``np.argsort(pdist, axis=-1)`` (evaluate_retrieval.py:67): (distance, index) ascending.
+    ``idx16``: uint16 ranks (returned as an int16 tensor holding their bit patterns; rows of at most 53,248 columns) -- half the
+    bytes for ``hierarchical_precision`` to read."""
     require_gpu(pdist, out)
     _f32_rows(pdist, "pdist")
     if (pdist.device.index if pdist.device.index is not None else torch.cuda.current_device()) not in _rank_ready:
         rank_rows_init(pdist.device)
     q, n = pdist.shape
     if out is None:
-        out = empty_rows(q, n, torch.int64 if idx64 else torch.int32, pdist.device)
+        out = empty_rows(q, n, torch.int16 if idx16 else (torch.int64 if idx64 else torch.int32), pdist.device)
     need = lib().se_rank_rows_workspace_bytes(q, n)
     ws = _workspace(need, pdist.device)
-    check(lib().se_rank_rows(ptr(pdist), pdist.stride(0), q, n, ptr(out), int(out.dtype == torch.int64),
+    check(lib().se_rank_rows(ptr(pdist), pdist.stride(0), q, n, ptr(out), _rank_width_code(out),
                              out.stride(0), ptr(ws), ws.numel(), stream_ptr()), "se_rank_rows")
     return out
 
@@ -504,12 +521,12 @@ def rank_rows_check(pdist, rank):
     adjacent entries can tell -- 0 for every output of ``rank_rows``.  Synchronises the stream."""
     require_gpu(pdist, rank)
     _f32_rows(pdist, "pdist")
-    if rank.dtype not in (torch.int32, torch.int64) or rank.stride(1) != 1 or rank.shape != pdist.shape:
-        raise SehipError("rank must be an int32 / int64 matrix of pdist's shape with contiguous rows")
+    if rank.dtype not in (torch.int32, torch.int64, torch.int16) or rank.stride(1) != 1 or rank.shape != pdist.shape:
+        raise SehipError("rank must be an int32 / int64 / int16 (uint16 bit patterns) matrix of pdist's shape with contiguous rows")
     q, n = pdist.shape
     ws = torch.empty((int(lib().se_rank_rows_check_workspace_bytes()),), dtype=torch.uint8, device=pdist.device)
     bad = ctypes.c_int64(0)
-    check(lib().se_rank_rows_check(ptr(pdist), pdist.stride(0), q, n, ptr(rank), int(rank.dtype == torch.int64), rank.stride(0),
+    check(lib().se_rank_rows_check(ptr(pdist), pdist.stride(0), q, n, ptr(rank), _rank_width_code(rank), rank.stride(0),
                                    ptr(ws), ws.numel(), ctypes.byref(bad), stream_ptr()), "se_rank_rows_check")
     return int(bad.value)
 
@@ -624,8 +641,8 @@ def hierarchical_precision(rank, cls, qcls, qidx, wup, lcs, best_wup, best_lcs, 
     lists of 4096 ranks and more, where it pays for the counting sort.
     Returns f64 [Q, 2 nk + 3]: P@k (WUP), P@k (LCS_HEIGHT), AHP (WUP), AHP (LCS_HEIGHT), AP."""
     require_gpu(rank, cls, qcls, wup, lcs, best_wup, best_lcs, ks)
-    if rank.dtype != torch.int32 or rank.stride(1) != 1:
-        raise SehipError("rank must be int32 with contiguous rows")
+    if rank.dtype not in (torch.int32, torch.int16) or rank.stride(1) != 1:
+        raise SehipError("rank must be int32 (or int16: the uint16 bit patterns rank_rows(idx16=True) writes) with contiguous rows")
     for t, name in ((cls, "cls"), (qcls, "qcls"), (ks, "ks")):
         if t.dtype != torch.int32 or not t.is_contiguous():
             raise SehipError("%s must be contiguous int32" % name)
@@ -642,8 +659,9 @@ def hierarchical_precision(rank, cls, qcls, qidx, wup, lcs, best_wup, best_lcs, 
     if class_order is None:
         class_order = L >= 4096
     order_ws = torch.empty((int(lib().se_hprec_order_workspace_bytes(Q)),), dtype=torch.uint8, device=rank.device) if class_order else None
-    check(lib().se_hierarchical_precision(ptr(rank), rank.stride(0), Q, L, ptr(cls), cls.numel(), ptr(qcls), ptr(qidx), ptr(wup), ptr(lcs), C,
-                                          ptr(curves.data), curves.list_len, ptr(ks), nk,
-                                          int(ahp_len), int(bool(want_ap)), ptr(out), out.stride(0), ptr(order_ws), stream_ptr()),
+    entry = lib().se_hierarchical_precision_r16 if rank.dtype == torch.int16 else lib().se_hierarchical_precision
+    check(entry(ptr(rank), rank.stride(0), Q, L, ptr(cls), cls.numel(), ptr(qcls), ptr(qidx), ptr(wup), ptr(lcs), C,
+                ptr(curves.data), curves.list_len, ptr(ks), nk,
+                int(ahp_len), int(bool(want_ap)), ptr(out), out.stride(0), ptr(order_ws), stream_ptr()),
           "se_hierarchical_precision")
     return out

@@ -157,6 +157,12 @@ def test_se_hierarchical_precision_general_rankings(n, q, class_order, with_qidx
         want = _hprec_standin(*args, ahp_len=ahp, want_ap=ap).numpy()
         got = sehip.hierarchical_precision(*dev, ahp_len=ahp, want_ap=ap, class_order=class_order).cpu().numpy()
         assert np.abs(got - want).max() <= 1e-10, (ahp, ap, np.abs(got - want).max())
+        if n <= 65536:
+            # the same rankings as uint16 indices (se_hierarchical_precision_r16; int16 tensors hold the bit patterns): the SAME numbers
+            # (only the width of the loads differs; rows that are not 16-byte aligned -- n = 3001 -- take the element loads)
+            dev16 = [dev[0].to(torch.int16)] + dev[1:]
+            got16 = sehip.hierarchical_precision(*dev16, ahp_len=ahp, want_ap=ap, class_order=class_order).cpu().numpy()
+            assert np.array_equal(got16, got), (ahp, ap, np.abs(got16 - got).max())
 
 
 @pytest.mark.gpu

@@ -335,6 +335,32 @@ def test_rank_rows_detector_picks_the_variant_in_subprocess():
     assert seen == {"cos": {"3"}, "euc": {"2"}, "few": {"0"}, "two": {"1"}}, (seen, out.stdout[-2000:])
 
 
+@pytest.mark.parametrize("n", [50000, 40961, 33000, 3001, 70])
+def test_rank_rows_uint16_output(sehip, n):
+    """idx64 == 2 of se_rank_rows: uint16 ranks (int16 tensors hold the bit patterns -- indices above 32,767 read as negative int16)
+    from every variant of the register-resident kernel == the int32 ranks; the order guard reads them; rows above 53,248 columns are
+    refused (SE_ERR_UNSUPPORTED), not silently truncated."""
+    rng = np.random.default_rng(n)
+    rows = [(0.1 * rng.standard_normal(n)).astype(np.float32),                     # cosine-like: image path at long rows
+            (200.0 + 20.0 * rng.standard_normal(n)).astype(np.float32),            # Euclid-like: window path
+            rng.choice(np.array([1.0, 2.0, 3.0, 4.0], dtype=np.float32), size=n),  # few values: plain three passes
+            np.zeros(n, dtype=np.float32)]
+    for base in rows:
+        pd = np.stack([base, base[::-1].copy(), np.roll(base, 17)])
+        d = dev(pd)
+        r32 = sehip.rank_rows(d)
+        r16 = sehip.rank_rows(d, idx16=True)
+        assert r16.dtype == torch.int16
+        assert np.array_equal(r16.cpu().numpy().view(np.uint16).astype(np.int32), r32.cpu().numpy())
+        assert sehip.rank_rows_check(d, r16) == 0
+    # unaligned / strided output: element stores
+    out = torch.empty((3, n + 3), dtype=torch.int16, device="cuda")[:, 1:n + 1]
+    sehip.rank_rows(d, out=out)
+    assert np.array_equal(out.cpu().numpy().view(np.uint16).astype(np.int32), r32.cpu().numpy())
+    with pytest.raises(sehip.SehipError):
+        sehip.rank_rows(torch.zeros((2, 53249), device="cuda"), idx16=True)
+
+
 def test_rank_rows_strided_and_unaligned_output(sehip):
     """Row pitches that are not multiples of 16 bytes (scalar write-out) and a strided input."""
     pdw = gauss(6, 3001, seed=5)

@@ -8,6 +8,46 @@ export SEHIP_LIB=${SEHIP_LIB:-$PWD/semantic-embeddings_amd/sehip/variants/libseh
 log=gpurun_out/r6_$stage.log
 : > $log
 case $stage in
+idx16)
+  unset SEHIP_LIB
+  timeout 1800 python -m pytest tests/test_gpu_retrieval.py tests/test_gpu_dropin.py -x -q -m gpu 2>&1 | tail -4 >> $log
+  timeout 300 python tools/eval_e2e.py 2>&1 | grep -v amdgpu.ids >> $log
+  timeout 300 python tools/eval_e2e.py --euclid 2>&1 | grep -v amdgpu.ids >> $log
+  timeout 300 python - >> $log 2>&1 <<'PY'
+import sys, os, numpy as np, torch
+sys.path[:0] = [os.path.join(os.getcwd(), "semantic-embeddings_amd"), os.getcwd()]
+import sehip
+n = 50000
+x = torch.from_numpy(np.random.default_rng(0).standard_normal((n, 100)).astype(np.float32)).cuda()
+sehip.normalize_rows_(x)
+pd = sehip.pairwise_dist(x, x, metric=sehip.METRIC_COSINE)
+for name, kw, dt in (("int32", {}, torch.int32), ("uint16", {"idx16": True}, torch.int16)):
+    rk = torch.empty((n, n), dtype=dt, device="cuda")
+    sehip.rank_rows(pd, out=rk, **kw); torch.cuda.synchronize()
+    ts = []
+    for _ in range(5):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); sehip.rank_rows(pd, out=rk, **kw); b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b))
+    print("rank_rows %s ranks 50k x 50k: median %.3f ms" % (name, float(np.median(ts))))
+    C = 100
+    rng = np.random.default_rng(1)
+    cls_h = rng.integers(0, C, size=n).astype(np.int32)
+    tab = rng.random((C, C)); tab = (tab + tab.T) / 2; np.fill_diagonal(tab, 1.0)
+    counts = np.bincount(cls_h, minlength=C)
+    best = np.stack([np.cumsum(np.repeat(tab[c][np.argsort(-tab[c], kind="stable")], counts[np.argsort(-tab[c], kind="stable")])) for c in range(C)])
+    cls = torch.from_numpy(cls_h).cuda(); tab_d, best_d = torch.from_numpy(tab).cuda(), torch.from_numpy(best).cuda()
+    qidx = torch.arange(n, dtype=torch.int32, device="cuda"); ks = torch.arange(1, 251, dtype=torch.int32, device="cuda")
+    curves = sehip.hprec_reciprocal_curves(best_d, best_d)
+    run = lambda: sehip.hierarchical_precision(rk, cls, cls, qidx, tab_d, tab_d, best_d, best_d, ks, ahp_len=0, want_ap=True, curves=curves)
+    res = run(); torch.cuda.synchronize()
+    ts = []
+    for _ in range(5):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); run(); b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b))
+    print("hierarchical_precision on %s ranks: median %.3f ms  checksum %.12f" % (name, float(np.median(ts)), float(res.sum())))
+    del rk
+PY
+  ;;
 topk6)
   unset SEHIP_LIB
   timeout 1800 python -m pytest tests/test_gpu_topk.py -x -q -m gpu 2>&1 | tail -3 >> $log
