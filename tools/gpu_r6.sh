@@ -177,9 +177,9 @@ two)
   ;;
 evidence)
   # end-of-round evidence: bench line (both branches), kernel microbenchmarks, rocprofv3 kernel stats of the bench command,
-  # phase profile of the image path.  Output: gpurun_out/r5ev/
+  # phase profile of the image path.  Output: gpurun_out/r6ev/
   unset SEHIP_LIB
-  OUT=gpurun_out/r5ev; mkdir -p $OUT; export TMPDIR=/tmp
+  OUT=gpurun_out/r6ev; mkdir -p $OUT; export TMPDIR=/tmp
   ( timeout 1500 python bench.py --steps 20 --warmup 5 ) > $OUT/bench.json 2> $OUT/bench.err; head -c 300 $OUT/bench.json >> $log; echo >> $log
   ( timeout 900 python bench.py --steps 20 --warmup 5 --metric euclid --no-train --no-sharded --no-cpu-baseline ) > $OUT/bench_euclid.json 2>> $OUT/bench.err
   for what in pdist rank fused shard hprec rownorm; do timeout 400 python tools/bench_kernels.py $what 2>&1 | grep -v amdgpu.ids; done > $OUT/kernels.log 2>&1
@@ -187,7 +187,7 @@ evidence)
   ( SEHIP_LIB=$PWD/semantic-embeddings_amd/sehip/libsehip_tuning.so SE_RANK_PEEL=2 SE_RR_PROFILE=1 timeout 300 python tools/dev_img.py time --reps 1 ) 2>&1 | grep -v amdgpu.ids >> $OUT/rank_phase_profile.txt
   ( timeout 600 python tools/topk_skew.py; timeout 600 python tools/topk_skew.py --n 160146 --q 20000 --d 1000 --classes 125 ) 2>&1 | grep -v amdgpu.ids > $OUT/topk_skew.txt
   cd /tmp
-  rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$OUT/prof -o r5 -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-train > $GRAFT_REPO_ROOT/$OUT/prof.log 2>&1
+  rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/$OUT/prof -o r6 -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-train > $GRAFT_REPO_ROOT/$OUT/prof.log 2>&1
   cd $GRAFT_REPO_ROOT
   DB=$(find $OUT/prof -name "*.db" | head -1)
   [ -n "$DB" ] && python tools/rocprof_summary.py $DB "python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-train" > $OUT/prof_summary.txt
@@ -196,7 +196,7 @@ evidence)
   ;;
 pmcrk)
   # FETCH / WRITE of the ranking kernels only (dev library)
-  OUT=gpurun_out/r5pmc2; mkdir -p $OUT; export TMPDIR=/tmp
+  OUT=gpurun_out/r6pmc2; mkdir -p $OUT; export TMPDIR=/tmp
   for c in FETCH_SIZE WRITE_SIZE; do
     timeout 600 rocprofv3 --pmc $c --output-format csv -d $OUT/p_$c -o x -- python tools/dev_img.py time --reps 2 > $OUT/p_$c.log 2>&1
     find $OUT/p_$c -name "*counter_collection.csv" | head -1 | xargs -I{} python tools/pmc_summary.py {} 2>&1 | grep -A2 "rank_rows_reg_kernel<98, false, true, [23]" >> $log
@@ -208,7 +208,7 @@ pmcrk)
 pmc)
   # PMC counter passes, each in its own rocprofv3 run with no tracing flags (MI355X_MICROARCH.md): the headline kernels
   unset SEHIP_LIB
-  OUT=gpurun_out/r5pmc; mkdir -p $OUT; export TMPDIR=/tmp
+  OUT=gpurun_out/r6pmc; mkdir -p $OUT; export TMPDIR=/tmp
   run_pmc () { # name counters cmd...
     local name=$1; local ctr=$2; shift 2
     timeout 600 rocprofv3 --pmc $ctr --output-format csv -d $OUT/pmc_$name -o $name -- "$@" > $OUT/pmc_$name.log 2>&1
