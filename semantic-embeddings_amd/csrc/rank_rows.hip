@@ -674,6 +674,19 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
         _Pragma("unroll 2") for (; j < RR_THREADS * ITEMS; j += RR_THREADS * 8)                                       \
             *reinterpret_cast<uint4 *>(pl + j) = *reinterpret_cast<const uint4 *>(xbuf + j);                          \
     }
+    // Padding fix-ups of the two-pass paths run on the wave(s) that hold slots behind the row's end -- and the whole workgroup waits
+    // for them at the next barrier.  A row that fills its instantiation to within RR_PADS wave steps (50,000 columns in the 98-key one:
+    // 3 steps) only has such slots in its last RR_PADS steps: those alone are visited (round 6: 98 x 2-3 VALU on one wave per phase).
+    constexpr int RR_PADS = ITEMS < 8 ? ITEMS : 8;
+#define RR_PAD_LOOP(NROW, BODY)                                                                                       \
+    {                                                                                                                 \
+        const int first_pad_ = ((NROW) - wave_s * (ITEMS * WAVE)) >> 6;   /* steps below it hold row positions only (negative: all padding) */ \
+        if (first_pad_ >= ITEMS - RR_PADS) {                                                                          \
+            _Pragma("unroll") for (int s = ITEMS - RR_PADS; s < ITEMS; s++) { BODY }                                  \
+        } else {                                                                                                      \
+            _Pragma("unroll") for (int s = 0; s < ITEMS; s++) { BODY }                                                \
+        }                                                                                                             \
+    }
     if ((int64_t)blockIdx.x < Q) {
         const float *drow = row_ptr(blockIdx.x);
         const int n0 = row_len(blockIdx.x);
@@ -751,8 +764,7 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
                     key[s] = q << 8;
                 }
                 if (wave_s * (ITEMS * WAVE) + ITEMS * WAVE > n_row) {   // wave-uniform: only the wave(s) that hold padding slots
-#pragma unroll
-                    for (int s = 0; s < ITEMS; s++) key[s] = (wpos_ + s * WAVE >= n_row) ? pk_ : key[s];
+                    RR_PAD_LOOP(n_row, key[s] = (wpos_ + s * WAVE >= n_row) ? pk_ : key[s];)
                 }
             } else {
                 RR_CANON(n_row)
@@ -802,8 +814,7 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
                 if (wave_s * (ITEMS * WAVE) + ITEMS * WAVE > n_row) {
                     int32_t lo_b = lo;
                     opaque(lo_b);
-#pragma unroll
-                    for (int s = 0; s < ITEMS; s++) below_l -= (wpos + s * WAVE >= n_row && (int32_t)key[s] < lo_b) ? 1u : 0u;
+                    RR_PAD_LOOP(n_row, below_l -= (wpos + s * WAVE >= n_row && (int32_t)key[s] < lo_b) ? 1u : 0u;)
                 }
             }
             uint32_t below_w = below_l;
@@ -832,8 +843,7 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
                 for (int s = 0; s < ITEMS; s++)
                     key[s] = (uint32_t)rr_clamp_i32(__builtin_elementwise_sub_sat((int32_t)key[s], lo1), 0, 0xFFFFFF) << 8;
                 if (wave_s * (ITEMS * WAVE) + ITEMS * WAVE > n_row) {
-#pragma unroll
-                    for (int s = 0; s < ITEMS; s++) key[s] = (wpos + s * WAVE >= n_row) ? 0xFFFFFF00u : key[s];
+                    RR_PAD_LOOP(n_row, key[s] = (wpos + s * WAVE >= n_row) ? 0xFFFFFF00u : key[s];)
                 }
             } else {
                 RR_CANON(n_row)
