@@ -868,7 +868,10 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
             uint32_t *pcnt = wcnt;              // [RR_WAVES][pcw]
             int pcw = CNT_WORDS;
             if (wide) {
-                wg_barrier();                // every wave has finished reading the exchange buffer (previous pass's key exchange)
+                // every wave has finished reading the exchange buffer (previous pass's key exchange).  The FIRST pass of a two-pass row
+                // needs no barrier of its own: the row's qualification (image path: the maximum search; window path: two reductions) put
+                // one between the previous row's write-out -- the last reader of the buffer -- and this point.
+                if (!(RAWKEYS && two && p == 0)) wg_barrier();
                 pcnt = reinterpret_cast<uint32_t *>(xbuf);
                 pcw = RR_WIDE_WORDS;
             }
