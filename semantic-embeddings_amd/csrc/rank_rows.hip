@@ -796,7 +796,9 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
             for (int off = 32; off > 0; off >>= 1) mxi = max(mxi, __shfl_xor(mxi, off, 64));
             if (lane == 0) stat[wave] = (uint32_t)mxi;
             if (tid == 0) stat[2 * RR_WAVES] = 0;                        // cursor of the list
+            RR_T(9)
             wg_barrier();
+            RR_T(10)
 #pragma unroll
             for (int w = 0; w < RR_WAVES; w++) mxi = max(mxi, (int32_t)stat[w]);
             const int32_t kmax = __builtin_amdgcn_readfirstlane(mxi);
@@ -821,6 +823,7 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
 #pragma unroll
             for (int off = 32; off > 0; off >>= 1) below_w += (uint32_t)__shfl_xor((int)below_w, off, 64);
             if (lane == 0) stat[RR_WAVES + wave] = below_w;
+            RR_T(11)
             wg_barrier();
             uint32_t below = 0;
 #pragma unroll
@@ -849,6 +852,7 @@ __global__ __launch_bounds__(RR_THREADS, RR_THREADS / 256) void rank_rows_reg_ke
                 RR_CANON(n_row)
             }
             // (the first barrier of pass 0 orders these LDS accesses before anything that follows)
+            RR_T(8)
         }
         __builtin_amdgcn_sched_barrier(0);
         {
@@ -1399,11 +1403,26 @@ __global__ __launch_bounds__(256) void rank_skew_detect_kernel(const float *__re
     if (threadIdx.x < 3) { row_max[threadIdx.x] = 0; row_below[threadIdx.x] = 0; }
     wg_barrier();
     const int cols = N < 1024 ? N : 1024;
+    // (round 6: the 12 samples of a thread -- 3 rows x up to 4 columns -- are requested together and kept in registers for both steps:
+    // the kernel used to walk them twice, one global-load round trip after the other: 42 us in front of every ranking call)
+    uint32_t kk[3][4];
+#pragma unroll
     for (int r = 0; r < 3; r++) {
         const int64_t row = (r == 0) ? 0 : (r == 1 ? Q / 2 : Q - 1);
         const float *drow = pdist + row * ldp;
-        for (int i = threadIdx.x; i < cols; i += 256) {
-            const uint32_t k = canon_key(drow[(int64_t)i * N / cols]);
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = threadIdx.x + 256 * u;
+            kk[r][u] = canon_key(drow[(int64_t)(i < cols ? i : 0) * N / cols]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int i = threadIdx.x + 256 * u;
+            if (i >= cols) continue;
+            const uint32_t k = kk[r][u];
             atomicAdd(&hist[k >> shift], 1u);
             if (k != 0xFFFFFFFFu) atomicMax(&row_max[r], k);
             // repeated keys among the first 256 sampled columns of the row (hash buckets: 4096 for 768 keys -- ~70 chance hits): rows made of
@@ -1414,12 +1433,12 @@ __global__ __launch_bounds__(256) void rank_skew_detect_kernel(const float *__re
     wg_barrier();
     // two-pass candidates: (nearly) every sampled key of every sampled row within RR_TWO_SPAN codes of the row's largest one --
     // one sampled key below the window stands for ~N / 1024 in the row; each row checks itself again inside the kernel
+#pragma unroll
     for (int r = 0; r < 3; r++) {
-        const int64_t row = (r == 0) ? 0 : (r == 1 ? Q / 2 : Q - 1);
-        const float *drow = pdist + row * ldp;
         const uint32_t lo = row_max[r] > RR_TWO_SPAN ? row_max[r] - RR_TWO_SPAN : 0u;
-        for (int i = threadIdx.x; i < cols; i += 256)
-            if (canon_key(drow[(int64_t)i * N / cols]) < lo) atomicAdd(&row_below[r], 1u);
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            if (threadIdx.x + 256 * u < cols && kk[r][u] < lo) atomicAdd(&row_below[r], 1u);
     }
     uint32_t mine = 0;
     for (int i = threadIdx.x; i < NBIN; i += 256) mine = hist[i] > mine ? hist[i] : mine;
@@ -1476,12 +1495,12 @@ static int launch_rank_reg_variant(const float *pdist, int64_t ldp, int64_t q, i
         SE_HIP_CHECK(hipStreamSynchronize(s));
         SE_HIP_CHECK(hipMemcpy(h, prof, sizeof(h), hipMemcpyDeviceToHost));
         SE_HIP_CHECK(hipFree(prof));
-        static const char *names[11] = {"load", "rank", "scan", "dest", "idx-write", "idx-read", "key-exchange", "write-out", "image-map", "tag-scan", "repair"};
+        static const char *names[12] = {"load", "rank", "scan", "dest", "idx-write", "idx-read", "key-exchange", "write-out", "image-map|window-map", "tag-scan|window-max", "repair|window-barrier-1", "window-count"};
         double tot = 0;
-        for (int i = 0; i < 11; i++) tot += (double)h[i];
+        for (int i = 0; i < 12; i++) tot += (double)h[i];
         if (tot > 0) {
             fprintf(stderr, "[se_rank_rows profile] ITEMS=%d hw=%d peel=%d grid=%lld:", ITEMS, (int)HW, VAR, (long long)grid);
-            for (int i = 0; i < 11; i++) fprintf(stderr, " %s %.1f%%", names[i], 100.0 * (double)h[i] / tot);
+            for (int i = 0; i < 12; i++) fprintf(stderr, " %s %.1f%%", names[i], 100.0 * (double)h[i] / tot);
             fprintf(stderr, "  (%.0f cycles per row; wave 0 of every workgroup, timestamps behind the phases' own barriers)", tot / (double)q);
             fprintf(stderr, "\n");
         }
